@@ -1,0 +1,258 @@
+/*
+ * pointnet_hip.h -- C ABI of libpointnet_hip.so, the MI355X (gfx950) PointNet hot path.
+ *
+ * The reference (MAPieschl/PointCloudProcessing) is pure Python on TensorFlow/Keras and has no FFI of
+ * its own; the boundary it exposes for this path is the Python module API of
+ *   point_cloud_analysis/pointnet/PointNet.py      (PointNet, TNet, ConvLayer, DenseLayer, PointCloudNormalization)
+ *   point_cloud_analysis/pointcloud/PointCloudSet.py
+ *   point_cloud_analysis/pointnet_train.py
+ * Each entry point below names the reference call site (file:line, relative to
+ * /root/reference/point_cloud_analysis/) whose arithmetic it replaces.  INTEGRATION.md shows the ctypes
+ * binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns PN_OK (0) or a negative pn_status; pn_last_error() gives the text
+ *     (thread-local);
+ *   - the caller owns every buffer: all pointers are DEVICE pointers unless a parameter says "host";
+ *     the library never allocates or frees device memory, keeps no global state, never synchronises
+ *     the host, and only enqueues work on the `stream` it is given (hipStream_t passed as void*), so
+ *     every call is safe to capture into a hipGraph;
+ *   - tensors are row-major and contiguous; point tensors are (B clouds) x (N points) x channels,
+ *     flattened to M = B*N rows; all floating point storage is fp32;
+ *   - `prec` selects the arithmetic of the per-point contractions with K >= 64, which run on the bf16
+ *     MFMA pipe with fp32 accumulation:  PN_PREC_BF16  = operands rounded to bf16 (1 MFMA per product),
+ *     PN_PREC_BF16X3 = operands split hi+lo into two bf16 each, 3 MFMAs per product (16 significant
+ *     bits per operand, ~1e-5 relative).  Everything else (K = 3 layers, per-cloud dense layers,
+ *     statistics, normalisation, losses, optimizer) is fp32 on the vector ALU.
+ */
+#ifndef POINTNET_HIP_H
+#define POINTNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PN_ABI_VERSION 1
+
+typedef enum {
+  PN_OK = 0,
+  PN_ERR_INVALID_ARGUMENT = -1,
+  PN_ERR_LAUNCH = -2,
+  PN_ERR_UNSUPPORTED = -3,
+  PN_ERR_WORKSPACE = -4
+} pn_status;
+
+#define PN_PREC_BF16 1
+#define PN_PREC_BF16X3 3
+
+typedef void* pn_stream; /* hipStream_t */
+
+int pn_abi_version(void);
+const char* pn_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * A "lazy" per-point operand: the value the contraction sees for row m, channel k is
+ *     v = max(lo,  ca[k] * s1[m*ld + k]  +  cb[k] * s2[m*ld + k]  +  cc[k])
+ * with ca/cb/cc optional (NULL => 1, 0, 0) and s2 optional (NULL => term dropped).
+ * This is how training-mode BatchNormalization never costs a pass of its own:
+ *   forward :  s1 = previous layer's pre-BN output z, ca = gamma*rsqrt(var+eps), cc = beta - mean*ca,
+ *              lo = 0  ==>  v = relu(bn(z))                      (PointNet.py:559-562)
+ *   backward:  s1 = dL/dy_hat, s2 = z, (ca,cb,cc) from pn_bn_bwd_finalize  ==>  v = dL/dz through the
+ *              batch statistics.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct pn_operand {
+  const float* s1;
+  const float* s2;
+  const float* ca;
+  const float* cb;
+  const float* cc;
+  int64_t ld; /* elements between consecutive rows of s1/s2 */
+  float lo;   /* lower clamp: 0 for ReLU, -INFINITY for none */
+  int32_t pad_;
+} pn_operand;
+
+/* --- PointCloudNormalization.call  (pointnet/PointNet.py:691-706) --------------------------------
+ * xyz (B,N,3) -> out (B,N,3) = (xyz - centroid) / max(max_n |xyz - centroid|, 1e-7);
+ * centroid (B,3), scale (B) are also returned (the layer's second output). */
+int pn_normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, pn_stream stream);
+
+/* --- ConvLayer with Cin = 3 (1x1 Conv2D, pointnet/PointNet.py:535-542,556; first layer of
+ * input_transform :406 and mlp_1_1 :120).  z[m,:] = x3[m,:] . W[b]  with W (3,C) shared
+ * (w_cloud_stride = 0) or one (3,C) matrix per cloud (w_cloud_stride = 3*C: the 3x3 input transform
+ * tf.matmul(pc, R) of :207 folded into the kernel: (pc.R).W = pc.(R.W)).
+ * Also emits per-row-tile partial sums  part[tile][0][c] = sum z, part[tile][1][c] = sum z^2
+ * (tile = 128 rows of one cloud; n_tiles = B*ceil(N/128)) for the BatchNormalization statistics. */
+int pn_conv3_fwd(const float* x3, const float* w, int64_t w_cloud_stride, int B, int N, int C, float* z,
+                 float* stat_partials, pn_stream stream);
+
+/* weight gradient of the above: slabs[tile][3][C] = sum_rows x3[row,:]^T dz[row,:], dz given lazily */
+int pn_conv3_wgrad(const float* x3, const pn_operand* dz, int B, int N, int C, float* slabs, pn_stream stream);
+
+/* --- ConvLayer forward, Cin in {64..1024}: z = relu(bn(x)) . W, stored pre-BN, plus BN partial sums.
+ * (pointnet/PointNet.py:554-566 for the layer; the lazy operand folds the PREVIOUS layer's BN+ReLU.)
+ *   x        lazy operand over (B*N, K)
+ *   w        (K, C) row-major [Keras kernel (1,1,K,C)]; w_cloud_stride != 0 => one matrix per cloud
+ *            (tf.matmul(X, R_64), PointNet.py:228, is this call with K = C = 64, w = R_64, stride 4096)
+ *   cloud_bias optional (B, C) added per cloud before the statistics (the global-feature half of
+ *            seg_l1's kernel applied to the tiled global vector, PointNet.py:268-275)
+ *   z        (B*N, C) or NULL (no store)
+ *   stat_partials  [n_tiles][2][C] or NULL */
+int pn_conv_fwd(const pn_operand* x, const float* w, int64_t w_cloud_stride, int B, int N, int K, int C,
+                const float* cloud_bias, float* z, float* stat_partials, int prec, pn_stream stream);
+
+/* --- ConvLayer (128 -> 1024) fused with tf.reduce_max(X, axis=1)  (PointNet.py:242-248, 425-429).
+ * Never stores the (B,N,C) tensor.  Because BN (per-channel affine) followed by ReLU is monotone in z
+ * with the sign of gamma, max_n relu(bn(z)) = relu(bn(sgn * max_n(sgn*z))).  Emits per tile
+ *   pmax[tile][c] = max over the tile's rows of sgn[c]*z,  pidx[tile][c] = its row index inside the cloud
+ *   (lowest index on ties), and the same stat_partials as pn_conv_fwd. */
+int pn_conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C, const float* sgn,
+                    float* pmax, int32_t* pidx, float* stat_partials, int prec, pn_stream stream);
+
+/* --- data gradient of a ConvLayer: out = [relu-mask] (dz . W^T + addend), plus the two partial sums
+ * BatchNormalization's backward needs (sum dy_hat, sum dy_hat*z) per channel.
+ *   dz      lazy operand over (B*N, K)   (K = the layer's output width)
+ *   w       (C, K) row-major             (C = the layer's input width; i.e. the Keras kernel as stored)
+ *   addend  optional (B*N, C) added before masking (second consumer of the same activation)
+ *   zmask/msc/msh  optional: previous layer's pre-BN z and its BN scale/shift; mask = (msc*z+msh > 0)
+ *   stat_partials  [n_tiles][2][C] or NULL */
+int pn_conv_bwd_data(const pn_operand* dz, const float* w, int64_t w_cloud_stride, int B, int N, int K, int C,
+                     const float* addend, const float* zmask, const float* msc, const float* msh, float* out,
+                     float* stat_partials, int prec, pn_stream stream);
+
+/* --- weight gradient / Gram matrix: slabs[s][i][j] = sum over the slab's rows of a[row,i]*b[row,j].
+ * slab_rows must be a multiple of 64; slabs are per cloud: n_slabs = B*ceil(N/slab_rows).  Reduce with
+ * pn_slab_reduce (fixed order => bitwise reproducible). */
+int pn_conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, int Cj, int slab_rows,
+                  float* slabs, int prec, pn_stream stream);
+
+/* out[g][e] = sum_{s < per_group} slabs[g*per_group + s][e],  e < elems;  groups = n_slabs/per_group */
+int pn_slab_reduce(const float* slabs, int n_slabs, int per_group, int64_t elems, float* out, pn_stream stream);
+
+/* --- BatchNormalization statistics -> coefficients (keras BatchNormalization, PointNet.py:528,559;
+ * momentum 0.99, eps 1e-3, biased variance).
+ * training statistics (use_batch_stats=1): reduces stat_partials [n_tiles][2][C] over `count` rows,
+ *   writes mean, invstd = rsqrt(var+eps), scale = gamma*invstd, shift = beta - mean*scale, sgn = sign(scale)
+ *   and (update_moving=1) moving <- momentum*moving + (1-momentum)*batch, in place.
+ * inference statistics (use_batch_stats=0; training=False or a frozen layer, PointNet.py:585-591): the same
+ *   coefficients from the moving statistics. */
+int pn_bn_finalize(const float* stat_partials, int n_tiles, int C, int64_t count, const float* gamma,
+                   const float* beta, float* moving_mean, float* moving_var, float momentum, float eps,
+                   int use_batch_stats, int update_moving, float* mean, float* invstd, float* scale, float* shift,
+                   pn_stream stream);
+
+/* backward of the same: from partial sums (sum dy_hat, sum dy_hat*z) builds dgamma, dbeta and the lazy
+ * coefficients (ca, cb, cc) with dz = ca*dy_hat + cb*z + cc.  batch_stats=0 (frozen / inference BN):
+ * ca = gamma*invstd, cb = cc = 0 and no dgamma/dbeta. */
+int pn_bn_bwd_finalize(const float* stat_partials, int n_tiles, int C, int64_t count, const float* gamma,
+                       const float* mean, const float* invstd, int batch_stats, float* dgamma, float* dbeta,
+                       float* ca, float* cb, float* cc, pn_stream stream);
+
+/* sgn[c] = +1 if gamma[c] >= 0 else -1 */
+int pn_sign(const float* gamma, int C, float* sgn, pn_stream stream);
+
+/* --- finish tf.reduce_max: reduce pmax/pidx over each cloud's tiles and apply BN+ReLU.
+ *   g[b][c] = relu(scale*zstar + shift), zstar[b][c] = sgn*max, arg[b][c] = row index in the cloud */
+int pn_max_finalize(const float* pmax, const int32_t* pidx, int B, int tiles_per_cloud, int C, const float* sgn,
+                    const float* scale, const float* shift, float* g, float* zstar, int32_t* arg, pn_stream stream);
+
+/* --- farthest point sampling (no counterpart in the reference; build-defined spec):
+ * per cloud, start at `start_idx`, repeatedly take the point with the largest squared distance (fp32,
+ * d = dx*dx + dy*dy + dz*dz evaluated left to right without fma contraction) to the selected set, ties ->
+ * lowest index.  idx_out (B, M) int32 in selection order; mindist (B, N), optional, receives the final distance of
+ * every point to the selected set.  workspace: pn_fps_workspace_bytes(B, N) bytes; its first int32 is an error flag
+ * (non-zero if a multi-block cloud timed out waiting for a peer block). */
+size_t pn_fps_workspace_bytes(int B, int N);
+int pn_fps(const float* xyz, int B, int N, int M, int start_idx, int32_t* idx_out, float* mindist, void* workspace,
+           size_t workspace_bytes, pn_stream stream);
+
+/* --- voxel-grid downsample (no counterpart in the reference; build-defined spec): key = floor((p-origin)/leaf)
+ * per axis (int32, must lie in [0, 2^21)), voxels ordered by ascending (kz, ky, kx); per voxel the centroid
+ * (fp64 accumulation in point-index order, rounded to fp32), the point count and the majority label (ties ->
+ * lowest label).  n_out is a device int32.  workspace: pn_voxel_workspace_bytes(N). */
+size_t pn_voxel_workspace_bytes(int N);
+int pn_voxel_downsample(const float* xyz, const int32_t* labels, int N, const float* leaf3_host,
+                        const float* origin3_host, int n_labels, float* centroids, int32_t* counts,
+                        int32_t* majority, int32_t* n_out, void* workspace, size_t workspace_bytes, pn_stream stream);
+
+
+/* ================================================================================================
+ * Whole-model entry points: PointNet.call (pointnet/PointNet.py:197-292) forward and its backward,
+ * sequenced natively on one stream.  Parameters live in ONE flat fp32 buffer (and gradients in a second
+ * buffer of the same layout) so that data-parallel training all-reduces a single contiguous range.
+ * ============================================================================================== */
+typedef struct pn_model_desc {
+  int32_t ccls;     /* classification_output_width  (PointNet.py:86)  */
+  int32_t cseg;     /* segmentation_output_width    (PointNet.py:87), <= 16 */
+  int32_t vanilla;  /* PointNet.py:91: no T-Nets, R = I */
+  int32_t reg_in;   /* regularize_input_transform   (PointNet.py:92)  */
+  int32_t reg_feat; /* regularize_feature_transform (PointNet.py:93)  */
+  int32_t prec;     /* PN_PREC_* */
+  float dropout_rate; /* PointNet.py:88 (0.3 in pointnet_train.py:301) */
+  float bn_momentum;  /* 0.99 (PointNet.py:502) */
+  float bn_eps;       /* 1e-3 (keras default)   */
+} pn_model_desc;
+
+/* one named range of the flat parameter buffer.  kind: 0 kernel, 1 gamma, 2 beta, 3 moving_mean,
+ * 4 moving_var, 5 bias, 6 T-Net w, 7 T-Net b.  block: index into the 15 trainability blocks
+ * (input_transform, mlp_1_1, mlp_1_2, feature_transform, mlp_2_1, mlp_2_2, mlp_2_3, mlp_cls_1..3, mlp_seg_1..5). */
+typedef struct pn_slot_info {
+  char name[64];
+  int64_t offset; /* in floats */
+  int32_t rows, cols, kind, block;
+} pn_slot_info;
+
+#define PN_NUM_BLOCKS 15
+
+typedef struct pn_model_io {
+  const float* pc; /* (B, N, 3) */
+  int32_t B, N;
+  float* params;            /* flat parameters (moving statistics are updated in place when training) */
+  float* grads;             /* flat gradients, same layout (NULL for inference) */
+  const uint8_t* trainable; /* HOST array of PN_NUM_BLOCKS flags (layer.trainable, PointNet.py:294-342); NULL = all */
+  int32_t training;         /* keras `training` argument */
+  int32_t pad_;
+  const uint8_t* keep1; /* dropout keep masks (B,512) / (B,256), 1 = keep; NULL = no dropout */
+  const uint8_t* keep2;
+  /* optional fused loss (pointnet_train.py:334-345): labels (B) / (B*N) int32, se3 target (B,3,3) */
+  const int32_t* labels_cls;
+  const int32_t* labels_seg;
+  const float* se3;
+  float loss_weights[3]; /* classification, segmentation, rotation */
+  float pad2_;
+  float* out_cls; /* (B, ccls) softmax  */
+  float* out_seg; /* (B*N, cseg) softmax */
+  float* out_R;   /* (B, 3, 3) or NULL  */
+  /* 16 device floats: [0] sum of classification NLL, [1] #correct classes, [2] sum of per-point NLL,
+   * [3] #correct points, [4] sum (R - se3)^2, [5] input-transform regulariser, [6] feature-transform regulariser */
+  float* scalars;
+  void* workspace;
+  size_t workspace_bytes;
+} pn_model_io;
+
+int pn_model_num_slots(const pn_model_desc* d);
+int64_t pn_model_param_floats(const pn_model_desc* d);
+int pn_model_slot_info(const pn_model_desc* d, int i, pn_slot_info* out);
+size_t pn_model_workspace_bytes(const pn_model_desc* d, int B, int N, int training);
+/* byte offset / size of a named intermediate inside the workspace (introspection for tests) */
+int pn_model_ws_lookup(const pn_model_desc* d, int B, int N, int training, const char* name, int64_t* offset, int64_t* bytes);
+
+int pn_model_forward(const pn_model_desc* d, const pn_model_io* io, pn_stream stream);
+/* backward of the last forward on the same workspace.  d_cls / d_seg / d_R are optional upstream gradients w.r.t.
+ * the three outputs; when NULL the gradients of the fused loss requested in the forward are used. */
+int pn_model_backward(const pn_model_desc* d, const pn_model_io* io, const float* d_cls, const float* d_seg,
+                      const float* d_R, pn_stream stream);
+
+/* keras Adam + ExponentialDecay (pointnet_train.py:310-319) over a flat range; the step counter and the step size
+ * stay on the device (iterations: int32; alpha_scratch: 2 floats) so the call can be replayed from a hipGraph.
+ * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce). */
+int pn_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int32_t* iterations,
+                 float* alpha_scratch, float lr0, float decay_rate, float decay_steps, float beta1, float beta2,
+                 float eps, float grad_scale, pn_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POINTNET_HIP_H */

@@ -1,0 +1,81 @@
+// extern "C" surface of libpointnet_hip.so: thin argument adapters over the launchers (see include/pointnet_hip.h).
+#include <stdarg.h>
+#include "pn_internal.h"
+
+namespace pn {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+const char* get_error() { return g_err; }
+}  // namespace pn
+
+using namespace pn;
+static inline hipStream_t S(pn_stream s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" {
+
+int pn_abi_version(void) { return PN_ABI_VERSION; }
+const char* pn_last_error(void) { return get_error(); }
+
+int pn_normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, pn_stream stream) {
+  return normalize(xyz, B, N, out, centroid, scale, S(stream));
+}
+int pn_conv3_fwd(const float* x3, const float* w, int64_t wcs, int B, int N, int C, float* z, float* part, pn_stream stream) {
+  return conv3_fwd(x3, w, wcs, B, N, C, z, part, S(stream));
+}
+int pn_conv3_wgrad(const float* x3, const pn_operand* dz, int B, int N, int C, float* slabs, pn_stream stream) {
+  return conv3_wgrad(x3, dz, B, N, C, slabs, S(stream));
+}
+int pn_conv_fwd(const pn_operand* x, const float* w, int64_t wcs, int B, int N, int K, int C, const float* cloud_bias, float* z,
+                float* part, int prec, pn_stream stream) {
+  return conv_fwd(x, w, wcs, B, N, K, C, cloud_bias, z, part, prec, S(stream));
+}
+int pn_conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C, const float* sgn, float* pmax, int32_t* pidx,
+                    float* part, int prec, pn_stream stream) {
+  return conv_fwd_max(x, w, B, N, K, C, sgn, pmax, pidx, part, prec, S(stream));
+}
+int pn_conv_bwd_data(const pn_operand* dz, const float* w, int64_t wcs, int B, int N, int K, int C, const float* addend,
+                     const float* zmask, const float* msc, const float* msh, float* out, float* part, int prec, pn_stream stream) {
+  return conv_bwd_data(dz, w, wcs, B, N, K, C, addend, zmask, msc, msh, out, part, prec, S(stream));
+}
+int pn_conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, int Cj, int slab_rows, float* slabs, int prec,
+                  pn_stream stream) {
+  return conv_wgrad(a, b, B, N, Ci, Cj, slab_rows, slabs, prec, S(stream));
+}
+int pn_slab_reduce(const float* slabs, int n_slabs, int per_group, int64_t elems, float* out, pn_stream stream) {
+  return slab_reduce(slabs, n_slabs, per_group, elems, out, S(stream));
+}
+int pn_bn_finalize(const float* part, int n_tiles, int C, int64_t count, const float* gamma, const float* beta, float* mm, float* mv,
+                   float momentum, float eps, int use_batch_stats, int update_moving, float* mean, float* invstd, float* scale,
+                   float* shift, pn_stream stream) {
+  return bn_finalize(part, n_tiles, C, count, gamma, beta, mm, mv, momentum, eps, use_batch_stats, update_moving, mean, invstd, scale,
+                     shift, S(stream));
+}
+int pn_bn_bwd_finalize(const float* part, int n_tiles, int C, int64_t count, const float* gamma, const float* mean,
+                       const float* invstd, int batch_stats, float* dgamma, float* dbeta, float* ca, float* cb, float* cc,
+                       pn_stream stream) {
+  return bn_bwd_finalize(part, n_tiles, C, count, gamma, mean, invstd, batch_stats, dgamma, dbeta, ca, cb, cc, S(stream));
+}
+int pn_sign(const float* gamma, int C, float* sgn, pn_stream stream) { return sign_of(gamma, C, sgn, S(stream)); }
+int pn_max_finalize(const float* pmax, const int32_t* pidx, int B, int tpc, int C, const float* sgn, const float* scale,
+                    const float* shift, float* g, float* zstar, int32_t* arg, pn_stream stream) {
+  return max_finalize(pmax, pidx, B, tpc, C, sgn, scale, shift, g, zstar, arg, S(stream));
+}
+size_t pn_fps_workspace_bytes(int B, int N) { return fps_workspace_bytes(B, N); }
+int pn_fps(const float* xyz, int B, int N, int M, int start_idx, int32_t* idx_out, float* mindist, void* ws, size_t ws_bytes,
+           pn_stream stream) {
+  return fps(xyz, B, N, M, start_idx, idx_out, mindist, ws, ws_bytes, S(stream));
+}
+size_t pn_voxel_workspace_bytes(int N) { return voxel_workspace_bytes(N); }
+int pn_voxel_downsample(const float* xyz, const int32_t* labels, int N, const float* leaf3_host, const float* origin3_host,
+                        int n_labels, float* centroids, int32_t* counts, int32_t* majority, int32_t* n_out, void* ws, size_t ws_bytes,
+                        pn_stream stream) {
+  return voxel_downsample(xyz, labels, N, leaf3_host, origin3_host, n_labels, centroids, counts, majority, n_out, ws, ws_bytes,
+                          S(stream));
+}
+
+}  // extern "C"

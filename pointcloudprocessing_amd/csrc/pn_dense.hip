@@ -1,0 +1,311 @@
+// Per-cloud dense layers (rows = B clouds): DenseLayer (pointnet/PointNet.py:597-679), the T-Net tail
+// X @ w + b (PointNet.py:436-442), the classification softmax + loss.  These are weight-streaming, latency
+// bound problems (M = batch size): fp32 on the vector ALU, split over K for parallelism, reduced in a
+// fixed order so results are bitwise reproducible.
+#include "pn_common.h"
+
+namespace pn {
+
+constexpr int DENSE_KS = 32;   // k per split
+constexpr int DENSE_RC = 16;   // rows per register chunk
+
+// partial[ks][r][j] = sum_{k in split ks} x[r][k] * w[k][j]        x: (R, K) ld = ldx ; w: (K, C)
+__global__ __launch_bounds__(256) void dense_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                            int R, int K, int C, float* __restrict__ partial) {
+  __shared__ float xs[DENSE_RC][DENSE_KS];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int ks = blockIdx.y, k0 = ks * DENSE_KS;
+  const int nk = min(DENSE_KS, K - k0);
+  for (int rc = 0; rc < R; rc += DENSE_RC) {
+    const int nr = min(DENSE_RC, R - rc);
+    __syncthreads();
+    for (int t = threadIdx.x; t < DENSE_RC * DENSE_KS; t += 256) {
+      const int r = t / DENSE_KS, k = t % DENSE_KS;
+      xs[r][k] = (r < nr && k < nk) ? x[(long long)(rc + r) * ldx + k0 + k] : 0.f;
+    }
+    __syncthreads();
+    if (j < C) {
+      float acc[DENSE_RC];
+#pragma unroll
+      for (int r = 0; r < DENSE_RC; ++r) acc[r] = 0.f;
+      for (int k = 0; k < nk; ++k) {
+        const float wv = w[(long long)(k0 + k) * C + j];
+#pragma unroll
+        for (int r = 0; r < DENSE_RC; ++r) acc[r] = fmaf(xs[r][k], wv, acc[r]);
+      }
+      for (int r = 0; r < nr; ++r) partial[((long long)ks * R + rc + r) * C + j] = acc[r];
+    }
+  }
+}
+
+// Finish a dense layer: z = sum_ks partial + bias; optional BatchNormalization over the R rows (batch or
+// moving statistics); optional ReLU; optional inverted dropout with a given keep mask.
+//   act: 0 none, 1 relu
+__global__ __launch_bounds__(256) void dense_finalize_kernel(const float* __restrict__ partial, int nks, int R, int C,
+                                                             const float* __restrict__ bias, const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, float* __restrict__ mm,
+                                                             float* __restrict__ mv, float momentum, float eps, int bn_mode,
+                                                             int act, const unsigned char* __restrict__ keep, float keep_scale,
+                                                             float* __restrict__ z_out, float* __restrict__ a_out,
+                                                             float* __restrict__ mean_o, float* __restrict__ invstd_o) {
+  // bn_mode: 0 no BN, 1 batch statistics (+ moving update), 2 moving statistics
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= C) return;
+  float s1 = 0.f;
+  for (int r = 0; r < R; ++r) {
+    float z = 0.f;
+    for (int ks = 0; ks < nks; ++ks) z += partial[((long long)ks * R + r) * C + j];
+    if (bias) z += bias[j];
+    z_out[(long long)r * C + j] = z;
+    s1 += z;
+  }
+  float sc = 1.f, sh = 0.f;
+  if (bn_mode) {
+    float mean, var;
+    if (bn_mode == 1) {
+      mean = s1 / (float)R;
+      float s2 = 0.f;
+      for (int r = 0; r < R; ++r) {
+        const float d = z_out[(long long)r * C + j] - mean;
+        s2 = fmaf(d, d, s2);
+      }
+      var = s2 / (float)R;
+      mm[j] = mm[j] * momentum + mean * (1.f - momentum);
+      mv[j] = mv[j] * momentum + var * (1.f - momentum);
+    } else {
+      mean = mm[j];
+      var = mv[j];
+    }
+    const float invstd = 1.0f / sqrtf(var + eps);
+    sc = gamma[j] * invstd;
+    sh = beta[j] - mean * sc;
+    if (mean_o) mean_o[j] = mean;
+    if (invstd_o) invstd_o[j] = invstd;
+  }
+  if (a_out) {
+    for (int r = 0; r < R; ++r) {
+      float y = fmaf(sc, z_out[(long long)r * C + j], sh);
+      if (act == 1) y = fmaxf(y, 0.f);
+      if (keep) y = keep[(long long)r * C + j] ? y * keep_scale : 0.f;
+      a_out[(long long)r * C + j] = y;
+    }
+  }
+}
+
+// Backward through [dropout] -> [relu] -> [BN] of a dense layer:  da (R,C) -> dz (R,C), dgamma, dbeta / dbias.
+__global__ __launch_bounds__(256) void dense_bwd_pre_kernel(const float* __restrict__ da, const float* __restrict__ z, int R, int C,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            int bn_mode, int act, const unsigned char* __restrict__ keep,
+                                                            float keep_scale, float* __restrict__ dz, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta, float* __restrict__ dbias) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= C) return;
+  float sc = 1.f, sh = 0.f, mu = 0.f, is = 1.f;
+  if (bn_mode) {
+    mu = mean[j]; is = invstd[j];
+    sc = gamma[j] * is;
+    sh = beta[j] - mu * sc;
+  }
+  float S1 = 0.f, S2 = 0.f;
+  for (int r = 0; r < R; ++r) {
+    const long long o = (long long)r * C + j;
+    float d = da[o];
+    if (keep) d = keep[o] ? d * keep_scale : 0.f;
+    const float zz = z[o];
+    if (act == 1 && !(fmaf(sc, zz, sh) > 0.f)) d = 0.f;
+    dz[o] = d;   // dy_hat for now
+    S1 += d;
+    S2 = fmaf(d, (zz - mu) * is, S2);
+  }
+  if (bn_mode == 1) {
+    if (dgamma) dgamma[j] = S2;
+    if (dbeta) dbeta[j] = S1;
+    const float invR = 1.f / (float)R;
+    for (int r = 0; r < R; ++r) {
+      const long long o = (long long)r * C + j;
+      const float zh = (z[o] - mu) * is;
+      dz[o] = sc * (dz[o] - S1 * invR - zh * S2 * invR);
+    }
+  } else if (bn_mode == 2) {
+    for (int r = 0; r < R; ++r) dz[(long long)r * C + j] *= sc;
+  } else {
+    if (dbias) dbias[j] = S1;
+  }
+}
+
+// dw[k][j] = sum_r x[r][k] * dz[r][j]
+__global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, int R,
+                                                          int K, int C, float* __restrict__ dw) {
+  constexpr int KT = 16;
+  __shared__ float xs[KT][DENSE_RC + 1];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int k0 = blockIdx.y * KT;
+  float acc[KT];
+#pragma unroll
+  for (int k = 0; k < KT; ++k) acc[k] = 0.f;
+  for (int rc = 0; rc < R; rc += DENSE_RC) {
+    const int nr = min(DENSE_RC, R - rc);
+    __syncthreads();
+    for (int t = threadIdx.x; t < KT * DENSE_RC; t += 256) {
+      const int k = t / DENSE_RC, r = t % DENSE_RC;
+      xs[k][r] = (r < nr && k0 + k < K) ? x[(long long)(rc + r) * ldx + k0 + k] : 0.f;
+    }
+    __syncthreads();
+    if (j < C) {
+      for (int r = 0; r < nr; ++r) {
+        const float d = dz[(long long)(rc + r) * C + j];
+#pragma unroll
+        for (int k = 0; k < KT; ++k) acc[k] = fmaf(xs[k][r], d, acc[k]);
+      }
+    }
+  }
+  if (j < C) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+      if (k0 + k < K) dw[(long long)(k0 + k) * C + j] = acc[k];
+  }
+}
+
+// out (C, R) = in (R, C)^T, 32x32 LDS tiles
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int R, int C, float* __restrict__ out) {
+  __shared__ float t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    if (by + i < R && bx + tx < C) t[i][tx] = in[(long long)(by + i) * C + bx + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (bx + i < C && by + tx < R) out[(long long)(bx + i) * R + by + tx] = t[tx][i];
+}
+
+// Row softmax + keras SparseCategoricalCrossentropy (clip 1e-7, log, sparse_softmax_xent) + its gradient
+// w.r.t. the logits, one thread per row.  Used for the classification head (rows = B).
+//   loss_sum[0] += sum_r nll_r ; correct[0] += #(argmax == label)      (single block => plain stores)
+__global__ __launch_bounds__(256) void softmax_xent_rows_kernel(const float* __restrict__ logits, int R, int C,
+                                                                const int* __restrict__ labels, float grad_scale,
+                                                                float* __restrict__ probs, float* __restrict__ dlogits,
+                                                                float* __restrict__ loss_sum, float* __restrict__ correct) {
+  __shared__ float rl[256], rc[256];
+  float myloss = 0.f, mycorr = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) {
+    const float* l = logits + (long long)r * C;
+    float mx = -INFINITY;
+    int am = 0;
+    for (int c = 0; c < C; ++c)
+      if (l[c] > mx) { mx = l[c]; am = c; }
+    float sum = 0.f;
+    for (int c = 0; c < C; ++c) sum += expf(l[c] - mx);
+    const float inv = 1.f / sum;
+    float* p = probs + (long long)r * C;
+    for (int c = 0; c < C; ++c) p[c] = expf(l[c] - mx) * inv;
+    if (labels) {
+      const int y = labels[r];
+      // keras: q = log(clip(p)), loss = -log_softmax(q)[y]
+      float qs = 0.f;
+      for (int c = 0; c < C; ++c) qs += fminf(fmaxf(p[c], 1e-7f), 1.f - 1e-7f);
+      const float py = fminf(fmaxf(p[y], 1e-7f), 1.f - 1e-7f);
+      myloss += -(logf(py) - logf(qs));
+      mycorr += (am == y) ? 1.f : 0.f;
+      if (dlogits) {
+        // dL/dp_i = (s_i - [i==y]) / p_i inside the clip range, 0 outside; s = clip(p)/sum clip(p)
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) {
+          const float pc = fminf(fmaxf(p[c], 1e-7f), 1.f - 1e-7f);
+          const bool inr = (p[c] > 1e-7f) && (p[c] < 1.f - 1e-7f);
+          const float dp = inr ? (pc / qs - (c == y ? 1.f : 0.f)) / p[c] : 0.f;
+          dot = fmaf(p[c], dp, dot);
+        }
+        float* d = dlogits + (long long)r * C;
+        for (int c = 0; c < C; ++c) {
+          const float pc = fminf(fmaxf(p[c], 1e-7f), 1.f - 1e-7f);
+          const bool inr = (p[c] > 1e-7f) && (p[c] < 1.f - 1e-7f);
+          const float dp = inr ? (pc / qs - (c == y ? 1.f : 0.f)) / p[c] : 0.f;
+          d[c] = grad_scale * p[c] * (dp - dot);
+        }
+      }
+    }
+  }
+  rl[threadIdx.x] = myloss; rc[threadIdx.x] = mycorr;
+  __syncthreads();
+  if (threadIdx.x == 0 && labels) {
+    float a = 0.f, b = 0.f;
+    for (int i = 0; i < 256; ++i) { a += rl[i]; b += rc[i]; }
+    if (loss_sum) loss_sum[0] = a;
+    if (correct) correct[0] = b;
+  }
+}
+
+// dlogits from an arbitrary upstream d(probs):  dlogit_j = p_j (dp_j - sum_i p_i dp_i)
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __restrict__ probs, const float* __restrict__ dprobs,
+                                                               long long R, int C, float* __restrict__ dlogits) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const float* p = probs + r * C;
+  const float* dp = dprobs + r * C;
+  float dot = 0.f;
+  for (int c = 0; c < C; ++c) dot = fmaf(p[c], dp[c], dot);
+  float* d = dlogits + r * C;
+  for (int c = 0; c < C; ++c) d[c] = p[c] * (dp[c] - dot);
+}
+
+// ---- host wrappers ---------------------------------------------------------------------------------------
+int dense_partial(const float* x, int ldx, const float* w, int R, int K, int C, float* partial, hipStream_t st) {
+  PN_CHECK_ARG(x && w && partial && R > 0 && K > 0 && C > 0, "dense_partial: bad arguments");
+  hipLaunchKernelGGL(dense_partial_kernel, dim3(cdiv(C, 256), cdiv(K, DENSE_KS)), dim3(256), 0, st, x, ldx, w, R, K, C, partial);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+int dense_nsplit(int K) { return cdiv(K, DENSE_KS); }
+
+int dense_finalize(const float* partial, int nks, int R, int C, const float* bias, const float* gamma, const float* beta, float* mm,
+                   float* mv, float momentum, float eps, int bn_mode, int act, const unsigned char* keep, float keep_scale,
+                   float* z_out, float* a_out, float* mean_o, float* invstd_o, hipStream_t st) {
+  PN_CHECK_ARG(partial && z_out, "dense_finalize: null pointer");
+  hipLaunchKernelGGL(dense_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, partial, nks, R, C, bias, gamma, beta, mm, mv,
+                     momentum, eps, bn_mode, act, keep, keep_scale, z_out, a_out, mean_o, invstd_o);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+int dense_bwd_pre(const float* da, const float* z, int R, int C, const float* gamma, const float* beta, const float* mean,
+                  const float* invstd, int bn_mode, int act, const unsigned char* keep, float keep_scale, float* dz, float* dgamma,
+                  float* dbeta, float* dbias, hipStream_t st) {
+  PN_CHECK_ARG(da && z && dz, "dense_bwd_pre: null pointer");
+  hipLaunchKernelGGL(dense_bwd_pre_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, da, z, R, C, gamma, beta, mean, invstd, bn_mode,
+                     act, keep, keep_scale, dz, dgamma, dbeta, dbias);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+int dense_wgrad(const float* x, int ldx, const float* dz, int R, int K, int C, float* dw, hipStream_t st) {
+  PN_CHECK_ARG(x && dz && dw, "dense_wgrad: null pointer");
+  hipLaunchKernelGGL(dense_wgrad_kernel, dim3(cdiv(C, 256), cdiv(K, 16)), dim3(256), 0, st, x, ldx, dz, R, K, C, dw);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+int transpose(const float* in, int R, int C, float* out, hipStream_t st) {
+  PN_CHECK_ARG(in && out && R > 0 && C > 0, "transpose: bad arguments");
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, st, in, R, C, out);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+int softmax_xent_rows(const float* logits, int R, int C, const int* labels, float grad_scale, float* probs, float* dlogits,
+                      float* loss_sum, float* correct, hipStream_t st) {
+  PN_CHECK_ARG(logits && probs && R > 0 && C > 0, "softmax_xent_rows: bad arguments");
+  hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3(1), dim3(256), 0, st, logits, R, C, labels, grad_scale, probs, dlogits,
+                     loss_sum, correct);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+int softmax_bwd_rows(const float* probs, const float* dprobs, long long R, int C, float* dlogits, hipStream_t st) {
+  PN_CHECK_ARG(probs && dprobs && dlogits, "softmax_bwd_rows: null pointer");
+  hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)cdivll(R, 256)), dim3(256), 0, st, probs, dprobs, R, C, dlogits);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+}  // namespace pn

@@ -1,0 +1,522 @@
+// Generic per-point contraction engine for gfx950 (bf16 MFMA 32x32x16, fp32 accumulate).
+//
+//   OUT[i, j] = sum_k  A(i, k) * B(j, k)
+//
+// Three problem shapes share one core:
+//   FWD       i = point row (tile of 128 rows of one cloud), j = output channel, k = input channel.
+//             A = lazy activation operand (row-major, k contiguous);  B = W[k][j]   (Keras kernel, k-major)
+//   BWD_DATA  i = point row, j = input channel of the layer, k = output channel.
+//             A = lazy dz operand;                                    B = W[j][k]   (same Keras kernel)
+//   WGRAD     i = channel of operand a, j = channel of operand b, k = point row inside a slab.
+//             A, B = lazy operands, both read "transposed" (k is the slow index in memory)
+//
+// LDS image of either operand is T[r][kk] bf16 with kk contiguous and a row pitch of BK+8 elements, which
+// makes every ds_read_b128 fragment read and every ds_write_b128 staging write conflict-free
+// (MI355X_MICROARCH.md, LDS table: b128 reads are served in 16-lane groups over 64 banks; pitch 144 B or
+// 80 B maps rows r..r+15 to 16 distinct 16-byte slots).  Operands are staged through registers because the
+// BatchNorm/ReLU (or BN-backward) affine is applied on the way in -- that is the fusion that removes the
+// separate normalisation passes of the reference's dataflow.
+//
+// MFMA lane maps used (cdna_hip_programming.md section 3): v_mfma_f32_32x32x16_bf16, lane l: r = l&31, h = l>>5
+//   A fragment element e (0..7) = A[row r][k = 8h+e];   B fragment element e = B[k = 8h+e][col r]
+//   C/D register g (0..15)      = D[row (g&3) + 8*(g>>2) + 4h][col r]
+#include "pn_common.h"
+
+namespace pn {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+enum { MODE_FWD = 0, MODE_BWD = 1, MODE_WGRAD = 2 };
+enum { EPI_STORE = 0, EPI_MAX = 1, EPI_SLAB = 2 };
+
+struct GemmArgs {
+  pn_operand a;       // FWD/BWD: activation-side operand.  WGRAD: operand a (channels Ci)
+  pn_operand b;       // WGRAD only: operand b (channels Cj)
+  const float* w;     // FWD: W[K][C];  BWD: W[C][K]
+  long long w_cloud_stride;
+  int B, N;           // clouds, points per cloud
+  int K;              // contraction length (FWD/BWD);   WGRAD: slab_rows
+  int C;              // output channels (FWD/BWD);      WGRAD: Cj
+  int Ci;             // WGRAD: Ci
+  int tiles_per_cloud;  // FWD/BWD: ceil(N/BM);  WGRAD: slabs per cloud
+  // epilogue
+  float* out;               // STORE: (B*N, C);  SLAB: slabs
+  const float* cloud_bias;  // STORE (optional) (B, C)
+  const float* addend;      // STORE (optional) (B*N, C)
+  const float* zmask;       // STORE (optional) relu mask source (B*N, C)
+  const float* msc;         // mask scale/shift per channel
+  const float* msh;
+  float* stat_partials;     // [tiles][2][C] (optional)
+  const float* sgn;         // MAX
+  float* pmax;              // MAX [tiles][C]
+  int* pidx;                // MAX [tiles][C]
+};
+
+template <int BK>
+struct Geo {
+  static constexpr int PITCH = BK + 8;  // bf16 elements
+};
+
+__device__ __forceinline__ void cvt_store8(__bf16* hi, __bf16* lo, const float (&v)[8], bool split) {
+  bf16x8 h;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) h[e] = (__bf16)v[e];
+  *reinterpret_cast<bf16x8*>(hi) = h;
+  if (split) {
+    bf16x8 l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) l[e] = (__bf16)(v[e] - (float)h[e]);
+    *reinterpret_cast<bf16x8*>(lo) = l;
+  }
+}
+
+// ---- "natural" stager: source[(row)*ld + k], k contiguous; coefficients indexed by k ------------------
+template <int TR, int BK, int NS, bool HAS2>
+__device__ __forceinline__ void stage_nat(__bf16* __restrict__ Thi, __bf16* __restrict__ Tlo, const pn_operand& op,
+                                          long long base, int nvalid_rows, int k0, int tid) {
+  constexpr int PITCH = Geo<BK>::PITCH;
+  constexpr int CH = BK / 8;     // 16-byte bf16 chunks per LDS row
+  constexpr int RP = 256 / CH;   // rows per pass
+  const int ch = tid % CH, rin = tid / CH;
+  const int k = k0 + ch * 8;
+  float ca[8], cb[8], cc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { ca[e] = 1.f; cb[e] = 0.f; cc[e] = 0.f; }
+  if (op.ca) {
+    const float4 t0 = *reinterpret_cast<const float4*>(op.ca + k), t1 = *reinterpret_cast<const float4*>(op.ca + k + 4);
+    ca[0] = t0.x; ca[1] = t0.y; ca[2] = t0.z; ca[3] = t0.w; ca[4] = t1.x; ca[5] = t1.y; ca[6] = t1.z; ca[7] = t1.w;
+  }
+  if (HAS2 && op.cb) {
+    const float4 t0 = *reinterpret_cast<const float4*>(op.cb + k), t1 = *reinterpret_cast<const float4*>(op.cb + k + 4);
+    cb[0] = t0.x; cb[1] = t0.y; cb[2] = t0.z; cb[3] = t0.w; cb[4] = t1.x; cb[5] = t1.y; cb[6] = t1.z; cb[7] = t1.w;
+  }
+  if (op.cc) {
+    const float4 t0 = *reinterpret_cast<const float4*>(op.cc + k), t1 = *reinterpret_cast<const float4*>(op.cc + k + 4);
+    cc[0] = t0.x; cc[1] = t0.y; cc[2] = t0.z; cc[3] = t0.w; cc[4] = t1.x; cc[5] = t1.y; cc[6] = t1.z; cc[7] = t1.w;
+  }
+  const float lo = op.lo;
+#pragma unroll
+  for (int p = 0; p < TR / RP; ++p) {
+    const int r = p * RP + rin;
+    float v[8];
+    if (r < nvalid_rows) {
+      const float* s = op.s1 + base + (long long)r * op.ld + k;
+      const float4 x0 = *reinterpret_cast<const float4*>(s), x1 = *reinterpret_cast<const float4*>(s + 4);
+      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
+      float y[8];
+      if (HAS2) {
+        const float* s2 = op.s2 + base + (long long)r * op.ld + k;
+        const float4 y0 = *reinterpret_cast<const float4*>(s2), y1 = *reinterpret_cast<const float4*>(s2 + 4);
+        y[0] = y0.x; y[1] = y0.y; y[2] = y0.z; y[3] = y0.w; y[4] = y1.x; y[5] = y1.y; y[6] = y1.z; y[7] = y1.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float t = fmaf(ca[e], v[e], cc[e]);
+        if (HAS2) t = fmaf(cb[e], y[e], t);
+        v[e] = fmaxf(t, lo);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    cvt_store8(Thi + r * PITCH + ch * 8, Tlo + r * PITCH + ch * 8, v, NS == 3);
+  }
+}
+
+// ---- "transposed" stager: source[(k)*ld + r], r (= the LDS row / channel) contiguous in memory;
+//      coefficients indexed by r.  Each lane owns one channel and gathers 8 consecutive k for it. -------
+template <int TR, int BK, int NS, bool HAS2>
+__device__ __forceinline__ void stage_trn(__bf16* __restrict__ Thi, __bf16* __restrict__ Tlo, const pn_operand& op,
+                                          long long base, int nvalid_k, int nvalid_r, int coef0, int tid) {
+  constexpr int PITCH = Geo<BK>::PITCH;
+  constexpr int KG = BK / 8;      // k-groups per chunk
+  constexpr int TPG = 256 / TR;   // k-groups covered per pass
+  static_assert(KG % TPG == 0, "tile geometry");
+  const int r = tid % TR, kgin = tid / TR;
+  const bool rv = r < nvalid_r;
+  float ca = 1.f, cb = 0.f, cc = 0.f;
+  if (rv) {
+    if (op.ca) ca = op.ca[coef0 + r];
+    if (HAS2 && op.cb) cb = op.cb[coef0 + r];
+    if (op.cc) cc = op.cc[coef0 + r];
+  }
+  const float lo = op.lo;
+#pragma unroll
+  for (int p = 0; p < KG / TPG; ++p) {
+    const int kg = p * TPG + kgin;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = kg * 8 + e;
+      float t = 0.f;
+      if (rv && k < nvalid_k) {
+        const long long off = base + (long long)k * op.ld + r;
+        t = fmaf(ca, op.s1[off], cc);
+        if (HAS2) t = fmaf(cb, op.s2[off], t);
+        t = fmaxf(t, lo);
+      }
+      v[e] = t;
+    }
+    cvt_store8(Thi + r * PITCH + kg * 8, Tlo + r * PITCH + kg * 8, v, NS == 3);
+  }
+}
+
+// ---- MFMA over one staged chunk ------------------------------------------------------------------------
+template <int MT, int NT, int BK, int NS>
+__device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT][NT], const __bf16* Ahi, const __bf16* Alo, const __bf16* Bhi,
+                                          const __bf16* Blo, int wrow0, int wcol0, int lane) {
+  constexpr int PITCH = Geo<BK>::PITCH;
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int ks = 0; ks < BK / 16; ++ks) {
+    bf16x8 ah[MT], al[MT], bh[NT], bl[NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const int o = (wrow0 + m * 32 + r) * PITCH + ks * 16 + h * 8;
+      ah[m] = *reinterpret_cast<const bf16x8*>(Ahi + o);
+      if (NS == 3) al[m] = *reinterpret_cast<const bf16x8*>(Alo + o);
+    }
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int o = (wcol0 + n * 32 + r) * PITCH + ks * 16 + h * 8;
+      bh[n] = *reinterpret_cast<const bf16x8*>(Bhi + o);
+      if (NS == 3) bl[n] = *reinterpret_cast<const bf16x8*>(Blo + o);
+    }
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        if (NS == 3) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+        }
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+      }
+  }
+}
+
+// ---- the kernel ----------------------------------------------------------------------------------------
+// 256 threads = 4 waves arranged 2 (rows) x 2 (cols); wave tile (BM/2) x (BN/2) = MT x NT MFMA tiles.
+template <int BM, int BN, int NS, int MODE, bool A2, bool B2, int EPI>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+  constexpr int BK = (NS == 3) ? 32 : 64;
+  constexpr int PITCH = Geo<BK>::PITCH;
+  constexpr int MT = BM / 64, NT = BN / 64;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TILE_A = BM * PITCH, TILE_B = BN * PITCH;
+  constexpr int NTILES = (NS == 3) ? 2 : 1;
+  constexpr int LDS_TILES_BYTES = (TILE_A + TILE_B) * NTILES * 2;
+  constexpr int LDS_EPI_BYTES = 2 * BN * 4 * 4;  // [2 waves rows][BN] x (up to 4 floats)
+  constexpr int LDS_BYTES = LDS_TILES_BYTES > LDS_EPI_BYTES ? LDS_TILES_BYTES : LDS_EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+  __bf16* Ahi = reinterpret_cast<__bf16*>(lds_raw);
+  __bf16* Bhi = Ahi + TILE_A;
+  __bf16* Alo = (NS == 3) ? (Bhi + TILE_B) : Ahi;
+  __bf16* Blo = (NS == 3) ? (Alo + TILE_A) : Bhi;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int wrow0 = wm * WTM, wcol0 = wn * WTN;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+
+  const int bx = blockIdx.x;
+  const int cloud = bx / g.tiles_per_cloud, tin = bx - cloud * g.tiles_per_cloud;
+
+  if (MODE == MODE_WGRAD) {
+    const int i0 = blockIdx.y * BM, j0 = blockIdx.z * BN;
+    const int rbeg = tin * g.K;
+    const int rend = min(g.N, rbeg + g.K);
+    for (int r0 = rbeg; r0 < rend; r0 += BK) {
+      const long long rowbase = (long long)cloud * g.N + r0;
+      const int nk = min(BK, rend - r0);
+      stage_trn<BM, BK, NS, A2>(Ahi, Alo, g.a, rowbase * g.a.ld + i0, nk, g.Ci - i0, i0, tid);
+      stage_trn<BN, BK, NS, B2>(Bhi, Blo, g.b, rowbase * g.b.ld + j0, nk, g.C - j0, j0, tid);
+      __syncthreads();
+      mma_chunk<MT, NT, BK, NS>(acc, Ahi, Alo, Bhi, Blo, wrow0, wcol0, lane);
+      __syncthreads();
+    }
+    // slab store
+    float* slab = g.out + (long long)bx * g.Ci * g.C;
+    const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int j = j0 + wcol0 + n * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int i = i0 + wrow0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (i < g.Ci && j < g.C) slab[(long long)i * g.C + j] = acc[m][n][e];
+        }
+      }
+    return;
+  }
+
+  // ---- FWD / BWD_DATA ----
+  const int row_in_cloud0 = tin * BM;
+  const int nrows = min(BM, g.N - row_in_cloud0);
+  const long long row0 = (long long)cloud * g.N + row_in_cloud0;
+  const int col0 = blockIdx.y * BN;
+  const long long wbase = (long long)cloud * g.w_cloud_stride;
+  pn_operand wop;
+  wop.s1 = g.w; wop.s2 = nullptr; wop.ca = nullptr; wop.cb = nullptr; wop.cc = nullptr;
+  wop.lo = -INFINITY;
+  wop.ld = (MODE == MODE_FWD) ? g.C : g.K;
+
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    stage_nat<BM, BK, NS, A2>(Ahi, Alo, g.a, row0 * g.a.ld, nrows, k0, tid);
+    if (MODE == MODE_FWD)
+      stage_trn<BN, BK, NS, false>(Bhi, Blo, wop, wbase + (long long)k0 * g.C + col0, BK, g.C - col0, 0, tid);
+    else
+      stage_nat<BN, BK, NS, false>(Bhi, Blo, wop, wbase + (long long)col0 * g.K, g.C - col0, k0, tid);
+    __syncthreads();
+    mma_chunk<MT, NT, BK, NS>(acc, Ahi, Alo, Bhi, Blo, wrow0, wcol0, lane);
+    __syncthreads();
+  }
+
+  const int r = lane & 31, h = lane >> 5;
+  float* red = reinterpret_cast<float*>(lds_raw);  // tiles are dead after the final barrier
+
+  if (EPI == EPI_STORE) {
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int jl = wcol0 + n * 32 + r, j = col0 + jl;
+      const bool jv = j < g.C;
+      float bias = 0.f, msc = 0.f, msh = 0.f;
+      if (jv && g.cloud_bias) bias = g.cloud_bias[(long long)cloud * g.C + j];
+      if (jv && g.zmask) { msc = g.msc[j]; msh = g.msh[j]; }
+      float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int il = wrow0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (il < nrows && jv) {
+            const long long o = (row0 + il) * g.C + j;
+            float v = acc[m][n][e] + bias;
+            if (g.addend) v += g.addend[o];
+            float w2 = v;
+            if (g.zmask) {
+              const float z = g.zmask[o];
+              if (!(fmaf(msc, z, msh) > 0.f)) v = 0.f;
+              w2 = z;
+            }
+            if (g.out) g.out[o] = v;
+            a1 += v;
+            a2 = fmaf(v, w2, a2);
+          }
+        }
+      s1[n] = a1 + __shfl_xor(a1, 32, 64);
+      s2[n] = a2 + __shfl_xor(a2, 32, 64);
+    }
+    if (g.stat_partials) {
+      if (h == 0) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int jl = wcol0 + n * 32 + r;
+          red[(wm * 2 + 0) * BN + jl] = s1[n];
+          red[(wm * 2 + 1) * BN + jl] = s2[n];
+        }
+      }
+      __syncthreads();
+      if (tid < BN && col0 + tid < g.C) {
+        float* p = g.stat_partials + (long long)bx * 2 * g.C + col0 + tid;
+        p[0] = red[0 * BN + tid] + red[2 * BN + tid];
+        p[g.C] = red[1 * BN + tid] + red[3 * BN + tid];
+      }
+    }
+  } else if (EPI == EPI_MAX) {
+    float s1[NT], s2[NT], bv[NT];
+    int bi[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int j = col0 + wcol0 + n * 32 + r;
+      const bool jv = j < g.C;
+      const float sg = jv ? g.sgn[j] : 1.f;
+      float a1 = 0.f, a2 = 0.f, best = -INFINITY;
+      int besti = 0x7fffffff;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int il = wrow0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          if (il < nrows) {
+            const float v = acc[m][n][e];
+            a1 += v;
+            a2 = fmaf(v, v, a2);
+            const float t = sg * v;
+            const int idx = row_in_cloud0 + il;
+            if (t > best || (t == best && idx < besti)) { best = t; besti = idx; }
+          }
+        }
+      s1[n] = a1 + __shfl_xor(a1, 32, 64);
+      s2[n] = a2 + __shfl_xor(a2, 32, 64);
+      const float ob = __shfl_xor(best, 32, 64);
+      const int oi = __shfl_xor(besti, 32, 64);
+      if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
+      bv[n] = best; bi[n] = besti;
+    }
+    if (h == 0) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int jl = wcol0 + n * 32 + r;
+        red[(wm * 4 + 0) * BN + jl] = s1[n];
+        red[(wm * 4 + 1) * BN + jl] = s2[n];
+        red[(wm * 4 + 2) * BN + jl] = bv[n];
+        reinterpret_cast<int*>(red)[(wm * 4 + 3) * BN + jl] = bi[n];
+      }
+    }
+    __syncthreads();
+    if (tid < BN && col0 + tid < g.C) {
+      const int j = col0 + tid;
+      if (g.stat_partials) {
+        float* p = g.stat_partials + (long long)bx * 2 * g.C + j;
+        p[0] = red[0 * BN + tid] + red[4 * BN + tid];
+        p[g.C] = red[1 * BN + tid] + red[5 * BN + tid];
+      }
+      float v0 = red[2 * BN + tid], v1 = red[6 * BN + tid];
+      int i0 = reinterpret_cast<int*>(red)[3 * BN + tid], i1 = reinterpret_cast<int*>(red)[7 * BN + tid];
+      if (v1 > v0 || (v1 == v0 && i1 < i0)) { v0 = v1; i0 = i1; }
+      g.pmax[(long long)bx * g.C + j] = v0;
+      g.pidx[(long long)bx * g.C + j] = i0;
+    }
+  }
+}
+
+// ---- host-side dispatch ----------------------------------------------------------------------------------
+template <int BM, int BN, int NS, int MODE, bool A2, bool B2, int EPI>
+static int launch(const GemmArgs& g, dim3 grid, hipStream_t st) {
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS, MODE, A2, B2, EPI>), grid, dim3(256), 0, st, g);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int check_operand(const pn_operand* o, const char* name) {
+  PN_CHECK_ARG(o && o->s1, "%s: null operand", name);
+  PN_CHECK_ARG(aligned16(o->s1) && (!o->s2 || aligned16(o->s2)), "%s: s1/s2 must be 16-byte aligned", name);
+  PN_CHECK_ARG((!o->ca || aligned16(o->ca)) && (!o->cb || aligned16(o->cb)) && (!o->cc || aligned16(o->cc)),
+               "%s: coefficient vectors must be 16-byte aligned", name);
+  PN_CHECK_ARG(o->ld > 0 && o->ld % 4 == 0, "%s: ld must be a positive multiple of 4", name);
+  return PN_OK;
+}
+
+template <int MODE, bool A2, int EPI>
+static int dispatch_rows(const GemmArgs& g, int prec, hipStream_t st) {
+  const bool wide = (g.C % 128 == 0);
+  if (EPI == EPI_MAX) {
+    dim3 grid(g.B * g.tiles_per_cloud, cdiv(g.C, 128));
+    if (prec == PN_PREC_BF16X3) return launch<128, 128, 3, MODE, A2, false, EPI>(g, grid, st);
+    return launch<128, 128, 1, MODE, A2, false, EPI>(g, grid, st);
+  }
+  if (wide) {
+    dim3 grid(g.B * g.tiles_per_cloud, g.C / 128);
+    if (prec == PN_PREC_BF16X3) return launch<128, 128, 3, MODE, A2, false, EPI>(g, grid, st);
+    return launch<128, 128, 1, MODE, A2, false, EPI>(g, grid, st);
+  }
+  dim3 grid(g.B * g.tiles_per_cloud, cdiv(g.C, 64));
+  if (prec == PN_PREC_BF16X3) return launch<128, 64, 3, MODE, A2, false, EPI>(g, grid, st);
+  return launch<128, 64, 1, MODE, A2, false, EPI>(g, grid, st);
+}
+
+int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, int K, int C, const float* cloud_bias,
+             float* z, float* stat_partials, int prec, hipStream_t st) {
+  PN_TRY(check_operand(x, "pn_conv_fwd.x"));
+  PN_CHECK_ARG(!x->s2, "pn_conv_fwd: the forward operand has no second source");
+  PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_fwd: B and N must be positive (B=%d N=%d)", B, N);
+  PN_CHECK_ARG(K >= 64 && K % 64 == 0, "pn_conv_fwd: K must be a multiple of 64 (K=%d)", K);
+  PN_CHECK_ARG(C >= 64 && C % 64 == 0, "pn_conv_fwd: C must be a multiple of 64 (C=%d)", C);
+  PN_CHECK_ARG(x->ld >= K, "pn_conv_fwd: x.ld < K");
+  PN_CHECK_ARG(w && aligned16(w), "pn_conv_fwd: w null or unaligned");
+  PN_CHECK_ARG(prec == PN_PREC_BF16 || prec == PN_PREC_BF16X3, "pn_conv_fwd: bad prec %d", prec);
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a = *x; g.w = w; g.w_cloud_stride = wcs; g.B = B; g.N = N; g.K = K; g.C = C;
+  g.tiles_per_cloud = cdiv(N, 128);
+  g.out = z; g.cloud_bias = cloud_bias; g.stat_partials = stat_partials;
+  return dispatch_rows<MODE_FWD, false, EPI_STORE>(g, prec, st);
+}
+
+int conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C, const float* sgn, float* pmax, int* pidx,
+                 float* stat_partials, int prec, hipStream_t st) {
+  PN_TRY(check_operand(x, "pn_conv_fwd_max.x"));
+  PN_CHECK_ARG(!x->s2, "pn_conv_fwd_max: the forward operand has no second source");
+  PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_fwd_max: B and N must be positive");
+  PN_CHECK_ARG(K >= 64 && K % 64 == 0, "pn_conv_fwd_max: K must be a multiple of 64 (K=%d)", K);
+  PN_CHECK_ARG(C >= 128 && C % 128 == 0, "pn_conv_fwd_max: C must be a multiple of 128 (C=%d)", C);
+  PN_CHECK_ARG(x->ld >= K, "pn_conv_fwd_max: x.ld < K");
+  PN_CHECK_ARG(w && aligned16(w) && sgn && pmax && pidx, "pn_conv_fwd_max: null pointer");
+  PN_CHECK_ARG(prec == PN_PREC_BF16 || prec == PN_PREC_BF16X3, "pn_conv_fwd_max: bad prec %d", prec);
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a = *x; g.w = w; g.B = B; g.N = N; g.K = K; g.C = C;
+  g.tiles_per_cloud = cdiv(N, 128);
+  g.sgn = sgn; g.pmax = pmax; g.pidx = pidx; g.stat_partials = stat_partials;
+  return dispatch_rows<MODE_FWD, false, EPI_MAX>(g, prec, st);
+}
+
+int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, int N, int K, int C, const float* addend,
+                  const float* zmask, const float* msc, const float* msh, float* out, float* stat_partials, int prec,
+                  hipStream_t st) {
+  PN_TRY(check_operand(dz, "pn_conv_bwd_data.dz"));
+  PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_bwd_data: B and N must be positive");
+  PN_CHECK_ARG(K >= 64 && K % 64 == 0, "pn_conv_bwd_data: K must be a multiple of 64 (K=%d)", K);
+  PN_CHECK_ARG(C >= 64 && C % 64 == 0, "pn_conv_bwd_data: C must be a multiple of 64 (C=%d)", C);
+  PN_CHECK_ARG(dz->ld >= K, "pn_conv_bwd_data: dz.ld < K");
+  PN_CHECK_ARG(w && aligned16(w), "pn_conv_bwd_data: w null or unaligned");
+  PN_CHECK_ARG(!zmask || (msc && msh), "pn_conv_bwd_data: zmask needs msc and msh");
+  PN_CHECK_ARG(prec == PN_PREC_BF16 || prec == PN_PREC_BF16X3, "pn_conv_bwd_data: bad prec %d", prec);
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a = *dz; g.w = w; g.w_cloud_stride = wcs; g.B = B; g.N = N; g.K = K; g.C = C;
+  g.tiles_per_cloud = cdiv(N, 128);
+  g.out = out; g.addend = addend; g.zmask = zmask; g.msc = msc; g.msh = msh; g.stat_partials = stat_partials;
+  if (dz->s2) return dispatch_rows<MODE_BWD, true, EPI_STORE>(g, prec, st);
+  return dispatch_rows<MODE_BWD, false, EPI_STORE>(g, prec, st);
+}
+
+template <int BM, int BN>
+static int dispatch_wgrad(const GemmArgs& g, bool b2, int prec, dim3 grid, hipStream_t st) {
+  if (prec == PN_PREC_BF16X3) {
+    if (b2) return launch<BM, BN, 3, MODE_WGRAD, false, true, EPI_SLAB>(g, grid, st);
+    return launch<BM, BN, 3, MODE_WGRAD, false, false, EPI_SLAB>(g, grid, st);
+  }
+  if (b2) return launch<BM, BN, 1, MODE_WGRAD, false, true, EPI_SLAB>(g, grid, st);
+  return launch<BM, BN, 1, MODE_WGRAD, false, false, EPI_SLAB>(g, grid, st);
+}
+
+int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, int Cj, int slab_rows, float* slabs, int prec,
+               hipStream_t st) {
+  PN_TRY(check_operand(a, "pn_conv_wgrad.a"));
+  PN_TRY(check_operand(b, "pn_conv_wgrad.b"));
+  PN_CHECK_ARG(!a->s2, "pn_conv_wgrad: operand a has no second source");
+  PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_wgrad: B and N must be positive");
+  PN_CHECK_ARG(Ci >= 64 && Ci % 64 == 0 && Cj >= 64 && Cj % 64 == 0, "pn_conv_wgrad: Ci, Cj must be multiples of 64 (%d, %d)",
+               Ci, Cj);
+  PN_CHECK_ARG(slab_rows >= 64 && slab_rows % 64 == 0, "pn_conv_wgrad: slab_rows must be a multiple of 64");
+  PN_CHECK_ARG(a->ld >= Ci && b->ld >= Cj, "pn_conv_wgrad: ld too small");
+  PN_CHECK_ARG(slabs != nullptr, "pn_conv_wgrad: null slabs");
+  PN_CHECK_ARG(prec == PN_PREC_BF16 || prec == PN_PREC_BF16X3, "pn_conv_wgrad: bad prec %d", prec);
+  GemmArgs g;
+  memset(&g, 0, sizeof(g));
+  g.a = *a; g.b = *b; g.B = B; g.N = N; g.K = slab_rows; g.C = Cj; g.Ci = Ci;
+  g.tiles_per_cloud = cdiv(N, slab_rows);
+  g.out = slabs;
+  const bool b2 = b->s2 != nullptr;
+  const int nslab = B * g.tiles_per_cloud;
+  if (Ci % 128 == 0 && Cj % 128 == 0) return dispatch_wgrad<128, 128>(g, b2, prec, dim3(nslab, Ci / 128, Cj / 128), st);
+  if (Cj % 128 == 0) return dispatch_wgrad<64, 128>(g, b2, prec, dim3(nslab, Ci / 64, Cj / 128), st);
+  return dispatch_wgrad<64, 64>(g, b2, prec, dim3(nslab, Ci / 64, Cj / 64), st);
+}
+
+}  // namespace pn

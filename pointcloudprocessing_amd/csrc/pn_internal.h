@@ -1,0 +1,89 @@
+// Internal launcher prototypes shared by the C-ABI wrappers (pn_api.cpp) and the model plan (pn_model.cpp).
+#pragma once
+#include "pn_common.h"
+
+namespace pn {
+
+// pn_gemm.hip
+int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, int K, int C, const float* cloud_bias, float* z,
+             float* stat_partials, int prec, hipStream_t st);
+int conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C, const float* sgn, float* pmax, int* pidx,
+                 float* stat_partials, int prec, hipStream_t st);
+int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, int N, int K, int C, const float* addend,
+                  const float* zmask, const float* msc, const float* msh, float* out, float* stat_partials, int prec,
+                  hipStream_t st);
+int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, int Cj, int slab_rows, float* slabs, int prec,
+               hipStream_t st);
+
+// pn_pointwise.hip
+int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st);
+int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st);
+int conv3_wgrad(const float* x3, const pn_operand* dz, int B, int N, int C, float* slabs, hipStream_t st);
+int slab_reduce(const float* slabs, int n_slabs, int per_group, long long elems, float* out, hipStream_t st);
+int bn_finalize(const float* part, int n_tiles, int C, long long count, const float* gamma, const float* beta, float* mm,
+                float* mv, float momentum, float eps, int use_batch, int update, float* mean, float* invstd, float* scale,
+                float* shift, hipStream_t st);
+int bn_bwd_finalize(const float* part, int n_tiles, int C, long long count, const float* gamma, const float* mean,
+                    const float* invstd, int batch_stats, float* dgamma, float* dbeta, float* ca, float* cb, float* cc,
+                    hipStream_t st);
+int sign_of(const float* gamma, int C, float* sgn, hipStream_t st);
+int max_finalize(const float* pmax, const int* pidx, int B, int tpc, int C, const float* sgn, const float* scale,
+                 const float* shift, float* g, float* zstar, int* arg, hipStream_t st);
+
+// pn_dense.hip
+int dense_partial(const float* x, int ldx, const float* w, int R, int K, int C, float* partial, hipStream_t st);
+int dense_nsplit(int K);
+int dense_finalize(const float* partial, int nks, int R, int C, const float* bias, const float* gamma, const float* beta, float* mm,
+                   float* mv, float momentum, float eps, int bn_mode, int act, const unsigned char* keep, float keep_scale,
+                   float* z_out, float* a_out, float* mean_o, float* invstd_o, hipStream_t st);
+int dense_bwd_pre(const float* da, const float* z, int R, int C, const float* gamma, const float* beta, const float* mean,
+                  const float* invstd, int bn_mode, int act, const unsigned char* keep, float keep_scale, float* dz, float* dgamma,
+                  float* dbeta, float* dbias, hipStream_t st);
+int dense_wgrad(const float* x, int ldx, const float* dz, int R, int K, int C, float* dw, hipStream_t st);
+int transpose(const float* in, int R, int C, float* out, hipStream_t st);
+int softmax_xent_rows(const float* logits, int R, int C, const int* labels, float grad_scale, float* probs, float* dlogits,
+                      float* loss_sum, float* correct, hipStream_t st);
+int softmax_bwd_rows(const float* probs, const float* dprobs, long long R, int C, float* dlogits, hipStream_t st);
+
+// pn_segout.hip
+int seg_out_fwd(const pn_operand* x, const float* w, const float* bias, long long M, int K, int C, const int* labels,
+                float grad_scale, float* probs, float* dlogits, float* part, hipStream_t st);
+int seg_out_part_stride();
+int seg_out_bwd(const pn_operand* x, const float* w, const float* dlogits, int B, int N, int K, int C, float* dyhat, float* stat_part,
+                float* wslab, hipStream_t st);
+int sum_partials(const float* part, int n, int stride, int elems, float* out, hipStream_t st);
+
+// pn_maxbwd.hip
+int maxbwd_prep(const float* dg, const float* g, const float* zstar, int B, int C, const float* mean, const float* invstd,
+                const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege, float* f, float* dgamma,
+                float* dbeta, hipStream_t st);
+int colsum_lazy(const pn_operand* x, int B, int N, int C, float* part, hipStream_t st);
+int maxbwd_dw(const pn_operand* x, const int* arg, const float* hs, int B, int N, int K, int C, const float* a1, const float* f,
+              const float* e, const float* GW, float* dW, hipStream_t st);
+int maxbwd_q(const float* w, const float* f, int K, int C, float* q, hipStream_t st);
+int maxbwd_scatter(const int* arg, const float* hs, const float* wt, const float* q, int B, int N, int K, int C, float* D,
+                   hipStream_t st);
+
+// pn_sample.hip
+size_t fps_workspace_bytes(int B, int N);
+int fps(const float* xyz, int B, int N, int M, int start_idx, int* idx_out, float* mindist, void* ws, size_t ws_bytes,
+        hipStream_t st);
+size_t voxel_workspace_bytes(int N);
+int voxel_downsample(const float* xyz, const int* labels, int N, const float* leaf, const float* origin, int n_labels,
+                     float* centroids, int* counts, int* majority, int* n_out, void* ws, size_t ws_bytes, hipStream_t st);
+
+// pn_optim.hip
+int adam_schedule(int* iterations, float lr0, float decay_rate, float decay_steps, float beta1, float beta2, float* alpha, float* lr,
+                  hipStream_t st);
+int adam(float* p, const float* g, float* m, float* v, long long n, const float* alpha, float beta1, float beta2, float eps,
+         float grad_scale, hipStream_t st);
+int mse(const float* R, const float* T, int n, float gscale, float* dR, float* loss_sum, hipStream_t st);
+int orth_reg(const float* R, int B, int K, float c, float* dR, float* loss_part, hipStream_t st);
+int fold3_fwd(const float* R, const float* W, int B, int C, float* Weff, hipStream_t st);
+int fold3_bwd(const float* dWeff, const float* R, const float* W, int B, int C, float* dR, float* dW, hipStream_t st);
+int fill_eye3(float* out, int B, hipStream_t st);
+int axpy(const float* x, float a, float* y, long long n, hipStream_t st);
+int cloud_bias_grad(const float* bwd_part, const float* fwd_part, int B, int tpc, int N, int C, const float* ca, const float* cb,
+                    const float* cc, float* dgb, hipStream_t st);
+
+}  // namespace pn

@@ -1,0 +1,770 @@
+// Whole-model plan: sequences the kernels of one PointNet forward / backward on a stream.
+//
+// Mirrors PointNet.call (point_cloud_analysis/pointnet/PointNet.py:197-292), TNet.call (:418-454) and the
+// loss assembly of pointnet_train.py:334-351.  All host logic here is pointer arithmetic over a caller-owned
+// workspace; nothing allocates, synchronises or keeps state, so a call can be captured into a hipGraph.
+//
+// Dataflow decisions (DESIGN.md has the long form):
+//   * every ConvLayer stores only its pre-BN output z; BatchNormalization + ReLU are applied by the consumer on
+//     load ("lazy operand"), statistics come from the producer's epilogue -> no normalisation / activation pass;
+//   * the three 128->1024 layers never store their (B,N,1024) output: the epilogue keeps per-(cloud,channel)
+//     max / argmax and the BN sums; their backward uses the Gram-matrix form (pn_maxbwd.hip);
+//   * tf.matmul(pc, R) is folded into mlp_1_1's kernel (per-cloud 3x64 weights); tf.matmul(X, R_64) is a
+//     per-cloud-weight contraction on the MFMA engine;
+//   * tile+concat in front of seg_l1 is never formed: seg_l1's kernel is split into its 64 per-point rows and
+//     its 1024 global rows, the latter applied once per cloud and added as a per-cloud bias.
+#include <string>
+#include <vector>
+#include "pn_internal.h"
+
+namespace pn {
+
+enum { BLK_IT = 0, BLK_M11, BLK_M12, BLK_FT, BLK_M21, BLK_M22, BLK_M23, BLK_C1, BLK_C2, BLK_C3, BLK_S1, BLK_S2, BLK_S3, BLK_S4,
+       BLK_S5, N_BLOCKS };
+
+struct Slot {
+  std::string name;
+  long long off;
+  int rows, cols, kind, block;   // kind: 0 kernel 1 gamma 2 beta 3 moving_mean 4 moving_var 5 bias 6 tnet_w 7 tnet_b
+};
+struct LRef {  // offsets (floats) into the flat parameter buffer; -1 when absent
+  long long kernel = -1, gamma = -1, beta = -1, mm = -1, mv = -1, bias = -1;
+  int cin = 0, cout = 0, block = 0;
+  bool has_bn = false;
+};
+struct TRef {
+  LRef c1, c2, c3, d1, d2;
+  long long w = -1, b = -1;
+  int K = 0;
+};
+struct Layout {
+  std::vector<Slot> slots;
+  TRef iT, fT;
+  LRef m11, m12, m21, m22, m23, c1, c2, c3, s1, s2, s3, s4, s5;
+  long long total = 0;
+};
+
+static long long add_slot(Layout& L, const std::string& name, int rows, int cols, int kind, int block) {
+  Slot s;
+  s.name = name; s.rows = rows; s.cols = cols; s.kind = kind; s.block = block;
+  s.off = L.total;
+  L.total += ((long long)rows * cols + 63) / 64 * 64;   // 256-byte aligned slots
+  L.slots.push_back(s);
+  return s.off;
+}
+static LRef add_layer(Layout& L, const std::string& prefix, int cin, int cout, bool has_bn, int block) {
+  LRef r;
+  r.cin = cin; r.cout = cout; r.block = block; r.has_bn = has_bn;
+  r.kernel = add_slot(L, prefix + ".kernel", cin, cout, 0, block);
+  if (has_bn) {
+    r.gamma = add_slot(L, prefix + ".bn.gamma", 1, cout, 1, block);
+    r.beta = add_slot(L, prefix + ".bn.beta", 1, cout, 2, block);
+    r.mm = add_slot(L, prefix + ".bn.moving_mean", 1, cout, 3, block);
+    r.mv = add_slot(L, prefix + ".bn.moving_var", 1, cout, 4, block);
+  } else {
+    r.bias = add_slot(L, prefix + ".bias", 1, cout, 5, block);
+  }
+  return r;
+}
+static TRef add_tnet(Layout& L, const std::string& name, int K, int block) {
+  TRef t;
+  t.K = K;
+  t.c1 = add_layer(L, name + ".conv1", K, 64, true, block);
+  t.c2 = add_layer(L, name + ".conv2", 64, 128, true, block);
+  t.c3 = add_layer(L, name + ".conv3", 128, 1024, true, block);
+  t.d1 = add_layer(L, name + ".dense1", 1024, 512, true, block);
+  t.d2 = add_layer(L, name + ".dense2", 512, 256, true, block);
+  t.w = add_slot(L, name + ".w", 256, K * K, 6, block);
+  t.b = add_slot(L, name + ".b", K, K, 7, block);
+  return t;
+}
+
+static Layout make_layout(const pn_model_desc& d) {
+  Layout L;
+  if (!d.vanilla) L.iT = add_tnet(L, "input_transform", 3, BLK_IT);
+  L.m11 = add_layer(L, "mlp_1_1", 3, 64, true, BLK_M11);
+  L.m12 = add_layer(L, "mlp_1_2", 64, 64, true, BLK_M12);
+  if (!d.vanilla) L.fT = add_tnet(L, "feature_transform", 64, BLK_FT);
+  L.m21 = add_layer(L, "mlp_2_1", 64, 64, true, BLK_M21);
+  L.m22 = add_layer(L, "mlp_2_2", 64, 128, true, BLK_M22);
+  L.m23 = add_layer(L, "mlp_2_3", 128, 1024, true, BLK_M23);
+  L.c1 = add_layer(L, "mlp_cls_1", 1024, 512, true, BLK_C1);
+  L.c2 = add_layer(L, "mlp_cls_2", 512, 256, true, BLK_C2);
+  L.c3 = add_layer(L, "mlp_cls_3", 256, d.ccls, false, BLK_C3);
+  L.s1 = add_layer(L, "mlp_seg_1", 1088, 512, true, BLK_S1);
+  L.s2 = add_layer(L, "mlp_seg_2", 512, 256, true, BLK_S2);
+  L.s3 = add_layer(L, "mlp_seg_3", 256, 128, true, BLK_S3);
+  L.s4 = add_layer(L, "mlp_seg_4", 128, 128, true, BLK_S4);
+  L.s5 = add_layer(L, "mlp_seg_5", 128, d.cseg, false, BLK_S5);
+  return L;
+}
+
+// ---- workspace ------------------------------------------------------------------------------------------
+struct Arena {
+  char* base = nullptr;
+  size_t off = 0;
+  std::vector<std::pair<std::string, std::pair<size_t, size_t>>>* dir = nullptr;
+  template <class T>
+  T* get(const char* name, size_t count) {
+    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    const size_t o = off;
+    off += bytes;
+    if (dir) dir->push_back({name, {o, count * sizeof(T)}});
+    return base ? reinterpret_cast<T*>(base + o) : nullptr;
+  }
+};
+
+struct CL {   // per-point conv layer state
+  float *Z = nullptr, *part = nullptr, *mean = nullptr, *invstd = nullptr, *scale = nullptr, *shift = nullptr;
+  float *ca = nullptr, *cb = nullptr, *cc = nullptr, *dy = nullptr;
+  int C = 0;
+};
+struct ML {   // extra state of a max-pooled layer
+  float *sgn, *pmax, *g, *zstar, *hs, *e, *nege, *f, *a1part, *a1, *gram, *GW, *Pm, *q, *D, *Wt, *dG;
+  int *pidx, *arg;
+};
+struct DLs {  // dense layer state (rows = B)
+  float *z, *a, *mean, *invstd, *dz, *Wt, *din;
+  int K, C;
+};
+struct TN {
+  CL c1, c2, c3;
+  ML m3;
+  DLs d1, d2;
+  float *R, *dR, *wT, *da2;
+};
+
+struct WS {
+  float *pcn, *cent, *scl;
+  TN iT, fT;
+  CL m11, m12, m21, m22, m23, s1, s2, s3, s4;
+  ML mm23;
+  DLs c1, c2, c3;
+  float *Weff1, *dWeff1, *X64, *dX64, *tmpA12, *gb, *dgb, *gbWt, *dGseg, *dGcls;
+  float *cls_logits, *cls_dlogits, *seg_dlogits, *seg_part, *dense_part, *slabs, *bpart, *s5slab, *R3eye, *regpart;
+  size_t slab_floats;
+};
+
+static long long wgrad_slab_rows(int B, int N, int Ci, int Cj, int* spc_out) {
+  const int bm = (Ci % 128 == 0 && Cj % 128 == 0) ? 128 : 64, bn = (Cj % 128 == 0) ? 128 : 64;
+  const int n_out = (Ci / bm) * (Cj / bn);
+  int target = 512 / n_out;
+  if (target < 1) target = 1;
+  int spc = cdiv(target, B);
+  const int max_spc = cdiv(N, 64);
+  if (spc > max_spc) spc = max_spc;
+  if (spc < 1) spc = 1;
+  int rows = cdiv(cdiv(N, spc), 64) * 64;
+  spc = cdiv(N, rows);
+  *spc_out = spc;
+  return rows;
+}
+static size_t wgrad_slab_floats(int B, int N, int Ci, int Cj) {
+  int spc;
+  wgrad_slab_rows(B, N, Ci, Cj, &spc);
+  return (size_t)B * spc * Ci * Cj;
+}
+
+static void plan_cl(Arena& A, CL& l, const char* nm, long long M, int T, int C, bool store_z, bool training) {
+  std::string n(nm);
+  l.C = C;
+  l.Z = store_z ? A.get<float>((n + ".Z").c_str(), (size_t)M * C) : nullptr;
+  l.part = A.get<float>((n + ".part").c_str(), (size_t)T * 2 * C);
+  l.mean = A.get<float>((n + ".mean").c_str(), C);
+  l.invstd = A.get<float>((n + ".invstd").c_str(), C);
+  l.scale = A.get<float>((n + ".scale").c_str(), C);
+  l.shift = A.get<float>((n + ".shift").c_str(), C);
+  if (training) {
+    l.ca = A.get<float>((n + ".ca").c_str(), C);
+    l.cb = A.get<float>((n + ".cb").c_str(), C);
+    l.cc = A.get<float>((n + ".cc").c_str(), C);
+    l.dy = store_z ? A.get<float>((n + ".dy").c_str(), (size_t)M * C) : nullptr;
+  }
+}
+static void plan_ml(Arena& A, ML& m, const char* nm, int B, long long M, int T, int K, int C, bool training) {
+  std::string n(nm);
+  m.sgn = A.get<float>((n + ".sgn").c_str(), C);
+  m.pmax = A.get<float>((n + ".pmax").c_str(), (size_t)T * C);
+  m.pidx = A.get<int>((n + ".pidx").c_str(), (size_t)T * C);
+  m.g = A.get<float>((n + ".g").c_str(), (size_t)B * C);
+  m.zstar = A.get<float>((n + ".zstar").c_str(), (size_t)B * C);
+  m.arg = A.get<int>((n + ".arg").c_str(), (size_t)B * C);
+  if (training) {
+    m.hs = A.get<float>((n + ".hs").c_str(), (size_t)B * C);
+    m.e = A.get<float>((n + ".e").c_str(), C);
+    m.nege = A.get<float>((n + ".nege").c_str(), C);
+    m.f = A.get<float>((n + ".f").c_str(), C);
+    m.a1part = A.get<float>((n + ".a1part").c_str(), (size_t)T * K);
+    m.a1 = A.get<float>((n + ".a1").c_str(), K);
+    m.gram = A.get<float>((n + ".gram").c_str(), (size_t)K * K);
+    m.GW = A.get<float>((n + ".GW").c_str(), (size_t)K * C);
+    m.Pm = A.get<float>((n + ".Pm").c_str(), (size_t)K * K);
+    m.q = A.get<float>((n + ".q").c_str(), K);
+    m.D = A.get<float>((n + ".D").c_str(), (size_t)M * K);
+    m.Wt = A.get<float>((n + ".Wt").c_str(), (size_t)K * C);
+    m.dG = A.get<float>((n + ".dG").c_str(), (size_t)B * C);
+  }
+}
+static void plan_dl(Arena& A, DLs& d, const char* nm, int B, int K, int C, bool training) {
+  std::string n(nm);
+  d.K = K; d.C = C;
+  d.z = A.get<float>((n + ".z").c_str(), (size_t)B * C);
+  d.a = A.get<float>((n + ".a").c_str(), (size_t)B * C);
+  d.mean = A.get<float>((n + ".mean").c_str(), C);
+  d.invstd = A.get<float>((n + ".invstd").c_str(), C);
+  if (training) {
+    d.dz = A.get<float>((n + ".dz").c_str(), (size_t)B * C);
+    d.Wt = A.get<float>((n + ".Wt").c_str(), (size_t)K * C);
+    d.din = A.get<float>((n + ".din").c_str(), (size_t)B * K);
+  }
+}
+static void plan_tn(Arena& A, TN& t, const char* nm, int B, long long M, int T, int K, bool training) {
+  std::string n(nm);
+  plan_cl(A, t.c1, (n + ".c1").c_str(), M, T, 64, true, training);
+  plan_cl(A, t.c2, (n + ".c2").c_str(), M, T, 128, true, training);
+  plan_cl(A, t.c3, (n + ".c3").c_str(), M, T, 1024, false, training);
+  plan_ml(A, t.m3, (n + ".m3").c_str(), B, M, T, 128, 1024, training);
+  plan_dl(A, t.d1, (n + ".d1").c_str(), B, 1024, 512, training);
+  plan_dl(A, t.d2, (n + ".d2").c_str(), B, 512, 256, training);
+  t.R = A.get<float>((n + ".R").c_str(), (size_t)B * K * K);
+  if (training) {
+    t.dR = A.get<float>((n + ".dR").c_str(), (size_t)B * K * K);
+    t.wT = A.get<float>((n + ".wT").c_str(), (size_t)256 * K * K);
+    t.da2 = A.get<float>((n + ".da2").c_str(), (size_t)B * 256);
+  }
+}
+
+static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool training) {
+  const long long M = (long long)B * N;
+  const int T = B * cdiv(N, 128);
+  w.pcn = A.get<float>("pcn", (size_t)M * 3);
+  w.cent = A.get<float>("centroid", (size_t)B * 3);
+  w.scl = A.get<float>("scale", B);
+  if (!d.vanilla) {
+    plan_tn(A, w.iT, "iT", B, M, T, 3, training);
+    plan_tn(A, w.fT, "fT", B, M, T, 64, training);
+  }
+  plan_cl(A, w.m11, "m11", M, T, 64, true, training);
+  plan_cl(A, w.m12, "m12", M, T, 64, true, training);
+  plan_cl(A, w.m21, "m21", M, T, 64, true, training);
+  plan_cl(A, w.m22, "m22", M, T, 128, true, training);
+  plan_cl(A, w.m23, "m23", M, T, 1024, false, training);
+  plan_ml(A, w.mm23, "mm23", B, M, T, 128, 1024, training);
+  plan_cl(A, w.s1, "s1", M, T, 512, true, training);
+  plan_cl(A, w.s2, "s2", M, T, 256, true, training);
+  plan_cl(A, w.s3, "s3", M, T, 128, true, training);
+  plan_cl(A, w.s4, "s4", M, T, 128, true, training);
+  plan_dl(A, w.c1, "c1", B, 1024, 512, training);
+  plan_dl(A, w.c2, "c2", B, 512, 256, training);
+  plan_dl(A, w.c3, "c3", B, 256, d.ccls, training);
+  w.Weff1 = A.get<float>("Weff1", (size_t)B * 3 * 64);
+  w.X64 = d.vanilla ? nullptr : A.get<float>("X64", (size_t)M * 64);
+  w.gb = A.get<float>("gb", (size_t)B * 512);
+  w.cls_logits = A.get<float>("cls_logits", (size_t)B * d.ccls);
+  w.seg_part = A.get<float>("seg_part", (size_t)cdivll(M, 256) * seg_out_part_stride());
+  w.dense_part = A.get<float>("dense_part", (size_t)32 * B * 4096);
+  w.R3eye = A.get<float>("R3eye", (size_t)B * 9);
+  w.regpart = A.get<float>("regpart", (size_t)2 * B);
+  w.slab_floats = 0;
+  if (training) {
+    w.dWeff1 = A.get<float>("dWeff1", (size_t)B * 3 * 64);
+    w.dX64 = A.get<float>("dX64", (size_t)M * 64);
+    w.tmpA12 = A.get<float>("tmpA12", (size_t)M * 64);
+    w.dgb = A.get<float>("dgb", (size_t)B * 512);
+    w.gbWt = A.get<float>("gbWt", (size_t)1024 * 512);
+    w.dGseg = A.get<float>("dGseg", (size_t)B * 1024);
+    w.dGcls = A.get<float>("dGcls", (size_t)B * 1024);
+    w.cls_dlogits = A.get<float>("cls_dlogits", (size_t)B * d.ccls);
+    w.seg_dlogits = A.get<float>("seg_dlogits", (size_t)M * d.cseg);
+    w.bpart = A.get<float>("bpart", (size_t)T * 2 * 512);
+    w.s5slab = A.get<float>("s5slab", (size_t)T * 128 * d.cseg);
+    size_t sf = 0;
+    const int shapes[][2] = {{64, 64}, {64, 128}, {128, 128}, {64, 512}, {512, 256}, {256, 128}};
+    for (auto& s : shapes) {
+      const size_t f = wgrad_slab_floats(B, N, s[0], s[1]);
+      if (f > sf) sf = f;
+    }
+    const size_t c3f = (size_t)T * 3 * 64;
+    if (c3f > sf) sf = c3f;
+    w.slab_floats = sf;
+    w.slabs = A.get<float>("slabs", sf);
+  }
+}
+
+// ---- the run context ------------------------------------------------------------------------------------
+struct Run {
+  const pn_model_desc& d;
+  const pn_model_io& io;
+  Layout L;
+  WS w;
+  int B, N, T, tpc, prec;
+  long long M;
+  hipStream_t st;
+  bool training;
+  float* P;
+  float* G;
+
+  bool tr(int block) const { return io.trainable ? io.trainable[block] != 0 : true; }
+  bool bn_batch(int block) const { return training && tr(block); }
+  float* p(long long off) const { return off >= 0 ? P + off : nullptr; }
+  float* gr(long long off) const { return (G && off >= 0) ? G + off : nullptr; }
+
+  static pn_operand lazy(const CL& l) {
+    pn_operand o;
+    memset(&o, 0, sizeof(o));
+    o.s1 = l.Z; o.ca = l.scale; o.cc = l.shift; o.ld = l.C; o.lo = 0.f;
+    return o;
+  }
+  static pn_operand plain(const float* x, long long ld) {
+    pn_operand o;
+    memset(&o, 0, sizeof(o));
+    o.s1 = x; o.ld = ld; o.lo = -INFINITY;
+    return o;
+  }
+  static pn_operand dzop(const CL& l) {
+    pn_operand o;
+    memset(&o, 0, sizeof(o));
+    o.s1 = l.dy; o.s2 = l.Z; o.ca = l.ca; o.cb = l.cb; o.cc = l.cc; o.ld = l.C; o.lo = -INFINITY;
+    return o;
+  }
+
+  // ---------------- forward pieces ----------------
+  int bn_fin(const CL& l, const LRef& r) {
+    const int ub = bn_batch(r.block) ? 1 : 0;
+    return bn_finalize(l.part, T, r.cout, M, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub, ub, l.mean,
+                       l.invstd, l.scale, l.shift, st);
+  }
+  int fwd_conv(CL& l, const LRef& r, const pn_operand& x, const float* W, long long wcs, const float* cloud_bias) {
+    PN_TRY(conv_fwd(&x, W, wcs, B, N, r.cin, r.cout, cloud_bias, l.Z, bn_batch(r.block) ? l.part : nullptr, prec,
+                    st));
+    return bn_fin(l, r);
+  }
+  int fwd_max(CL& l, ML& m, const LRef& r, const pn_operand& x) {
+    PN_TRY(sign_of(p(r.gamma), r.cout, m.sgn, st));
+    PN_TRY(conv_fwd_max(&x, p(r.kernel), B, N, r.cin, r.cout, m.sgn, m.pmax, m.pidx, bn_batch(r.block) ? l.part : nullptr, prec, st));
+    PN_TRY(bn_fin(l, r));
+    return max_finalize(m.pmax, m.pidx, B, tpc, r.cout, m.sgn, l.scale, l.shift, m.g, m.zstar, m.arg, st);
+  }
+  int fwd_dense(DLs& dl, const LRef& r, const float* x, int act, const unsigned char* keep) {
+    PN_TRY(dense_partial(x, r.cin, p(r.kernel), B, r.cin, r.cout, w.dense_part, st));
+    const int mode = r.has_bn ? (bn_batch(r.block) ? 1 : 2) : 0;
+    const float ks = 1.f / (1.f - d.dropout_rate);
+    return dense_finalize(w.dense_part, dense_nsplit(r.cin), B, r.cout, p(r.bias), p(r.gamma), p(r.beta), p(r.mm), p(r.mv),
+                          d.bn_momentum, d.bn_eps, mode, act, keep, ks, dl.z, dl.a, dl.mean, dl.invstd, st);
+  }
+  int fwd_tnet(TN& t, const TRef& r, const pn_operand* x) {
+    if (r.K == 3) {
+      PN_TRY(conv3_fwd(w.pcn, p(r.c1.kernel), 0, B, N, 64, t.c1.Z, bn_batch(r.c1.block) ? t.c1.part : nullptr, st));
+      PN_TRY(bn_fin(t.c1, r.c1));
+    } else {
+      PN_TRY(fwd_conv(t.c1, r.c1, *x, p(r.c1.kernel), 0, nullptr));
+    }
+    PN_TRY(fwd_conv(t.c2, r.c2, lazy(t.c1), p(r.c2.kernel), 0, nullptr));
+    PN_TRY(fwd_max(t.c3, t.m3, r.c3, lazy(t.c2)));
+    PN_TRY(fwd_dense(t.d1, r.d1, t.m3.g, 1, nullptr));
+    PN_TRY(fwd_dense(t.d2, r.d2, t.d1.a, 1, nullptr));
+    PN_TRY(dense_partial(t.d2.a, 256, p(r.w), B, 256, r.K * r.K, w.dense_part, st));
+    return dense_finalize(w.dense_part, dense_nsplit(256), B, r.K * r.K, p(r.b), nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0,
+                          nullptr, 1.f, t.R, nullptr, nullptr, nullptr, st);
+  }
+
+  pn_operand x64op() const { return d.vanilla ? lazy(w.m12) : plain(w.X64, 64); }
+
+  int forward() {
+    PN_TRY(normalize(io.pc, B, N, w.pcn, w.cent, w.scl, st));
+    if (!d.vanilla) {
+      PN_TRY(fwd_tnet(w.iT, L.iT, nullptr));
+      PN_TRY(fold3_fwd(w.iT.R, p(L.m11.kernel), B, 64, w.Weff1, st));
+      PN_TRY(conv3_fwd(w.pcn, w.Weff1, 192, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st));
+    } else {
+      PN_TRY(conv3_fwd(w.pcn, p(L.m11.kernel), 0, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st));
+    }
+    PN_TRY(bn_fin(w.m11, L.m11));
+    PN_TRY(fwd_conv(w.m12, L.m12, lazy(w.m11), p(L.m12.kernel), 0, nullptr));
+    if (!d.vanilla) {
+      const pn_operand a12 = lazy(w.m12);
+      PN_TRY(fwd_tnet(w.fT, L.fT, &a12));
+      PN_TRY(conv_fwd(&a12, w.fT.R, 4096, B, N, 64, 64, nullptr, w.X64, nullptr, prec, st));
+    }
+    const pn_operand x64 = x64op();
+    PN_TRY(fwd_conv(w.m21, L.m21, x64, p(L.m21.kernel), 0, nullptr));
+    PN_TRY(fwd_conv(w.m22, L.m22, lazy(w.m21), p(L.m22.kernel), 0, nullptr));
+    PN_TRY(fwd_max(w.m23, w.mm23, L.m23, lazy(w.m22)));
+    const float* Gf = w.mm23.g;
+
+    // classification head (PointNet.py:252-263)
+    PN_TRY(fwd_dense(w.c1, L.c1, Gf, 1, training ? io.keep1 : nullptr));
+    PN_TRY(fwd_dense(w.c2, L.c2, w.c1.a, 1, training ? io.keep2 : nullptr));
+    PN_TRY(dense_partial(w.c2.a, 256, p(L.c3.kernel), B, 256, d.ccls, w.dense_part, st));
+    PN_TRY(dense_finalize(w.dense_part, dense_nsplit(256), B, d.ccls, p(L.c3.bias), nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0,
+                          nullptr, 1.f, w.cls_logits, nullptr, nullptr, nullptr, st));
+    const bool fused = io.labels_cls != nullptr;
+    PN_TRY(softmax_xent_rows(w.cls_logits, B, d.ccls, io.labels_cls, fused ? io.loss_weights[0] / (float)B : 0.f, io.out_cls,
+                             (fused && training) ? w.cls_dlogits : nullptr, io.scalars ? io.scalars + 0 : nullptr,
+                             io.scalars ? io.scalars + 1 : nullptr, st));
+
+    // segmentation head (PointNet.py:268-290)
+    const float* Ws1 = p(L.s1.kernel);
+    PN_TRY(dense_partial(Gf, 1024, Ws1 + 64 * 512, B, 1024, 512, w.dense_part, st));
+    PN_TRY(dense_finalize(w.dense_part, dense_nsplit(1024), B, 512, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0, nullptr,
+                          1.f, w.gb, nullptr, nullptr, nullptr, st));
+    // seg_l1 always emits its forward partials: the backward needs the per-cloud sums of z
+    PN_TRY(conv_fwd(&x64, Ws1, 0, B, N, 64, 512, w.gb, w.s1.Z, w.s1.part, prec, st));
+    PN_TRY(bn_fin(w.s1, L.s1));
+    PN_TRY(fwd_conv(w.s2, L.s2, lazy(w.s1), p(L.s2.kernel), 0, nullptr));
+    PN_TRY(fwd_conv(w.s3, L.s3, lazy(w.s2), p(L.s3.kernel), 0, nullptr));
+    PN_TRY(fwd_conv(w.s4, L.s4, lazy(w.s3), p(L.s4.kernel), 0, nullptr));
+    const pn_operand a4 = lazy(w.s4);
+    const bool fseg = io.labels_seg != nullptr;
+    PN_TRY(seg_out_fwd(&a4, p(L.s5.kernel), p(L.s5.bias), M, 128, d.cseg, io.labels_seg, fseg ? io.loss_weights[1] / (float)M : 0.f,
+                       io.out_seg, (fseg && training) ? w.seg_dlogits : nullptr, fseg ? w.seg_part : nullptr, st));
+    if (fseg && io.scalars)
+      PN_TRY(sum_partials(w.seg_part, (int)cdivll(M, 256), seg_out_part_stride(), 2, io.scalars + 2, st));
+
+    // third output: the input transform (PointNet.py:292); identity for vanilla (:211)
+    if (io.out_R) {
+      if (!d.vanilla) {
+        if (hipMemcpyAsync(io.out_R, w.iT.R, (size_t)B * 9 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
+          set_error("pn_model_forward: copy of R failed");
+          return PN_ERR_LAUNCH;
+        }
+      } else {
+        PN_TRY(fill_eye3(io.out_R, B, st));
+      }
+    }
+    if (io.se3 && io.scalars) {
+      const float* Rp = d.vanilla ? io.out_R : w.iT.R;
+      if (Rp) PN_TRY(mse(Rp, io.se3, B * 9, 0.f, nullptr, io.scalars + 4, st));
+    }
+    if (io.scalars && !d.vanilla) {
+      if (d.reg_in) {
+        PN_TRY(orth_reg(w.iT.R, B, 3, 1e-3f, nullptr, w.regpart, st));
+        PN_TRY(sum_partials(w.regpart, B, 1, 1, io.scalars + 5, st));
+      }
+      if (d.reg_feat) {
+        PN_TRY(orth_reg(w.fT.R, B, 64, 1e-3f, nullptr, w.regpart + B, st));
+        PN_TRY(sum_partials(w.regpart + B, B, 1, 1, io.scalars + 6, st));
+      }
+    }
+    return PN_OK;
+  }
+
+  // ---------------- backward pieces ----------------
+  int wgrad_to(const pn_operand& a, const pn_operand& b, int Ci, int Cj, float* out, bool per_cloud) {
+    int spc;
+    const int rows = (int)wgrad_slab_rows(B, N, Ci, Cj, &spc);
+    if ((size_t)B * spc * Ci * Cj > w.slab_floats) {
+      set_error("wgrad: slab scratch too small");
+      return PN_ERR_WORKSPACE;
+    }
+    PN_TRY(conv_wgrad(&a, &b, B, N, Ci, Cj, rows, w.slabs, prec, st));
+    return slab_reduce(w.slabs, B * spc, per_cloud ? spc : B * spc, (long long)Ci * Cj, out, st);
+  }
+  int bn_bwd_fin(const CL& l, const LRef& r, const float* part) {
+    const int bs = bn_batch(r.block) ? 1 : 0;
+    return bn_bwd_finalize(part, T, r.cout, M, p(r.gamma), l.mean, l.invstd, bs, bs ? gr(r.gamma) : nullptr, bs ? gr(r.beta) : nullptr,
+                           l.ca, l.cb, l.cc, st);
+  }
+  // standard interior step: given cur.dy (+ w.bpart holding its stats) produce prev.dy and cur's weight gradient
+  int bwd_step(CL& cur, const LRef& rc, CL& prev, const pn_operand& prev_act) {
+    PN_TRY(bn_bwd_fin(cur, rc, w.bpart));
+    const pn_operand dz = dzop(cur);
+    if (tr(rc.block) && G) PN_TRY(wgrad_to(prev_act, dz, rc.cin, rc.cout, gr(rc.kernel), false));
+    return conv_bwd_data(&dz, p(rc.kernel), 0, B, N, rc.cout, rc.cin, nullptr, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st);
+  }
+  // backward of a max-pooled layer: dG (B,C) -> prev.dy (+stats in w.bpart), this layer's parameter gradients
+  int bwd_max(CL& l, ML& m, const LRef& r, const pn_operand& xop, CL& prev, const float* dG) {
+    const int K = r.cin, C = r.cout;
+    const int bs = bn_batch(r.block) ? 1 : 0;
+    const bool wg = tr(r.block) && G;
+    PN_TRY(maxbwd_prep(dG, m.g, m.zstar, B, C, l.mean, l.invstd, l.scale, bs, M, m.hs, m.e, m.nege, m.f, wg ? gr(r.gamma) : nullptr,
+                       wg ? gr(r.beta) : nullptr, st));
+    if (wg) {
+      PN_TRY(wgrad_to(xop, xop, K, K, m.gram, false));
+      PN_TRY(colsum_lazy(&xop, B, N, K, m.a1part, st));
+      PN_TRY(slab_reduce(m.a1part, T, T, K, m.a1, st));
+      const pn_operand gop = plain(m.gram, K);
+      PN_TRY(conv_fwd(&gop, p(r.kernel), 0, 1, K, K, C, nullptr, m.GW, nullptr, PN_PREC_BF16X3, st));
+      PN_TRY(maxbwd_dw(&xop, m.arg, m.hs, B, N, K, C, m.a1, m.f, m.e, m.GW, gr(r.kernel), st));
+    }
+    pn_operand wop = plain(p(r.kernel), C);
+    wop.ca = m.nege;
+    PN_TRY(conv_bwd_data(&wop, p(r.kernel), 0, 1, K, C, K, nullptr, nullptr, nullptr, nullptr, m.Pm, nullptr, PN_PREC_BF16X3, st));
+    PN_TRY(maxbwd_q(p(r.kernel), m.f, K, C, m.q, st));
+    PN_TRY(transpose(p(r.kernel), K, C, m.Wt, st));
+    PN_TRY(maxbwd_scatter(m.arg, m.hs, m.Wt, m.q, B, N, K, C, m.D, st));
+    return conv_bwd_data(&xop, m.Pm, 0, B, N, K, K, m.D, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st);
+  }
+  // dense layer backward: da (B,C) -> dx (B,K) written to dx_out; parameter gradients
+  int bwd_dense(DLs& dl, const LRef& r, const float* xin, const float* da, int act, const unsigned char* keep, float* dx_out) {
+    const int mode = r.has_bn ? (bn_batch(r.block) ? 1 : 2) : 0;
+    const bool wg = tr(r.block) && G;
+    const float ks = 1.f / (1.f - d.dropout_rate);
+    PN_TRY(dense_bwd_pre(da, dl.z, B, r.cout, p(r.gamma), p(r.beta), dl.mean, dl.invstd, mode, act, keep, ks, dl.dz,
+                         (wg && mode == 1) ? gr(r.gamma) : nullptr, (wg && mode == 1) ? gr(r.beta) : nullptr,
+                         (wg && mode == 0) ? gr(r.bias) : nullptr, st));
+    if (wg) PN_TRY(dense_wgrad(xin, r.cin, dl.dz, B, r.cin, r.cout, gr(r.kernel), st));
+    if (dx_out) {
+      PN_TRY(transpose(p(r.kernel), r.cin, r.cout, dl.Wt, st));
+      PN_TRY(dense_partial(dl.dz, r.cout, dl.Wt, B, r.cout, r.cin, w.dense_part, st));
+      PN_TRY(dense_finalize(w.dense_part, dense_nsplit(r.cout), B, r.cin, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0,
+                            nullptr, 1.f, dx_out, nullptr, nullptr, nullptr, st));
+    }
+    return PN_OK;
+  }
+  // T-Net backward from dR (B,K*K); leaves c1's dz coefficients ready (c1.dy + c1.ca/cb/cc)
+  int bwd_tnet(TN& t, const TRef& r, const pn_operand* x) {
+    const int KK = r.K * r.K;
+    const bool wg = tr(r.c1.block) && G;
+    if (wg) {
+      PN_TRY(sum_partials(t.dR, B, KK, KK, gr(r.b), st));                      // db = sum_b dR
+      PN_TRY(dense_wgrad(t.d2.a, 256, t.dR, B, 256, KK, gr(r.w), st));          // dw = a2^T dR
+    }
+    PN_TRY(transpose(p(r.w), 256, KK, t.wT, st));
+    PN_TRY(dense_partial(t.dR, KK, t.wT, B, KK, 256, w.dense_part, st));
+    PN_TRY(dense_finalize(w.dense_part, dense_nsplit(KK), B, 256, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0, nullptr, 1.f,
+                          t.da2, nullptr, nullptr, nullptr, st));
+    PN_TRY(bwd_dense(t.d2, r.d2, t.d1.a, t.da2, 1, nullptr, t.d2.din));
+    PN_TRY(bwd_dense(t.d1, r.d1, t.m3.g, t.d2.din, 1, nullptr, t.m3.dG));
+    PN_TRY(bwd_max(t.c3, t.m3, r.c3, lazy(t.c2), t.c2, t.m3.dG));
+    // c2 -> c1
+    PN_TRY(bwd_step(t.c2, r.c2, t.c1, lazy(t.c1)));
+    PN_TRY(bn_bwd_fin(t.c1, r.c1, w.bpart));
+    const pn_operand dz1 = dzop(t.c1);
+    if (wg) {
+      if (r.K == 3) {
+        PN_TRY(conv3_wgrad(w.pcn, &dz1, B, N, 64, w.slabs, st));
+        PN_TRY(slab_reduce(w.slabs, T, T, 3 * 64, gr(r.c1.kernel), st));
+      } else {
+        PN_TRY(wgrad_to(*x, dz1, 64, 64, gr(r.c1.kernel), false));
+      }
+    }
+    return PN_OK;
+  }
+
+  int backward(const float* d_cls, const float* d_seg, const float* d_R) {
+    if (!G) {
+      set_error("pn_model_backward: grads buffer is NULL");
+      return PN_ERR_INVALID_ARGUMENT;
+    }
+    if (hipMemsetAsync(G, 0, (size_t)L.total * sizeof(float), st) != hipSuccess) {
+      set_error("pn_model_backward: memset failed");
+      return PN_ERR_LAUNCH;
+    }
+    const pn_operand x64 = x64op();
+    const float* Ws1 = p(L.s1.kernel);
+    const bool fused = io.labels_cls != nullptr || io.labels_seg != nullptr;
+    bool has_seg = d_seg != nullptr || (io.labels_seg != nullptr && io.loss_weights[1] != 0.f);
+    bool has_cls = d_cls != nullptr || (io.labels_cls != nullptr && io.loss_weights[0] != 0.f);
+    (void)fused;
+
+    // ---- segmentation head ----
+    bool have_dx64 = false;     // w.dX64 holds the seg head's contribution to d(X_64)
+    bool have_dGseg = false;
+    if (has_seg) {
+      if (d_seg) PN_TRY(softmax_bwd_rows(io.out_seg, d_seg, M, d.cseg, w.seg_dlogits, st));
+      const pn_operand a4 = lazy(w.s4);
+      PN_TRY(seg_out_bwd(&a4, p(L.s5.kernel), w.seg_dlogits, B, N, 128, d.cseg, w.s4.dy, w.bpart, w.s5slab, st));
+      if (tr(BLK_S5)) {
+        PN_TRY(slab_reduce(w.s5slab, T, T, (long long)128 * d.cseg, gr(L.s5.kernel), st));
+        PN_TRY(sum_partials(w.seg_dlogits, (int)M, d.cseg, d.cseg, gr(L.s5.bias), st));
+      }
+      PN_TRY(bwd_step(w.s4, L.s4, w.s3, lazy(w.s3)));
+      PN_TRY(bwd_step(w.s3, L.s3, w.s2, lazy(w.s2)));
+      PN_TRY(bwd_step(w.s2, L.s2, w.s1, lazy(w.s1)));
+      PN_TRY(bn_bwd_fin(w.s1, L.s1, w.bpart));
+      const pn_operand dz1 = dzop(w.s1);
+      PN_TRY(cloud_bias_grad(w.bpart, w.s1.part, B, tpc, N, 512, w.s1.ca, w.s1.cb, w.s1.cc, w.dgb, st));
+      if (tr(BLK_S1)) {
+        PN_TRY(wgrad_to(x64, dz1, 64, 512, gr(L.s1.kernel), false));
+        PN_TRY(dense_wgrad(w.mm23.g, 1024, w.dgb, B, 1024, 512, gr(L.s1.kernel) + 64 * 512, st));
+      }
+      PN_TRY(transpose(Ws1 + 64 * 512, 1024, 512, w.gbWt, st));
+      PN_TRY(dense_partial(w.dgb, 512, w.gbWt, B, 512, 1024, w.dense_part, st));
+      PN_TRY(dense_finalize(w.dense_part, dense_nsplit(512), B, 1024, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0, nullptr,
+                            1.f, w.dGseg, nullptr, nullptr, nullptr, st));
+      have_dGseg = true;
+      PN_TRY(conv_bwd_data(&dz1, Ws1, 0, B, N, 512, 64, nullptr, nullptr, nullptr, nullptr, w.dX64, nullptr, prec, st));
+      have_dx64 = true;
+    }
+
+    // ---- classification head ----
+    bool have_dGcls = false;
+    if (has_cls) {
+      if (d_cls) PN_TRY(softmax_bwd_rows(io.out_cls, d_cls, B, d.ccls, w.cls_dlogits, st));
+      PN_TRY(bwd_dense(w.c3, L.c3, w.c2.a, w.cls_dlogits, 0, nullptr, w.c3.din));
+      PN_TRY(bwd_dense(w.c2, L.c2, w.c1.a, w.c3.din, 1, io.keep2, w.c2.din));
+      PN_TRY(bwd_dense(w.c1, L.c1, w.mm23.g, w.c2.din, 1, io.keep1, w.dGcls));
+      have_dGcls = true;
+    }
+    float* dG = w.mm23.dG;
+    if (hipMemsetAsync(dG, 0, (size_t)B * 1024 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return PN_ERR_LAUNCH; }
+    if (have_dGcls) PN_TRY(axpy(w.dGcls, 1.f, dG, (long long)B * 1024, st));
+    if (have_dGseg) PN_TRY(axpy(w.dGseg, 1.f, dG, (long long)B * 1024, st));
+
+    const bool have_R_grad = !d.vanilla && (d_R != nullptr || (io.se3 != nullptr && io.loss_weights[2] != 0.f) || d.reg_in);
+    const bool trunk = has_seg || has_cls || (!d.vanilla && d.reg_feat);
+    if (!trunk && !have_R_grad) return PN_OK;
+
+    // ---- mlp_2 ----
+    if (has_seg || has_cls) {
+      PN_TRY(bwd_max(w.m23, w.mm23, L.m23, lazy(w.m22), w.m22, dG));
+      PN_TRY(bwd_step(w.m22, L.m22, w.m21, lazy(w.m21)));
+      PN_TRY(bn_bwd_fin(w.m21, L.m21, w.bpart));
+      const pn_operand dz21 = dzop(w.m21);
+      if (tr(BLK_M21)) PN_TRY(wgrad_to(x64, dz21, 64, 64, gr(L.m21.kernel), false));
+      if (d.vanilla) {
+        PN_TRY(conv_bwd_data(&dz21, p(L.m21.kernel), 0, B, N, 64, 64, have_dx64 ? w.dX64 : nullptr, w.m12.Z, w.m12.scale, w.m12.shift,
+                             w.m12.dy, w.bpart, prec, st));
+      } else {
+        PN_TRY(conv_bwd_data(&dz21, p(L.m21.kernel), 0, B, N, 64, 64, have_dx64 ? w.dX64 : nullptr, nullptr, nullptr, nullptr, w.dX64,
+                             nullptr, prec, st));
+      }
+    }
+    if (!d.vanilla) {
+      // ---- feature transform: X_64 = A_12 . R_64 ----
+      if (hipMemsetAsync(w.fT.dR, 0, (size_t)B * 4096 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return PN_ERR_LAUNCH; }
+      const pn_operand a12 = lazy(w.m12);
+      const bool have_dx = has_seg || has_cls;
+      if (have_dx) {
+        const pn_operand dx = plain(w.dX64, 64);
+        PN_TRY(wgrad_to(a12, dx, 64, 64, w.fT.dR, true));
+        PN_TRY(conv_bwd_data(&dx, w.fT.R, 4096, B, N, 64, 64, nullptr, nullptr, nullptr, nullptr, w.tmpA12, nullptr, prec, st));
+      }
+      if (d.reg_feat) PN_TRY(orth_reg(w.fT.R, B, 64, 1e-3f, w.fT.dR, nullptr, st));
+      PN_TRY(bwd_tnet(w.fT, L.fT, &a12));
+      const pn_operand dzf1 = dzop(w.fT.c1);
+      PN_TRY(conv_bwd_data(&dzf1, p(L.fT.c1.kernel), 0, B, N, 64, 64, have_dx ? w.tmpA12 : nullptr, w.m12.Z, w.m12.scale, w.m12.shift,
+                           w.m12.dy, w.bpart, prec, st));
+    }
+    // ---- mlp_1 ----
+    PN_TRY(bwd_step(w.m12, L.m12, w.m11, lazy(w.m11)));
+    PN_TRY(bn_bwd_fin(w.m11, L.m11, w.bpart));
+    const pn_operand dz11 = dzop(w.m11);
+    PN_TRY(conv3_wgrad(w.pcn, &dz11, B, N, 64, w.slabs, st));
+    if (d.vanilla) {
+      if (tr(BLK_M11)) PN_TRY(slab_reduce(w.slabs, T, T, 3 * 64, gr(L.m11.kernel), st));
+      return PN_OK;
+    }
+    PN_TRY(slab_reduce(w.slabs, T, tpc, 3 * 64, w.dWeff1, st));
+    if (hipMemsetAsync(w.iT.dR, 0, (size_t)B * 9 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return PN_ERR_LAUNCH; }
+    PN_TRY(fold3_bwd(w.dWeff1, w.iT.R, p(L.m11.kernel), B, 64, w.iT.dR, tr(BLK_M11) ? gr(L.m11.kernel) : nullptr, st));
+    // ---- input transform ----
+    if (d_R) PN_TRY(axpy(d_R, 1.f, w.iT.dR, (long long)B * 9, st));
+    if (io.se3 && io.loss_weights[2] != 0.f && !d_R)
+      PN_TRY(mse(w.iT.R, io.se3, B * 9, 2.f * io.loss_weights[2] / (float)(B * 9), w.iT.dR, nullptr, st));
+    if (d.reg_in) PN_TRY(orth_reg(w.iT.R, B, 3, 1e-3f, w.iT.dR, nullptr, st));
+    return bwd_tnet(w.iT, L.iT, nullptr);
+  }
+};
+
+static int check_desc(const pn_model_desc* d) {
+  PN_CHECK_ARG(d != nullptr, "pn_model: null descriptor");
+  PN_CHECK_ARG(d->ccls >= 1 && d->ccls <= 4096, "pn_model: classification width %d out of range", d->ccls);
+  PN_CHECK_ARG(d->cseg >= 1 && d->cseg <= 16, "pn_model: segmentation width %d not in [1,16]", d->cseg);
+  PN_CHECK_ARG(d->dropout_rate >= 0.f && d->dropout_rate < 1.f, "pn_model: dropout rate must be in [0,1)");
+  PN_CHECK_ARG(d->prec == PN_PREC_BF16 || d->prec == PN_PREC_BF16X3, "pn_model: bad prec %d", d->prec);
+  return PN_OK;
+}
+
+static int make_run(const pn_model_desc* d, const pn_model_io* io, hipStream_t st, Run*& out) {
+  PN_TRY(check_desc(d));
+  PN_CHECK_ARG(io && io->pc && io->params && io->workspace, "pn_model: null io pointer");
+  PN_CHECK_ARG(io->B > 0 && io->N > 0, "pn_model: B and N must be positive (B=%d N=%d)", io->B, io->N);
+  PN_CHECK_ARG(io->out_cls && io->out_seg, "pn_model: output buffers are required");
+  Run* r = new Run{*d, *io};
+  r->L = make_layout(*d);
+  r->B = io->B; r->N = io->N; r->M = (long long)io->B * io->N;
+  r->tpc = cdiv(io->N, 128); r->T = io->B * r->tpc;
+  r->prec = d->prec; r->st = st; r->training = io->training != 0;
+  r->P = io->params; r->G = io->grads;
+  Arena A;
+  A.base = reinterpret_cast<char*>(io->workspace);
+  plan_ws(A, r->w, *d, io->B, io->N, r->training);
+  if (A.off > io->workspace_bytes) {
+    set_error("pn_model: workspace too small (%zu needed, %zu given)", A.off, io->workspace_bytes);
+    delete r;
+    return PN_ERR_WORKSPACE;
+  }
+  out = r;
+  return PN_OK;
+}
+
+}  // namespace pn
+
+using namespace pn;
+
+extern "C" {
+
+int pn_model_num_slots(const pn_model_desc* d) {
+  if (check_desc(d) != PN_OK) return -1;
+  return (int)make_layout(*d).slots.size();
+}
+int64_t pn_model_param_floats(const pn_model_desc* d) {
+  if (check_desc(d) != PN_OK) return -1;
+  return make_layout(*d).total;
+}
+int pn_model_slot_info(const pn_model_desc* d, int i, pn_slot_info* out) {
+  PN_TRY(check_desc(d));
+  const Layout L = make_layout(*d);
+  PN_CHECK_ARG(out && i >= 0 && i < (int)L.slots.size(), "pn_model_slot_info: index %d out of range", i);
+  const Slot& s = L.slots[i];
+  memset(out, 0, sizeof(*out));
+  strncpy(out->name, s.name.c_str(), sizeof(out->name) - 1);
+  out->offset = s.off; out->rows = s.rows; out->cols = s.cols; out->kind = s.kind; out->block = s.block;
+  return PN_OK;
+}
+size_t pn_model_workspace_bytes(const pn_model_desc* d, int B, int N, int training) {
+  if (check_desc(d) != PN_OK || B <= 0 || N <= 0) return 0;
+  Arena A;
+  WS w;
+  plan_ws(A, w, *d, B, N, training != 0);
+  return A.off;
+}
+int pn_model_ws_lookup(const pn_model_desc* d, int B, int N, int training, const char* name, int64_t* offset, int64_t* bytes) {
+  PN_TRY(check_desc(d));
+  PN_CHECK_ARG(name && offset && bytes && B > 0 && N > 0, "pn_model_ws_lookup: bad arguments");
+  Arena A;
+  WS w;
+  std::vector<std::pair<std::string, std::pair<size_t, size_t>>> dir;
+  A.dir = &dir;
+  plan_ws(A, w, *d, B, N, training != 0);
+  for (auto& e : dir)
+    if (e.first == name) {
+      *offset = (int64_t)e.second.first;
+      *bytes = (int64_t)e.second.second;
+      return PN_OK;
+    }
+  set_error("pn_model_ws_lookup: no workspace buffer named '%s'", name);
+  return PN_ERR_INVALID_ARGUMENT;
+}
+int pn_model_forward(const pn_model_desc* d, const pn_model_io* io, pn_stream stream) {
+  Run* r = nullptr;
+  PN_TRY(make_run(d, io, reinterpret_cast<hipStream_t>(stream), r));
+  const int rc = r->forward();
+  delete r;
+  return rc;
+}
+int pn_model_backward(const pn_model_desc* d, const pn_model_io* io, const float* d_cls, const float* d_seg, const float* d_R,
+                      pn_stream stream) {
+  Run* r = nullptr;
+  PN_TRY(make_run(d, io, reinterpret_cast<hipStream_t>(stream), r));
+  int rc;
+  if (!r->training) {
+    set_error("pn_model_backward: the forward pass must have run with training=1");
+    rc = PN_ERR_INVALID_ARGUMENT;
+  } else {
+    rc = r->backward(d_cls, d_seg, d_R);
+  }
+  delete r;
+  return rc;
+}
+int pn_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int32_t* iterations, float* alpha_scratch, float lr0,
+                 float decay_rate, float decay_steps, float beta1, float beta2, float eps, float grad_scale, pn_stream stream) {
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  PN_CHECK_ARG(iterations && alpha_scratch, "pn_adam_step: null pointer");
+  PN_TRY(adam_schedule(iterations, lr0, decay_rate, decay_steps, beta1, beta2, alpha_scratch, alpha_scratch + 1, st));
+  return adam(params, grads, m, v, n, alpha_scratch, beta1, beta2, eps, grad_scale, st);
+}
+
+}  // extern "C"

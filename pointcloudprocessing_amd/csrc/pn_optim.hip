@@ -1,0 +1,210 @@
+// Optimizer, scalar losses and the 3x3 transform fold (gfx950).  Reference semantics:
+// keras.optimizers.Adam + ExponentialDecay (point_cloud_analysis/pointnet_train.py:310-319),
+// keras.losses.MeanSquaredError on the input transform (pointnet_train.py:339),
+// the orthogonality regulariser 1e-3 * l2_loss(I - R R^T) (pointnet/PointNet.py:447-451).
+#include "pn_common.h"
+
+namespace pn {
+
+// state[0] = iterations (as float bits of an int), hyper[0] = alpha for this step.  One thread; keeps the
+// whole schedule on the device so a captured hipGraph replays with the right learning rate.
+__global__ void adam_schedule_kernel(int* __restrict__ iterations, float lr0, float decay_rate, float decay_steps, float beta1,
+                                     float beta2, float* __restrict__ alpha_out, float* __restrict__ lr_out) {
+  const int it = *iterations;           // optimizer.iterations before this update
+  const double lr = (double)lr0 * pow((double)decay_rate, (double)it / (double)decay_steps);
+  const double t = (double)(it + 1);
+  const double alpha = lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t));
+  *alpha_out = (float)alpha;
+  if (lr_out) *lr_out = (float)lr;
+  *iterations = it + 1;
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, const float* __restrict__ alpha_p, float beta1,
+                                                   float beta2, float eps, float grad_scale) {
+  const float alpha = *alpha_p;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = g[i] * grad_scale;
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+    const float vi = v[i] + (gi * gi - v[i]) * (1.f - beta2);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= mi * alpha / (sqrtf(vi) + eps);
+  }
+}
+
+// MeanSquaredError over (B,3,3) and its gradient (weight w folded in): out loss_sum = sum (R-T)^2
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ R, const float* __restrict__ T, int n, float gscale,
+                                                  float* __restrict__ dR, float* __restrict__ loss_sum) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = R[i] - T[i];
+    s = fmaf(d, d, s);
+    if (dR) dR[i] += gscale * d;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+    for (int i = 0; i < 256; ++i) a += red[i];
+    if (loss_sum) *loss_sum = a;
+  }
+}
+
+// Orthogonality regulariser per cloud: E = I - R R^T; loss += c/2 * sum E^2; dR += -2c E R.   block per cloud
+__global__ __launch_bounds__(256) void orth_reg_kernel(const float* __restrict__ R, int K, float c, float* __restrict__ dR,
+                                                       float* __restrict__ loss_part) {
+  extern __shared__ float sm[];
+  float* Rs = sm;            // K*K
+  float* Es = sm + K * K;    // K*K
+  __shared__ float red[256];
+  const int b = blockIdx.x;
+  const float* Rb = R + (long long)b * K * K;
+  for (int i = threadIdx.x; i < K * K; i += 256) Rs[i] = Rb[i];
+  __syncthreads();
+  float s = 0.f;
+  for (int ij = threadIdx.x; ij < K * K; ij += 256) {
+    const int i = ij / K, j = ij % K;
+    float d = 0.f;
+    for (int k = 0; k < K; ++k) d = fmaf(Rs[i * K + k], Rs[j * K + k], d);
+    const float e = (i == j ? 1.f : 0.f) - d;
+    Es[ij] = e;
+    s = fmaf(e, e, s);
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float a = 0.f;
+    for (int i = 0; i < 256; ++i) a += red[i];
+    if (loss_part) loss_part[b] = 0.5f * c * a;
+  }
+  if (dR) {
+    float* dRb = dR + (long long)b * K * K;
+    for (int ij = threadIdx.x; ij < K * K; ij += 256) {
+      const int i = ij / K, j = ij % K;
+      float d = 0.f;
+      for (int k = 0; k < K; ++k) d = fmaf(Es[i * K + k], Rs[k * K + j], d);
+      dRb[ij] += -2.f * c * d;
+    }
+  }
+}
+
+// Weff[b] (3,C) = R[b] (3,3) @ W (3,C)           -- tf.matmul(pc, R) folded into the first kernel
+__global__ __launch_bounds__(256) void fold3_fwd_kernel(const float* __restrict__ R, const float* __restrict__ W, int C,
+                                                        float* __restrict__ Weff) {
+  const int b = blockIdx.x;
+  for (int t = threadIdx.x; t < 3 * C; t += 256) {
+    const int i = t / C, c = t % C;
+    const float* r = R + (long long)b * 9 + i * 3;
+    Weff[(long long)b * 3 * C + t] = fmaf(r[2], W[2 * C + c], fmaf(r[1], W[C + c], r[0] * W[c]));
+  }
+}
+// dR[b][i][k] += sum_c dWeff[b][i][c] W[k][c]
+__global__ __launch_bounds__(64) void fold3_bwd_r_kernel(const float* __restrict__ dWeff, const float* __restrict__ W, int C,
+                                                         float* __restrict__ dR) {
+  const int b = blockIdx.x, ik = blockIdx.y, i = ik / 3, k = ik % 3;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < C; c += 64) s = fmaf(dWeff[((long long)b * 3 + i) * C + c], W[k * C + c], s);
+  s = wave_sum(s);
+  if (threadIdx.x == 0) dR[(long long)b * 9 + ik] += s;
+}
+// dW[k][c] = sum_b sum_i R[b][i][k] dWeff[b][i][c]
+__global__ __launch_bounds__(256) void fold3_bwd_w_kernel(const float* __restrict__ dWeff, const float* __restrict__ R, int B, int C,
+                                                          float* __restrict__ dW) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= 3 * C) return;
+  const int k = t / C, c = t % C;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b)
+    for (int i = 0; i < 3; ++i) s = fmaf(R[(long long)b * 9 + i * 3 + k], dWeff[((long long)b * 3 + i) * C + c], s);
+  dW[t] = s;
+}
+
+// y[i] = a*x[i] + y[i] / plain helpers
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float a, float* __restrict__ y, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = fmaf(a, x[i], y[i]);
+}
+
+// seg_l1 global-feature bias gradient: dgb[b][c] = ca[c]*sum_n dyhat + cb[c]*sum_n z + N*cc[c]
+__global__ __launch_bounds__(256) void cloud_bias_grad_kernel(const float* __restrict__ bwd_part, const float* __restrict__ fwd_part,
+                                                              int tiles_per_cloud, int N, int C, const float* __restrict__ ca,
+                                                              const float* __restrict__ cb, const float* __restrict__ cc,
+                                                              float* __restrict__ dgb) {
+  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  float sd = 0.f, sz = 0.f;
+  for (int t = 0; t < tiles_per_cloud; ++t) {
+    const long long o = ((long long)b * tiles_per_cloud + t) * 2 * C + c;
+    sd += bwd_part[o];
+    sz += fwd_part[o];
+  }
+  dgb[(long long)b * C + c] = fmaf(ca[c], sd, fmaf(cb[c], sz, (float)N * cc[c]));
+}
+
+__global__ void fill_eye3_kernel(float* __restrict__ out, int B) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < B * 9) out[i] = ((i % 9) % 4 == 0) ? 1.f : 0.f;
+}
+int fill_eye3(float* out, int B, hipStream_t st) {
+  hipLaunchKernelGGL(fill_eye3_kernel, dim3(cdiv(B * 9, 256)), dim3(256), 0, st, out, B);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+int adam_schedule(int* iterations, float lr0, float decay_rate, float decay_steps, float beta1, float beta2, float* alpha, float* lr,
+                  hipStream_t st) {
+  hipLaunchKernelGGL(adam_schedule_kernel, dim3(1), dim3(1), 0, st, iterations, lr0, decay_rate, decay_steps, beta1, beta2, alpha, lr);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+int adam(float* p, const float* g, float* m, float* v, long long n, const float* alpha, float beta1, float beta2, float eps,
+         float grad_scale, hipStream_t st) {
+  PN_CHECK_ARG(p && g && m && v && alpha && n > 0, "pn_adam: bad arguments");
+  const long long blocks = cdivll(n, 256);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, p, g, m, v, n, alpha, beta1,
+                     beta2, eps, grad_scale);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+int mse(const float* R, const float* T, int n, float gscale, float* dR, float* loss_sum, hipStream_t st) {
+  hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, st, R, T, n, gscale, dR, loss_sum);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+int orth_reg(const float* R, int B, int K, float c, float* dR, float* loss_part, hipStream_t st) {
+  PN_CHECK_ARG(K <= 64, "orth_reg: K must be <= 64");
+  hipLaunchKernelGGL(orth_reg_kernel, dim3(B), dim3(256), (size_t)2 * K * K * sizeof(float), st, R, K, c, dR, loss_part);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+int fold3_fwd(const float* R, const float* W, int B, int C, float* Weff, hipStream_t st) {
+  hipLaunchKernelGGL(fold3_fwd_kernel, dim3(B), dim3(256), 0, st, R, W, C, Weff);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+int fold3_bwd(const float* dWeff, const float* R, const float* W, int B, int C, float* dR, float* dW, hipStream_t st) {
+  if (dR) {
+    hipLaunchKernelGGL(fold3_bwd_r_kernel, dim3(B, 9), dim3(64), 0, st, dWeff, W, C, dR);
+    PN_CHECK_LAUNCH();
+  }
+  if (dW) {
+    hipLaunchKernelGGL(fold3_bwd_w_kernel, dim3(cdiv(3 * C, 256)), dim3(256), 0, st, dWeff, R, B, C, dW);
+    PN_CHECK_LAUNCH();
+  }
+  return PN_OK;
+}
+int axpy(const float* x, float a, float* y, long long n, hipStream_t st) {
+  hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, st, x, a, y, n);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+int cloud_bias_grad(const float* bwd_part, const float* fwd_part, int B, int tpc, int N, int C, const float* ca, const float* cb,
+                    const float* cc, float* dgb, hipStream_t st) {
+  hipLaunchKernelGGL(cloud_bias_grad_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, st, bwd_part, fwd_part, tpc, N, C, ca, cb, cc, dgb);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+}  // namespace pn

@@ -1,0 +1,311 @@
+// Bandwidth-bound per-point kernels and the small finalisers between contractions (gfx950).
+#include "pn_common.h"
+
+namespace pn {
+
+// ------------------------------------------------------------------------------------------------------
+// PointCloudNormalization (reference: pointnet/PointNet.py:691-706).  One 1024-thread block per cloud:
+// pass 1 centroid (wave shuffle + LDS), pass 2 max radius, pass 3 write.  12 B/point in, 12 B/point out;
+// the cloud (<= a few MB) stays in L2 between passes.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void normalize_kernel(const float* __restrict__ xyz, int N, float* __restrict__ out,
+                                                         float* __restrict__ centroid, float* __restrict__ scale) {
+  __shared__ float red[16][3];
+  __shared__ float bc[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* p = xyz + (long long)b * N * 3;
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  for (int i = tid; i < N; i += 1024) {
+    sx += p[3 * i]; sy += p[3 * i + 1]; sz += p[3 * i + 2];
+  }
+  sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
+  if (lane == 0) { red[wave][0] = sx; red[wave][1] = sy; red[wave][2] = sz; }
+  __syncthreads();
+  if (tid < 3) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[w][tid];
+    bc[tid] = s / (float)N;
+  }
+  __syncthreads();
+  const float cx = bc[0], cy = bc[1], cz = bc[2];
+  float md = 0.f;
+  for (int i = tid; i < N; i += 1024) {
+    const float dx = p[3 * i] - cx, dy = p[3 * i + 1] - cy, dz = p[3 * i + 2] - cz;
+    md = fmaxf(md, sqrtf(dx * dx + dy * dy + dz * dz));
+  }
+  md = wave_max(md);
+  __syncthreads();
+  if (lane == 0) red[wave][0] = md;
+  __syncthreads();
+  if (tid == 0) {
+    float m = 0.f;
+    for (int w = 0; w < 16; ++w) m = fmaxf(m, red[w][0]);
+    bc[3] = fmaxf(m, 1e-7f);
+  }
+  __syncthreads();
+  const float sc = bc[3];
+  float* o = out + (long long)b * N * 3;
+  for (int i = tid; i < N; i += 1024) {
+    o[3 * i] = (p[3 * i] - cx) / sc;
+    o[3 * i + 1] = (p[3 * i + 1] - cy) / sc;
+    o[3 * i + 2] = (p[3 * i + 2] - cz) / sc;
+  }
+  if (tid == 0) {
+    if (centroid) { centroid[3 * b] = cx; centroid[3 * b + 1] = cy; centroid[3 * b + 2] = cz; }
+    if (scale) scale[b] = sc;
+  }
+}
+
+int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st) {
+  PN_CHECK_ARG(xyz && out, "pn_normalize: null pointer");
+  PN_CHECK_ARG(B > 0 && N > 0, "pn_normalize: B and N must be positive (B=%d N=%d)", B, N);
+  hipLaunchKernelGGL(normalize_kernel, dim3(B), dim3(1024), 0, st, xyz, N, out, centroid, scale);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// ConvLayer with Cin = 3 (PointNet.py:406, 120): lane <-> output channel, a wave walks rows; the 3 inputs
+// of a row are wave-uniform loads.  Tile = 128 rows of one cloud, 4 waves x 32 rows.  C = 64 * CG.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv3_fwd_kernel(const float* __restrict__ x3, const float* __restrict__ w,
+                                                        long long wcs, int N, int C, int tiles_per_cloud,
+                                                        float* __restrict__ z, float* __restrict__ part) {
+  __shared__ float red[4][2][64];
+  const int bx = blockIdx.x, cloud = bx / tiles_per_cloud, tin = bx - cloud * tiles_per_cloud;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = blockIdx.y * 64 + lane;
+  const float* wb = w + (long long)cloud * wcs;
+  const float w0 = wb[c], w1 = wb[C + c], w2 = wb[2 * C + c];
+  const int r0 = tin * 128 + wave * 32;
+  const int r1 = min(N, r0 + 32);
+  float s1 = 0.f, s2 = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const long long row = (long long)cloud * N + r;
+    const float a0 = x3[row * 3], a1 = x3[row * 3 + 1], a2 = x3[row * 3 + 2];
+    const float v = fmaf(a2, w2, fmaf(a1, w1, a0 * w0));
+    if (z) z[row * C + c] = v;
+    s1 += v;
+    s2 = fmaf(v, v, s2);
+  }
+  if (part) {
+    red[wave][0][lane] = s1;
+    red[wave][1][lane] = s2;
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, l = tid & 63;
+      const float s = red[0][which][l] + red[1][which][l] + red[2][which][l] + red[3][which][l];
+      part[(long long)bx * 2 * C + which * C + blockIdx.y * 64 + l] = s;
+    }
+  }
+}
+
+int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st) {
+  PN_CHECK_ARG(x3 && w, "pn_conv3_fwd: null pointer");
+  PN_CHECK_ARG(B > 0 && N > 0, "pn_conv3_fwd: B and N must be positive");
+  PN_CHECK_ARG(C >= 64 && C % 64 == 0, "pn_conv3_fwd: C must be a multiple of 64 (C=%d)", C);
+  const int tpc = cdiv(N, 128);
+  hipLaunchKernelGGL(conv3_fwd_kernel, dim3(B * tpc, C / 64), dim3(256), 0, st, x3, w, wcs, N, C, tpc, z, part);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// weight gradient: slabs[tile][kk][c] = sum_rows x3[row][kk] * dz[row][c]
+__global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restrict__ x3, const pn_operand dz, int N, int C,
+                                                          int tiles_per_cloud, float* __restrict__ slabs) {
+  __shared__ float red[4][3][64];
+  const int bx = blockIdx.x, cloud = bx / tiles_per_cloud, tin = bx - cloud * tiles_per_cloud;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c = blockIdx.y * 64 + lane;
+  const float ca = dz.ca ? dz.ca[c] : 1.f, cb = (dz.s2 && dz.cb) ? dz.cb[c] : 0.f, cc = dz.cc ? dz.cc[c] : 0.f;
+  const int r0 = tin * 128 + wave * 32;
+  const int r1 = min(N, r0 + 32);
+  float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const long long row = (long long)cloud * N + r;
+    float d = fmaf(ca, dz.s1[row * dz.ld + c], cc);
+    if (dz.s2) d = fmaf(cb, dz.s2[row * dz.ld + c], d);
+    d = fmaxf(d, dz.lo);
+    g0 = fmaf(x3[row * 3], d, g0);
+    g1 = fmaf(x3[row * 3 + 1], d, g1);
+    g2 = fmaf(x3[row * 3 + 2], d, g2);
+  }
+  red[wave][0][lane] = g0; red[wave][1][lane] = g1; red[wave][2][lane] = g2;
+  __syncthreads();
+  if (tid < 192) {
+    const int kk = tid >> 6, l = tid & 63;
+    slabs[(long long)bx * 3 * C + kk * C + blockIdx.y * 64 + l] = red[0][kk][l] + red[1][kk][l] + red[2][kk][l] + red[3][kk][l];
+  }
+}
+
+int conv3_wgrad(const float* x3, const pn_operand* dz, int B, int N, int C, float* slabs, hipStream_t st) {
+  PN_CHECK_ARG(x3 && dz && dz->s1 && slabs, "pn_conv3_wgrad: null pointer");
+  PN_CHECK_ARG(B > 0 && N > 0, "pn_conv3_wgrad: B and N must be positive");
+  PN_CHECK_ARG(C >= 64 && C % 64 == 0 && dz->ld >= C, "pn_conv3_wgrad: bad C/ld");
+  const int tpc = cdiv(N, 128);
+  hipLaunchKernelGGL(conv3_wgrad_kernel, dim3(B * tpc, C / 64), dim3(256), 0, st, x3, *dz, N, C, tpc, slabs);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// fixed-order slab reduction: out[g][e] = sum_s slabs[g*per_group+s][e]
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int per_group, long long elems,
+                                                          float* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (e >= elems) return;
+  const int grp = blockIdx.y;
+  const float* s = slabs + (long long)grp * per_group * elems + e;
+  float acc = 0.f;
+  for (int i = 0; i < per_group; ++i) acc += s[(long long)i * elems];
+  out[(long long)grp * elems + e] = acc;
+}
+
+int slab_reduce(const float* slabs, int n_slabs, int per_group, long long elems, float* out, hipStream_t st) {
+  PN_CHECK_ARG(slabs && out, "pn_slab_reduce: null pointer");
+  PN_CHECK_ARG(n_slabs > 0 && per_group > 0 && n_slabs % per_group == 0 && elems > 0, "pn_slab_reduce: bad sizes");
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdivll(elems, 256), n_slabs / per_group), dim3(256), 0, st, slabs,
+                     per_group, elems, out);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// BatchNormalization coefficient finalisers (keras BatchNormalization semantics, see pointnet_hip.h)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int n_tiles, int C, double inv_count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ mm, float* __restrict__ mv, float momentum,
+                                                          float eps, int use_batch, int update, float* __restrict__ mean_o,
+                                                          float* __restrict__ invstd_o, float* __restrict__ scale_o,
+                                                          float* __restrict__ shift_o) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (use_batch) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < n_tiles; ++t) {
+      s1 += (double)part[(long long)t * 2 * C + c];
+      s2 += (double)part[(long long)t * 2 * C + C + c];
+    }
+    const double m = s1 * inv_count;
+    double v = s2 * inv_count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    if (update) {
+      mm[c] = mm[c] * momentum + mean * (1.f - momentum);
+      mv[c] = mv[c] * momentum + var * (1.f - momentum);
+    }
+  } else {
+    mean = mm[c];
+    var = mv[c];
+  }
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float sc = gamma[c] * invstd;
+  if (mean_o) mean_o[c] = mean;
+  if (invstd_o) invstd_o[c] = invstd;
+  scale_o[c] = sc;
+  shift_o[c] = beta[c] - mean * sc;
+}
+
+int bn_finalize(const float* part, int n_tiles, int C, long long count, const float* gamma, const float* beta, float* mm,
+                float* mv, float momentum, float eps, int use_batch, int update, float* mean, float* invstd, float* scale,
+                float* shift, hipStream_t st) {
+  PN_CHECK_ARG(gamma && beta && mm && mv && scale && shift, "pn_bn_finalize: null pointer");
+  PN_CHECK_ARG(C > 0, "pn_bn_finalize: C must be positive");
+  PN_CHECK_ARG(!use_batch || (part && n_tiles > 0 && count > 0), "pn_bn_finalize: batch statistics need partials");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, n_tiles, C, 1.0 / (double)(count > 0 ? count : 1),
+                     gamma, beta, mm, mv, momentum, eps, use_batch, update, mean, invstd, scale, shift);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int n_tiles, int C,
+                                                              double inv_count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              int batch_stats, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ ca,
+                                                              float* __restrict__ cb, float* __restrict__ cc) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float a = gamma[c] * invstd[c];
+  if (!batch_stats) {
+    ca[c] = a; cb[c] = 0.f; cc[c] = 0.f;
+    return;
+  }
+  double s1 = 0.0, s2 = 0.0;
+  for (int t = 0; t < n_tiles; ++t) {
+    s1 += (double)part[(long long)t * 2 * C + c];
+    s2 += (double)part[(long long)t * 2 * C + C + c];
+  }
+  // S1 = sum dy_hat ; S2 = sum dy_hat * zhat, zhat = (z - mean) * invstd
+  const double S1 = s1;
+  const double S2 = (s2 - (double)mean[c] * s1) * (double)invstd[c];
+  if (dgamma) dgamma[c] = (float)S2;
+  if (dbeta) dbeta[c] = (float)S1;
+  const double b = -(double)a * (double)invstd[c] * S2 * inv_count;
+  ca[c] = a;
+  cb[c] = (float)b;
+  cc[c] = (float)(-(double)a * S1 * inv_count - b * (double)mean[c]);
+}
+
+int bn_bwd_finalize(const float* part, int n_tiles, int C, long long count, const float* gamma, const float* mean,
+                    const float* invstd, int batch_stats, float* dgamma, float* dbeta, float* ca, float* cb, float* cc,
+                    hipStream_t st) {
+  PN_CHECK_ARG(gamma && invstd && ca && cb && cc, "pn_bn_bwd_finalize: null pointer");
+  PN_CHECK_ARG(!batch_stats || (part && mean && n_tiles > 0 && count > 0), "pn_bn_bwd_finalize: batch statistics need partials");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, n_tiles, C,
+                     1.0 / (double)(count > 0 ? count : 1), gamma, mean, invstd, batch_stats, dgamma, dbeta, ca, cb, cc);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// sgn[c] = +1 if gamma[c] >= 0 else -1 (the sign of the BN scale, known before the statistics are)
+__global__ void sign_kernel(const float* __restrict__ gamma, int C, float* __restrict__ sgn) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) sgn[c] = gamma[c] >= 0.f ? 1.f : -1.f;
+}
+int sign_of(const float* gamma, int C, float* sgn, hipStream_t st) {
+  hipLaunchKernelGGL(sign_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, gamma, C, sgn);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// finish tf.reduce_max (PointNet.py:248, 429)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void max_finalize_kernel(const float* __restrict__ pmax, const int* __restrict__ pidx,
+                                                           int tiles_per_cloud, int C, const float* __restrict__ sgn,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           float* __restrict__ g, float* __restrict__ zstar,
+                                                           int* __restrict__ arg) {
+  const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (c >= C) return;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int t = 0; t < tiles_per_cloud; ++t) {
+    const long long o = ((long long)b * tiles_per_cloud + t) * C + c;
+    const float v = pmax[o];
+    const int i = pidx[o];
+    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  }
+  const float zs = sgn[c] * best;
+  const long long o = (long long)b * C + c;
+  g[o] = fmaxf(fmaf(scale[c], zs, shift[c]), 0.f);
+  if (zstar) zstar[o] = zs;
+  if (arg) arg[o] = bi;
+}
+
+int max_finalize(const float* pmax, const int* pidx, int B, int tpc, int C, const float* sgn, const float* scale,
+                 const float* shift, float* g, float* zstar, int* arg, hipStream_t st) {
+  PN_CHECK_ARG(pmax && pidx && sgn && scale && shift && g, "pn_max_finalize: null pointer");
+  PN_CHECK_ARG(B > 0 && tpc > 0 && C > 0, "pn_max_finalize: bad sizes");
+  hipLaunchKernelGGL(max_finalize_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, st, pmax, pidx, tpc, C, sgn, scale, shift, g,
+                     zstar, arg);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+}  // namespace pn

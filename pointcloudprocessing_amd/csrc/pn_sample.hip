@@ -1,0 +1,304 @@
+// Point-cloud downsampling for dense scans: farthest point sampling and voxel-grid centroids (gfx950).
+// The reference has neither (its only resize is truncate / random duplicate,
+// pointcloud/PointCloudSet.py:443-470); the specification is build-defined and stated in pointnet_hip.h,
+// with NumPy oracles in oracle/sampling_oracle.py.
+#include <cstring>
+#include "pn_common.h"
+#include <rocprim/device/device_radix_sort.hpp>
+
+namespace pn {
+
+// ------------------------------------------------------------------------------------------------------
+// FPS.  M sequential rounds, each a full argmax over the cloud: latency bound, not bandwidth bound.  A
+// block keeps 16 points per thread (xyz + running min-distance) in registers, so a round touches no
+// memory except the selected point.  Clouds above 16384 points are split over `bpc` co-resident blocks
+// that exchange one 8-byte {distance, index, round-tag} granule per round through device-scope relaxed
+// atomics (a single naturally aligned 8-byte sc1 store/load needs no other ordering:
+// MI355X_MICROARCH.md, "R2's granule").  Every spin is bounded.
+// ------------------------------------------------------------------------------------------------------
+constexpr int FPS_T = 1024;
+constexpr int FPS_PPT = 16;
+constexpr int FPS_PER_BLOCK = FPS_T * FPS_PPT;
+
+__device__ __forceinline__ void fps_better(float& best, int& bi, float ob, int oi) {
+  if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+}
+
+__global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xyz, int N, int M, int start_idx, int bpc,
+                                                    int* __restrict__ idx_out, float* __restrict__ mindist,
+                                                    unsigned long long* __restrict__ xchg, int* __restrict__ err) {
+  __shared__ float s_best[2][16];
+  __shared__ int s_idx[2][16];
+  __shared__ int s_cur;
+  const int cloud = blockIdx.x / bpc, blk = blockIdx.x - cloud * bpc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* p = xyz + (long long)cloud * N * 3;
+  const int base = blk * FPS_PER_BLOCK;
+  float px[FPS_PPT], py[FPS_PPT], pz[FPS_PPT], md[FPS_PPT];
+#pragma unroll
+  for (int j = 0; j < FPS_PPT; ++j) {
+    const int i = base + j * FPS_T + tid;
+    if (i < N) {
+      px[j] = p[3 * i]; py[j] = p[3 * i + 1]; pz[j] = p[3 * i + 2];
+      md[j] = INFINITY;
+    } else {
+      px[j] = py[j] = pz[j] = 0.f;
+      md[j] = -1.f;
+    }
+  }
+  int cur = start_idx;
+  unsigned long long* xc = xchg + (long long)cloud * 2 * bpc;
+  for (int it = 0; it < M; ++it) {
+    if (blk == 0 && tid == 0) idx_out[(long long)cloud * M + it] = cur;
+    if (it == M - 1) break;
+    const float cx = p[3 * cur], cy = p[3 * cur + 1], cz = p[3 * cur + 2];
+    float best = -1.f;
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < FPS_PPT; ++j) {
+      const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
+      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      if (md[j] >= 0.f) {
+        md[j] = fminf(md[j], d);
+        if (md[j] > best) { best = md[j]; bi = base + j * FPS_T + tid; }
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ob = __shfl_xor(best, o, 64);
+      const int oi = __shfl_xor(bi, o, 64);
+      fps_better(best, bi, ob, oi);
+    }
+    const int par = it & 1;
+    if (lane == 0) { s_best[par][wave] = best; s_idx[par][wave] = bi; }
+    __syncthreads();
+    best = s_best[par][0]; bi = s_idx[par][0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) fps_better(best, bi, s_best[par][w], s_idx[par][w]);
+    if (bpc > 1) {
+      const unsigned tag = (unsigned)(it + 1) & 0xfffu;
+      if (tid == 0) {
+        const unsigned long long gr = ((unsigned long long)__float_as_uint(best) << 32) |
+                                      ((unsigned long long)((unsigned)bi & 0xfffffu) << 12) | tag;
+        __hip_atomic_store(&xc[par * bpc + blk], gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (wave == 0) {
+        float gb = -1.f;
+        int gi = 0x7fffffff;
+        int timed_out = 0;
+        if (lane < bpc) {
+          unsigned long long gr = 0;
+          int spins = 0;
+          for (;;) {
+            gr = __hip_atomic_load(&xc[par * bpc + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(gr & 0xfffu) == tag) break;
+            if (++spins > (1 << 22)) { timed_out = 1; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          gb = __uint_as_float((unsigned)(gr >> 32));
+          gi = (int)((gr >> 12) & 0xfffffu);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+          const float ob = __shfl_xor(gb, o, 64);
+          const int oi = __shfl_xor(gi, o, 64);
+          fps_better(gb, gi, ob, oi);
+        }
+        const int any_to = __any(timed_out);
+        if (lane == 0) {
+          s_cur = any_to ? -1 : gi;
+          if (any_to) atomicExch(err, 1);
+        }
+      }
+      __syncthreads();
+      bi = s_cur;
+      if (bi < 0) break;   // block-uniform: a peer never published (error flag set)
+    }
+    cur = bi;
+  }
+  if (mindist) {
+#pragma unroll
+    for (int j = 0; j < FPS_PPT; ++j) {
+      const int i = base + j * FPS_T + tid;
+      if (i < N) mindist[(long long)cloud * N + i] = md[j];
+    }
+  }
+}
+
+size_t fps_workspace_bytes(int B, int N) {
+  const int bpc = cdiv(N, FPS_PER_BLOCK);
+  return 16 + (size_t)B * 2 * bpc * sizeof(unsigned long long);
+}
+
+int fps(const float* xyz, int B, int N, int M, int start_idx, int* idx_out, float* mindist, void* ws, size_t ws_bytes,
+        hipStream_t st) {
+  PN_CHECK_ARG(xyz && idx_out, "pn_fps: null pointer");
+  PN_CHECK_ARG(B > 0 && N > 0 && M > 0, "pn_fps: B, N, M must be positive (B=%d N=%d M=%d)", B, N, M);
+  PN_CHECK_ARG(start_idx >= 0 && start_idx < N, "pn_fps: start_idx %d outside [0,%d)", start_idx, N);
+  const int bpc = cdiv(N, FPS_PER_BLOCK);
+  PN_CHECK_ARG(bpc <= 64, "pn_fps: N=%d exceeds %d points per cloud", N, 64 * FPS_PER_BLOCK);
+  PN_CHECK_ARG(ws && ws_bytes >= fps_workspace_bytes(B, N), "pn_fps: workspace too small");
+  int* err = reinterpret_cast<int*>(ws);
+  unsigned long long* xchg = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + 16);
+  if (hipMemsetAsync(ws, 0, fps_workspace_bytes(B, N), st) != hipSuccess) {
+    set_error("pn_fps: hipMemsetAsync failed");
+    return PN_ERR_LAUNCH;
+  }
+  // blocks of one cloud must be co-resident (they wait for each other): at most 128 blocks per launch
+  const int clouds_per_launch = bpc > 1 ? (128 / bpc > 0 ? 128 / bpc : 1) : B;
+  for (int b0 = 0; b0 < B; b0 += clouds_per_launch) {
+    const int nb = (B - b0) < clouds_per_launch ? (B - b0) : clouds_per_launch;
+    hipLaunchKernelGGL(fps_kernel, dim3(nb * bpc), dim3(FPS_T), 0, st, xyz + (long long)b0 * N * 3, N, M, start_idx, bpc,
+                       idx_out + (long long)b0 * M, mindist ? mindist + (long long)b0 * N : nullptr,
+                       xchg + (long long)b0 * 2 * bpc, err);
+    PN_CHECK_LAUNCH();
+  }
+  return PN_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// voxel grid
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void voxel_keys_kernel(const float* __restrict__ xyz, int N, float lx, float ly, float lz, float ox,
+                                                         float oy, float oz, unsigned long long* __restrict__ keys,
+                                                         int* __restrict__ vals, int* __restrict__ err) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const float fx = floorf(__fdiv_rn(__fsub_rn(xyz[3 * i], ox), lx));
+  const float fy = floorf(__fdiv_rn(__fsub_rn(xyz[3 * i + 1], oy), ly));
+  const float fz = floorf(__fdiv_rn(__fsub_rn(xyz[3 * i + 2], oz), lz));
+  const float lim = 2097152.f;  // 2^21
+  if (!(fx >= 0.f && fx < lim && fy >= 0.f && fy < lim && fz >= 0.f && fz < lim)) atomicExch(err, 1);
+  const unsigned long long kx = (unsigned long long)fminf(fmaxf(fx, 0.f), lim - 1.f);
+  const unsigned long long ky = (unsigned long long)fminf(fmaxf(fy, 0.f), lim - 1.f);
+  const unsigned long long kz = (unsigned long long)fminf(fmaxf(fz, 0.f), lim - 1.f);
+  keys[i] = (kz << 42) | (ky << 21) | kx;
+  vals[i] = i;
+}
+
+// single block: segment heads of the sorted keys -> seg_start[], n_out
+__global__ __launch_bounds__(1024) void voxel_heads_kernel(const unsigned long long* __restrict__ keys, int N, int* __restrict__ seg_start,
+                                                           int* __restrict__ n_out) {
+  __shared__ int wsum[16];
+  __shared__ int carry;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < N; c0 += 1024) {
+    const int i = c0 + tid;
+    const int flag = (i < N) && (i == 0 || keys[i] != keys[i - 1]);
+    int v = flag;   // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int t = __shfl_up(v, o, 64);
+      if (lane >= o) v += t;
+    }
+    if (lane == 63) wsum[wave] = v;
+    __syncthreads();
+    int off = carry;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+    if (flag) seg_start[off + v - 1] = i;
+    __syncthreads();
+    if (tid == 1023) carry = off + v;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    seg_start[carry] = N;
+    *n_out = carry;
+  }
+}
+
+__global__ __launch_bounds__(256) void voxel_reduce_kernel(const float* __restrict__ xyz, const int* __restrict__ labels,
+                                                           const int* __restrict__ sorted_idx, const int* __restrict__ seg_start,
+                                                           const int* __restrict__ n_out, int n_labels, float* __restrict__ centroids,
+                                                           int* __restrict__ counts, int* __restrict__ majority) {
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= *n_out) return;
+  const int s = seg_start[v], e = seg_start[v + 1];
+  double sx = 0.0, sy = 0.0, sz = 0.0;
+  int hist[32];
+#pragma unroll
+  for (int l = 0; l < 32; ++l) hist[l] = 0;
+  for (int t = s; t < e; ++t) {
+    const int i = sorted_idx[t];
+    sx += (double)xyz[3 * i]; sy += (double)xyz[3 * i + 1]; sz += (double)xyz[3 * i + 2];
+    if (labels) {
+      const int l = labels[i];
+      if (l >= 0 && l < n_labels) hist[l]++;
+    }
+  }
+  const double inv = 1.0 / (double)(e - s);
+  centroids[3 * v] = (float)(sx * inv);
+  centroids[3 * v + 1] = (float)(sy * inv);
+  centroids[3 * v + 2] = (float)(sz * inv);
+  if (counts) counts[v] = e - s;
+  if (majority) {
+    int best = 0, bl = labels ? 0 : -1;
+    if (labels)
+      for (int l = 0; l < n_labels; ++l)
+        if (hist[l] > best) { best = hist[l]; bl = l; }
+    majority[v] = bl;
+  }
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct VoxelLayout {
+  size_t keys_in, keys_out, idx_in, idx_out, seg, err, tmp, tmp_bytes, total;
+};
+
+static VoxelLayout voxel_layout(int N) {
+  VoxelLayout L;
+  size_t off = 0;
+  L.err = off; off += 256;
+  L.keys_in = off; off += align256((size_t)N * 8);
+  L.keys_out = off; off += align256((size_t)N * 8);
+  L.idx_in = off; off += align256((size_t)N * 4);
+  L.idx_out = off; off += align256((size_t)N * 4);
+  L.seg = off; off += align256((size_t)(N + 1) * 4);
+  size_t tb = 0;
+  unsigned long long* k = nullptr;
+  int* v = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, tb, k, k, v, v, (size_t)N, 0, 63, (hipStream_t)0);
+  L.tmp = off; L.tmp_bytes = tb; off += align256(tb);
+  L.total = off;
+  return L;
+}
+
+size_t voxel_workspace_bytes(int N) { return N > 0 ? voxel_layout(N).total : 0; }
+
+int voxel_downsample(const float* xyz, const int* labels, int N, const float* leaf, const float* origin, int n_labels,
+                     float* centroids, int* counts, int* majority, int* n_out, void* ws, size_t ws_bytes, hipStream_t st) {
+  PN_CHECK_ARG(xyz && leaf && origin && centroids && n_out, "pn_voxel_downsample: null pointer");
+  PN_CHECK_ARG(N > 0, "pn_voxel_downsample: N must be positive (N=%d)", N);
+  PN_CHECK_ARG(leaf[0] > 0.f && leaf[1] > 0.f && leaf[2] > 0.f, "pn_voxel_downsample: leaf sizes must be positive");
+  PN_CHECK_ARG(n_labels >= 0 && n_labels <= 32, "pn_voxel_downsample: n_labels %d outside [0,32]", n_labels);
+  const VoxelLayout L = voxel_layout(N);
+  PN_CHECK_ARG(ws && ws_bytes >= L.total, "pn_voxel_downsample: workspace too small (%zu < %zu)", ws_bytes, L.total);
+  char* w = reinterpret_cast<char*>(ws);
+  int* err = reinterpret_cast<int*>(w + L.err);
+  unsigned long long* kin = reinterpret_cast<unsigned long long*>(w + L.keys_in);
+  unsigned long long* kout = reinterpret_cast<unsigned long long*>(w + L.keys_out);
+  int* iin = reinterpret_cast<int*>(w + L.idx_in);
+  int* iout = reinterpret_cast<int*>(w + L.idx_out);
+  int* seg = reinterpret_cast<int*>(w + L.seg);
+  if (hipMemsetAsync(err, 0, 4, st) != hipSuccess) { set_error("pn_voxel_downsample: memset failed"); return PN_ERR_LAUNCH; }
+  hipLaunchKernelGGL(voxel_keys_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, xyz, N, leaf[0], leaf[1], leaf[2], origin[0],
+                     origin[1], origin[2], kin, iin, err);
+  PN_CHECK_LAUNCH();
+  size_t tb = L.tmp_bytes;
+  if (rocprim::radix_sort_pairs(w + L.tmp, tb, kin, kout, iin, iout, (size_t)N, 0, 63, st) != hipSuccess) {
+    set_error("pn_voxel_downsample: radix sort failed");
+    return PN_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(voxel_heads_kernel, dim3(1), dim3(1024), 0, st, kout, N, seg, n_out);
+  PN_CHECK_LAUNCH();
+  hipLaunchKernelGGL(voxel_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, xyz, labels, iout, seg, n_out, n_labels, centroids,
+                     counts, majority);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+int voxel_error_flag_offset() { return 0; }
+
+}  // namespace pn
