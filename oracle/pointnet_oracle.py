@@ -167,7 +167,7 @@ def normalize(pc: torch.Tensor):
 class _Ctx:
     """Per-call state: which blocks are trainable, new moving statistics, regularisation losses."""
 
-    def __init__(self, training, trainable, quant, dropout_masks, dropout_rate, tie_split):
+    def __init__(self, training, trainable, quant, dropout_masks, dropout_rate, tie_split, decisions=None):
         self.training = training
         self.trainable = trainable
         self.quant = quant
@@ -177,6 +177,7 @@ class _Ctx:
         self.reg_losses = []
         self.tie_split = tie_split
         self.taps: Dict[str, torch.Tensor] = {}
+        self.decisions = decisions or {}
 
 
 def _bn(ctx: _Ctx, p, prefix: str, z: torch.Tensor):
@@ -196,6 +197,15 @@ def _bn(ctx: _Ctx, p, prefix: str, z: torch.Tensor):
     return z * inv + (beta - mean * inv)
 
 
+def _relu(ctx: _Ctx, prefix: str, y):
+    """ReLU; with an injected decision mask (tests: the discrete choices of the implementation under test are
+    imposed so that the remaining comparison is between continuous functions)."""
+    m = ctx.decisions.get(f"{prefix}.relu")
+    if m is not None:
+        return y * m.to(y.dtype).reshape(y.shape)
+    return torch.relu(y)
+
+
 def _mm(ctx: _Ctx, a, w, quantize: bool):
     if quantize and ctx.quant is not None:
         return ctx.quant(a) @ ctx.quant(w)
@@ -206,12 +216,14 @@ def conv_layer(ctx, p, prefix, x, act="relu", mfma=True, kernel=None):
     """ConvLayer.call PointNet.py:554-566: 1x1 conv == per-point matmul with kernel (Cin, Cout)."""
     w = p[f"{prefix}.kernel"] if kernel is None else kernel
     z = _mm(ctx, x, w, mfma)
+    ctx.taps[f"{prefix}.z"] = z
     if f"{prefix}.bn.gamma" in p:
         z = _bn(ctx, p, prefix, z)
+        ctx.taps[f"{prefix}.y"] = z
     else:
         z = z + p[f"{prefix}.bias"]
     if act == "relu":
-        return torch.relu(z)
+        return _relu(ctx, prefix, z)
     if act == "softmax":
         return torch.softmax(z, dim=-1)
     return z
@@ -225,7 +237,7 @@ def dense_layer(ctx, p, prefix, x, act="relu"):
     else:
         z = z + p[f"{prefix}.bias"]
     if act == "relu":
-        return torch.relu(z)
+        return _relu(ctx, prefix, z)
     if act == "softmax":
         return torch.softmax(z, dim=-1)
     return z
@@ -272,7 +284,10 @@ class _MaxTiesSplit(torch.autograd.Function):
         return eq / eq.sum(dim=1, keepdim=True) * g.unsqueeze(1)
 
 
-def reduce_max_points(ctx: _Ctx, x):
+def reduce_max_points(ctx: _Ctx, x, name: str = ""):
+    idx = ctx.decisions.get(f"{name}.argmax")
+    if idx is not None:      # injected argmax rows (B, C): value and gradient both go through that row
+        return x.gather(1, idx.long().unsqueeze(1)).squeeze(1)
     return _MaxTiesSplit.apply(x) if ctx.tie_split else _MaxTiesToFirst.apply(x)
 
 
@@ -282,7 +297,7 @@ def tnet(ctx, p, name, x, regularize: bool):
     h = conv_layer(ctx, p, f"{name}.conv1", x, mfma=(k >= 64))    # K=3 first layer stays fp32 on the GPU
     h = conv_layer(ctx, p, f"{name}.conv2", h)
     h = conv_layer(ctx, p, f"{name}.conv3", h)
-    g = reduce_max_points(ctx, h)                                 # :429
+    g = reduce_max_points(ctx, h, name)                           # :429
     ctx.taps[f"{name}.global"] = g
     h = dense_layer(ctx, p, f"{name}.dense1", g)                  # :432
     h = dense_layer(ctx, p, f"{name}.dense2", h)                  # :433
@@ -298,7 +313,8 @@ def forward(p, pc, training: bool = False, trainable: Optional[Dict[str, bool]] 
             vanilla: bool = False, regularize_input_transform: bool = False,
             regularize_feature_transform: bool = False, dropout_rate: float = 0.3,
             dropout_masks: Optional[Dict[str, torch.Tensor]] = None,
-            quant: Optional[Callable] = None, tie_split: bool = False, return_ctx: bool = False):
+            quant: Optional[Callable] = None, tie_split: bool = False, return_ctx: bool = False,
+            decisions: Optional[Dict[str, torch.Tensor]] = None):
     """PointNet.call PointNet.py:197-292.  Returns [cls (B,Ccls), seg (B,N,Cseg), R (B,3,3)] and, in
     training mode, the updated moving statistics (ctx.new_stats) plus add_loss terms (ctx.reg_losses).
 
@@ -306,7 +322,7 @@ def forward(p, pc, training: bool = False, trainable: Optional[Dict[str, bool]] 
     training mode dropout is skipped (the reference's dropout is unseeded, so it has no reproducible
     stream to match).  `quant`: optional rounding applied to both operands of every per-point matmul
     with K >= 64 (emulates the GPU's bf16 MFMA operand rounding for the bf16 configs)."""
-    ctx = _Ctx(training, trainable or {}, quant, dropout_masks, dropout_rate, tie_split)
+    ctx = _Ctx(training, trainable or {}, quant, dropout_masks, dropout_rate, tie_split, decisions)
     pcn, _ = normalize(pc)                                        # :202
     ctx.taps["pcn"] = pcn
     if not vanilla:
@@ -327,7 +343,7 @@ def forward(p, pc, training: bool = False, trainable: Optional[Dict[str, bool]] 
     h = conv_layer(ctx, p, "mlp_2_1", x64)                        # :236
     h = conv_layer(ctx, p, "mlp_2_2", h)                          # :239
     h = conv_layer(ctx, p, "mlp_2_3", h)                          # :242
-    g = reduce_max_points(ctx, h)                                 # :248
+    g = reduce_max_points(ctx, h, "mlp_2_3")                      # :248
     ctx.taps["global"] = g
 
     c = dense_layer(ctx, p, "mlp_cls_1", g)                       # :252
@@ -341,8 +357,10 @@ def forward(p, pc, training: bool = False, trainable: Optional[Dict[str, bool]] 
     # the optional operand rounding applies to the per-point 64-wide part only, as on the GPU.
     w1 = p["mlp_seg_1.kernel"]
     z1 = _mm(ctx, x64, w1[:64], True) + (g @ w1[64:]).unsqueeze(1)
+    ctx.taps["mlp_seg_1.z"] = z1
     z1 = _bn(ctx, p, "mlp_seg_1", z1)
-    s = torch.relu(z1)                                            # :275
+    ctx.taps["mlp_seg_1.y"] = z1
+    s = _relu(ctx, "mlp_seg_1", z1)                               # :275
     s = conv_layer(ctx, p, "mlp_seg_2", s)                        # :278
     s = conv_layer(ctx, p, "mlp_seg_3", s)                        # :281
     s = conv_layer(ctx, p, "mlp_seg_4", s)                        # :284
@@ -469,4 +487,4 @@ def train_step(p, pc, targets, loss_weights, trainable, opt_state, lr_cfg, step_
             keras_adam_step(p[k], g, opt_state[k][0], opt_state[k][1], step_index, lr)
         for k, vnew in ctx.new_stats.items():
             p[k].copy_(vnew)
-    return float(loss), {k: float(v) for k, v in parts.items()}, outs
+    return float(loss.detach()), {k: float(v.detach()) for k, v in parts.items()}, outs

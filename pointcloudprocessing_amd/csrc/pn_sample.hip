@@ -27,6 +27,7 @@ __device__ __forceinline__ void fps_better(float& best, int& bi, float ob, int o
 __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xyz, int N, int M, int start_idx, int bpc,
                                                     int* __restrict__ idx_out, float* __restrict__ mindist,
                                                     unsigned long long* __restrict__ xchg, int* __restrict__ err) {
+#pragma clang fp contract(off)   // the distance is specified without fused multiply-add (bit-exact vs the oracle)
   __shared__ float s_best[2][16];
   __shared__ int s_idx[2][16];
   __shared__ int s_cur;
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
 #pragma unroll
     for (int j = 0; j < FPS_PPT; ++j) {
       const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
-      const float d = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+      const float d = (dx * dx + dy * dy) + dz * dz;   // no contraction: see the pragma above
       if (md[j] >= 0.f) {
         md[j] = fminf(md[j], d);
         if (md[j] > best) { best = md[j]; bi = base + j * FPS_T + tid; }
@@ -162,11 +163,12 @@ int fps(const float* xyz, int B, int N, int M, int start_idx, int* idx_out, floa
 __global__ __launch_bounds__(256) void voxel_keys_kernel(const float* __restrict__ xyz, int N, float lx, float ly, float lz, float ox,
                                                          float oy, float oz, unsigned long long* __restrict__ keys,
                                                          int* __restrict__ vals, int* __restrict__ err) {
+#pragma clang fp contract(off)
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= N) return;
-  const float fx = floorf(__fdiv_rn(__fsub_rn(xyz[3 * i], ox), lx));
-  const float fy = floorf(__fdiv_rn(__fsub_rn(xyz[3 * i + 1], oy), ly));
-  const float fz = floorf(__fdiv_rn(__fsub_rn(xyz[3 * i + 2], oz), lz));
+  const float fx = floorf((xyz[3 * i] - ox) / lx);
+  const float fy = floorf((xyz[3 * i + 1] - oy) / ly);
+  const float fz = floorf((xyz[3 * i + 2] - oz) / lz);
   const float lim = 2097152.f;  // 2^21
   if (!(fx >= 0.f && fx < lim && fy >= 0.f && fy < lim && fz >= 0.f && fz < lim)) atomicExch(err, 1);
   const unsigned long long kx = (unsigned long long)fminf(fmaxf(fx, 0.f), lim - 1.f);

@@ -1,0 +1,173 @@
+"""Thin torch-tensor wrappers over the op-level C ABI (include/pointnet_hip.h).
+
+Every function takes contiguous fp32 HIP tensors, allocates its outputs with torch (device memory plumbing
+only) and enqueues the HIP kernels on torch's current stream.  Nothing here computes on the CPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, current_stream, lib, operand, ptr, require_gpu_tensor
+
+F32 = torch.float32
+
+
+def _tiles(B, N):
+    return B * ((N + 127) // 128)
+
+
+def normalize(xyz: torch.Tensor):
+    """PointCloudNormalization.call (reference pointnet/PointNet.py:691-706) -> (normalized, (centroid, scale))."""
+    require_gpu_tensor(xyz, "xyz", F32)
+    B, N, _ = xyz.shape
+    out = torch.empty_like(xyz)
+    cen = torch.empty(B, 1, 3, device=xyz.device, dtype=F32)
+    scl = torch.empty(B, 1, 1, device=xyz.device, dtype=F32)
+    check(lib().pn_normalize(ptr(xyz), B, N, ptr(out), ptr(cen), ptr(scl), current_stream()), "pn_normalize")
+    return out, (cen, scl)
+
+
+def conv3_fwd(x3, w, B, N, per_cloud=False, want_stats=True):
+    C_ = w.shape[-1]
+    z = torch.empty(B * N, C_, device=x3.device, dtype=F32)
+    part = torch.empty(_tiles(B, N), 2, C_, device=x3.device, dtype=F32) if want_stats else None
+    check(lib().pn_conv3_fwd(ptr(x3), ptr(w), 3 * C_ if per_cloud else 0, B, N, C_, ptr(z), ptr(part), current_stream()),
+          "pn_conv3_fwd")
+    return z, part
+
+
+def conv3_wgrad(x3, dz_op, B, N, C_):
+    slabs = torch.empty(_tiles(B, N), 3, C_, device=x3.device, dtype=F32)
+    check(lib().pn_conv3_wgrad(ptr(x3), C.byref(dz_op), B, N, C_, ptr(slabs), current_stream()), "pn_conv3_wgrad")
+    return slabs
+
+
+def conv_fwd(x_op, w, B, N, K, C_, prec, w_cloud_stride=0, cloud_bias=None, store=True, want_stats=True):
+    dev = w.device
+    z = torch.empty(B * N, C_, device=dev, dtype=F32) if store else None
+    part = torch.empty(_tiles(B, N), 2, C_, device=dev, dtype=F32) if want_stats else None
+    check(lib().pn_conv_fwd(C.byref(x_op), ptr(w), w_cloud_stride, B, N, K, C_, ptr(cloud_bias), ptr(z), ptr(part), prec,
+                            current_stream()), "pn_conv_fwd")
+    return z, part
+
+
+def conv_fwd_max(x_op, w, B, N, K, C_, sgn, prec):
+    dev = w.device
+    T = _tiles(B, N)
+    pmax = torch.empty(T, C_, device=dev, dtype=F32)
+    pidx = torch.empty(T, C_, device=dev, dtype=torch.int32)
+    part = torch.empty(T, 2, C_, device=dev, dtype=F32)
+    check(lib().pn_conv_fwd_max(C.byref(x_op), ptr(w), B, N, K, C_, ptr(sgn), ptr(pmax), ptr(pidx), ptr(part), prec,
+                                current_stream()), "pn_conv_fwd_max")
+    return pmax, pidx, part
+
+
+def conv_bwd_data(dz_op, w, B, N, K, C_, prec, w_cloud_stride=0, addend=None, zmask=None, msc=None, msh=None,
+                  want_stats=True):
+    dev = w.device
+    out = torch.empty(B * N, C_, device=dev, dtype=F32)
+    part = torch.empty(_tiles(B, N), 2, C_, device=dev, dtype=F32) if want_stats else None
+    check(lib().pn_conv_bwd_data(C.byref(dz_op), ptr(w), w_cloud_stride, B, N, K, C_, ptr(addend), ptr(zmask), ptr(msc),
+                                 ptr(msh), ptr(out), ptr(part), prec, current_stream()), "pn_conv_bwd_data")
+    return out, part
+
+
+def conv_wgrad(a_op, b_op, B, N, Ci, Cj, prec, slab_rows=256, per_cloud=False):
+    dev = torch.device("cuda")
+    spc = (N + slab_rows - 1) // slab_rows
+    slabs = torch.empty(B * spc, Ci, Cj, device=dev, dtype=F32)
+    check(lib().pn_conv_wgrad(C.byref(a_op), C.byref(b_op), B, N, Ci, Cj, slab_rows, ptr(slabs), prec, current_stream()),
+          "pn_conv_wgrad")
+    groups = B if per_cloud else 1
+    out = torch.empty(groups, Ci, Cj, device=dev, dtype=F32)
+    check(lib().pn_slab_reduce(ptr(slabs), B * spc, spc if per_cloud else B * spc, Ci * Cj, ptr(out), current_stream()),
+          "pn_slab_reduce")
+    return out if per_cloud else out[0]
+
+
+def slab_reduce(slabs, per_group):
+    n = slabs.shape[0]
+    elems = slabs[0].numel()
+    out = torch.empty(n // per_group, *slabs.shape[1:], device=slabs.device, dtype=F32)
+    check(lib().pn_slab_reduce(ptr(slabs), n, per_group, elems, ptr(out), current_stream()), "pn_slab_reduce")
+    return out
+
+
+def bn_finalize(part, count, gamma, beta, moving_mean, moving_var, use_batch_stats=True, update_moving=True,
+                momentum=0.99, eps=1e-3):
+    C_ = gamma.numel()
+    dev = gamma.device
+    mean, invstd, scale, shift = (torch.empty(C_, device=dev, dtype=F32) for _ in range(4))
+    nt = part.shape[0] if part is not None else 0
+    check(lib().pn_bn_finalize(ptr(part), nt, C_, count, ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), momentum,
+                               eps, int(use_batch_stats), int(update_moving), ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                               current_stream()), "pn_bn_finalize")
+    return mean, invstd, scale, shift
+
+
+def bn_bwd_finalize(part, count, gamma, mean, invstd, batch_stats=True):
+    C_ = gamma.numel()
+    dev = gamma.device
+    dgamma, dbeta, ca, cb, cc = (torch.zeros(C_, device=dev, dtype=F32) for _ in range(5))
+    nt = part.shape[0] if part is not None else 0
+    check(lib().pn_bn_bwd_finalize(ptr(part), nt, C_, count, ptr(gamma), ptr(mean), ptr(invstd), int(batch_stats), ptr(dgamma),
+                                   ptr(dbeta), ptr(ca), ptr(cb), ptr(cc), current_stream()), "pn_bn_bwd_finalize")
+    return dgamma, dbeta, ca, cb, cc
+
+
+def sign(gamma):
+    s = torch.empty_like(gamma)
+    check(lib().pn_sign(ptr(gamma), gamma.numel(), ptr(s), current_stream()), "pn_sign")
+    return s
+
+
+def max_finalize(pmax, pidx, B, sgn, scale, shift):
+    T, C_ = pmax.shape
+    dev = pmax.device
+    g = torch.empty(B, C_, device=dev, dtype=F32)
+    zstar = torch.empty(B, C_, device=dev, dtype=F32)
+    arg = torch.empty(B, C_, device=dev, dtype=torch.int32)
+    check(lib().pn_max_finalize(ptr(pmax), ptr(pidx), B, T // B, C_, ptr(sgn), ptr(scale), ptr(shift), ptr(g), ptr(zstar),
+                                ptr(arg), current_stream()), "pn_max_finalize")
+    return g, zstar, arg
+
+
+def farthest_point_sample(xyz: torch.Tensor, m: int, start_idx: int = 0, return_mindist: bool = False):
+    """xyz (B,N,3) -> idx (B,m) int32 in selection order (spec: include/pointnet_hip.h, pn_fps)."""
+    require_gpu_tensor(xyz, "xyz", F32)
+    B, N, _ = xyz.shape
+    idx = torch.empty(B, m, device=xyz.device, dtype=torch.int32)
+    md = torch.empty(B, N, device=xyz.device, dtype=F32)
+    nbytes = lib().pn_fps_workspace_bytes(B, N)
+    ws = torch.empty(nbytes, device=xyz.device, dtype=torch.uint8)
+    check(lib().pn_fps(ptr(xyz), B, N, m, start_idx, ptr(idx), ptr(md), ptr(ws), nbytes, current_stream()), "pn_fps")
+    if int(ws[:4].view(torch.int32).item()) != 0:
+        raise _lib.PointNetHipError("pn_fps: a block timed out waiting for a peer block")
+    return (idx, md) if return_mindist else idx
+
+
+def voxel_downsample(xyz: torch.Tensor, leaf, origin, labels: Optional[torch.Tensor] = None, n_labels: int = 0):
+    """xyz (N,3) -> (centroids (V,3), counts (V,), majority (V,) or None) ordered by ascending (kz,ky,kx)."""
+    require_gpu_tensor(xyz, "xyz", F32)
+    N = xyz.shape[0]
+    dev = xyz.device
+    cent = torch.empty(N, 3, device=dev, dtype=F32)
+    cnt = torch.empty(N, device=dev, dtype=torch.int32)
+    maj = torch.empty(N, device=dev, dtype=torch.int32)
+    nout = torch.zeros(1, device=dev, dtype=torch.int32)
+    nbytes = lib().pn_voxel_workspace_bytes(N)
+    ws = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    leaf_c = (C.c_float * 3)(*[float(v) for v in leaf])
+    org_c = (C.c_float * 3)(*[float(v) for v in origin])
+    if labels is not None:
+        require_gpu_tensor(labels, "labels", torch.int32)
+    check(lib().pn_voxel_downsample(ptr(xyz), ptr(labels), N, leaf_c, org_c, n_labels, ptr(cent), ptr(cnt), ptr(maj), ptr(nout),
+                                    ptr(ws), nbytes, current_stream()), "pn_voxel_downsample")
+    v = int(nout.item())
+    if int(ws[:4].view(torch.int32).item()) != 0:
+        raise _lib.PointNetHipError("pn_voxel_downsample: a voxel key fell outside [0, 2^21)")
+    return cent[:v], cnt[:v], (maj[:v] if labels is not None else None)

@@ -1,0 +1,37 @@
+"""keras.optimizers.Adam + ExponentialDecay (reference pointnet_train.py:310-319) on the model's flat buffers.
+
+One native launch pair per step (schedule + update, pn_adam_step); the step counter and step size live on the
+device, so a training step captured in a hipGraph replays with the right learning rate.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import check, current_stream, lib, ptr, require_gpu_tensor
+
+
+class KerasAdam:
+    def __init__(self, params_flat: torch.Tensor, learning_rate: float, decay_steps: float = 1.0, decay_rate: float = 1.0,
+                 beta_1: float = 0.9, beta_2: float = 0.999, epsilon: float = 1e-7):
+        require_gpu_tensor(params_flat, "params_flat", torch.float32)
+        self.params = params_flat
+        self.m = torch.zeros_like(params_flat)
+        self.v = torch.zeros_like(params_flat)
+        self.iterations = torch.zeros(1, dtype=torch.int32, device=params_flat.device)
+        self._alpha = torch.zeros(2, dtype=torch.float32, device=params_flat.device)   # [step size, learning rate]
+        self.lr0, self.decay_steps, self.decay_rate = float(learning_rate), float(decay_steps), float(decay_rate)
+        self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
+
+    def step(self, grads_flat: torch.Tensor, grad_scale: float = 1.0):
+        check(lib().pn_adam_step(ptr(self.params), ptr(grads_flat), ptr(self.m), ptr(self.v), self.params.numel(),
+                                 ptr(self.iterations), ptr(self._alpha), self.lr0, self.decay_rate, self.decay_steps, self.beta_1,
+                                 self.beta_2, self.epsilon, float(grad_scale), current_stream()), "pn_adam_step")
+
+    @property
+    def learning_rate(self) -> float:
+        return float(self._alpha[1].item())
+
+    def state_dict(self):
+        return {"m": self.m, "v": self.v, "iterations": self.iterations}

@@ -1,0 +1,312 @@
+"""GPU parity tests of the op-level C ABI against CPU restatements (numpy / torch-CPU).
+
+Every test calls libpointnet_hip.so through pointcloudprocessing_amd.ops (ctypes) and compares with a
+CPU computation of the same formula.  Integer-valued inputs make the bf16 MFMA path EXACT, so layout bugs
+(row/column swaps, k permutations) show up as hard mismatches, not tolerance noise.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pointnet_oracle as O          # noqa: E402  (checker only)
+from oracle import sampling_oracle as SO         # noqa: E402
+
+
+def _ops():
+    from pointcloudprocessing_amd import ops
+    return ops
+
+
+def _lib():
+    from pointcloudprocessing_amd import _lib
+    return _lib
+
+
+def ints(gen, shape, lo=-3, hi=4):
+    return torch.randint(lo, hi, shape, generator=gen).to(torch.float32)
+
+
+def bf16r(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def lazy_ref(s1, ca=None, cc=None, s2=None, cb=None, relu=False):
+    v = s1.double()
+    if ca is not None:
+        v = v * ca.double()
+    if s2 is not None:
+        v = v + cb.double() * s2.double()
+    if cc is not None:
+        v = v + cc.double()
+    if relu:
+        v = torch.clamp(v, min=0)
+    return v
+
+
+# ------------------------------------------------------------------------------------------------
+def test_normalize_matches_reference_formula(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    for B, N in [(3, 1000), (2, 1), (1, 5000), (4, 257)]:
+        s = torch.rand(B, 1, 1, generator=g) * 49 + 1
+        o = (torch.rand(B, 1, 3, generator=g) * 2 - 1) * 100
+        pc = o + s * (torch.rand(B, N, 3, generator=g) * 2 - 1)
+        ref, (rc, rs) = O.normalize(pc.double())
+        out, (cen, scl) = ops.normalize(pc.to(dev))
+        assert torch.allclose(out.cpu().double(), ref, atol=2e-6, rtol=0), (B, N)
+        assert torch.allclose(cen.cpu().double(), rc, atol=1e-4)
+        assert torch.allclose(scl.cpu().double(), rs, rtol=1e-6)
+    # degenerate cloud: all points equal -> scale clamps at 1e-7, output 0 (PointNet.py:701)
+    pc = torch.ones(1, 64, 3) * 3.5
+    out, (_, scl) = ops.normalize(pc.to(dev))
+    assert float(out.abs().max()) == 0.0 and abs(float(scl) - 1e-7) < 1e-12
+
+
+@pytest.mark.parametrize("B,N,per_cloud", [(2, 300, False), (3, 128, True), (1, 1, False)])
+def test_conv3_fwd_and_wgrad(dev, B, N, per_cloud):
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B * N, 3, generator=g)
+    w = torch.randn((B, 3, 64) if per_cloud else (3, 64), generator=g)
+    z, part = ops.conv3_fwd(x.to(dev), w.to(dev), B, N, per_cloud=per_cloud)
+    xr = x.view(B, N, 3).double()
+    ref = xr @ (w.double() if per_cloud else w.double().unsqueeze(0))
+    assert torch.allclose(z.cpu().double().view(B, N, 64), ref, atol=1e-5)
+    s = part.cpu().double().sum(0)
+    assert torch.allclose(s[0], ref.reshape(-1, 64).sum(0), atol=1e-3)
+    assert torch.allclose(s[1], (ref.reshape(-1, 64) ** 2).sum(0), atol=1e-2, rtol=1e-5)
+    # weight gradient with a two-source lazy dz
+    dy = torch.randn(B * N, 64, generator=g)
+    zz = torch.randn(B * N, 64, generator=g)
+    ca, cb, cc = (torch.randn(64, generator=g) for _ in range(3))
+    op = _lib().operand(dy.to(dev), ca=ca.to(dev), cc=cc.to(dev), s2=zz.to(dev), cb=cb.to(dev))
+    slabs = ops.conv3_wgrad(x.to(dev), op, B, N, 64)
+    dz = lazy_ref(dy, ca, cc, zz, cb)
+    ref_w = torch.einsum("bnk,bnc->bkc", xr, dz.view(B, N, 64))
+    tpc = (N + 127) // 128
+    got = ops.slab_reduce(slabs, tpc).cpu().double()
+    assert torch.allclose(got, ref_w, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("prec", [1, 3])
+@pytest.mark.parametrize("B,N,K,C", [(2, 256, 64, 64), (1, 200, 128, 128), (3, 130, 64, 128), (2, 64, 512, 256),
+                                     (1, 384, 128, 1024)])
+def test_conv_fwd_exact_on_integers(dev, prec, B, N, K, C):
+    """small-integer operands are exact in bf16 and in the fp32 accumulator: result must match bit for bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    x = ints(g, (B * N, K))
+    w = ints(g, (K, C))
+    bias = ints(g, (B, C))
+    op = _lib().operand(x.to(dev))
+    z, part = ops.conv_fwd(op, w.to(dev), B, N, K, C, prec, cloud_bias=bias.to(dev))
+    ref = (x.double() @ w.double()).view(B, N, C) + bias.double().unsqueeze(1)
+    assert torch.equal(z.cpu().double().view(B, N, C), ref), "MFMA layout / indexing error"
+    s = part.cpu().double().sum(0)
+    assert torch.equal(s[0], ref.reshape(-1, C).sum(0))
+    assert torch.equal(s[1], (ref.reshape(-1, C) ** 2).sum(0))
+
+
+@pytest.mark.parametrize("prec", [1, 3])
+def test_conv_fwd_lazy_bn_relu_and_per_cloud_weights(dev, prec):
+    """tf.matmul(X, R_64) (PointNet.py:228) with the previous layer's BN+ReLU applied on load."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(4)
+    B, N, K, C = 3, 200, 64, 64
+    zprev = torch.randn(B * N, K, generator=g)
+    sc = torch.rand(K, generator=g) + 0.5
+    sh = torch.randn(K, generator=g) * 0.3
+    R = torch.randn(B, K, C, generator=g) / 8
+    op = _lib().operand(zprev.to(dev), ca=sc.to(dev), cc=sh.to(dev), relu=True)
+    z, _ = ops.conv_fwd(op, R.to(dev), B, N, K, C, prec, w_cloud_stride=K * C, want_stats=False)
+    a = lazy_ref(zprev, sc, sh, relu=True).float()
+    if prec == 1:
+        ref = (bf16r(a).view(B, N, K).double() @ bf16r(R).double())
+        tol = 1e-4          # only the accumulation order differs
+    else:
+        ref = a.view(B, N, K).double() @ R.double()
+        tol = 2e-4          # split-bf16: ~2^-17 per product
+    err = (z.cpu().double().view(B, N, C) - ref).abs().max()
+    assert err < tol * max(1.0, float(ref.abs().max())), float(err)
+
+
+@pytest.mark.parametrize("prec", [1, 3])
+@pytest.mark.parametrize("B,N", [(2, 256), (3, 200), (1, 1000)])
+def test_conv_fwd_max_matches_reduce_max(dev, prec, B, N):
+    """ConvLayer(128->1024)+BN+ReLU+reduce_max (PointNet.py:242-248) without the (B,N,1024) tensor."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    K, C = 128, 1024
+    x = ints(g, (B * N, K), -2, 3)
+    w = ints(g, (K, C), -2, 3)
+    gamma = torch.randn(C, generator=g)          # both signs: exercises the min side of the monotone trick
+    beta = torch.randn(C, generator=g)
+    mm = torch.zeros(C)
+    mv = torch.ones(C)
+    sgn = ops.sign(gamma.to(dev))
+    op = _lib().operand(x.to(dev))
+    pmax, pidx, part = ops.conv_fwd_max(op, w.to(dev), B, N, K, C, sgn, prec)
+    mean, invstd, scale, shift = ops.bn_finalize(part, B * N, gamma.to(dev), beta.to(dev), mm.to(dev), mv.to(dev))
+    gfeat, zstar, arg = ops.max_finalize(pmax, pidx, B, sgn, scale, shift)
+    z = (x.double() @ w.double()).view(B, N, C)
+    m = z.reshape(-1, C).mean(0)
+    v = ((z.reshape(-1, C) - m) ** 2).mean(0)
+    assert torch.allclose(mean.cpu().double(), m, atol=1e-4)
+    inv = torch.rsqrt(v + 1e-3) * gamma.double()
+    y = torch.relu(z * inv + (beta.double() - m * inv))
+    ref = y.max(dim=1).values
+    assert torch.allclose(gfeat.cpu().double(), ref, atol=2e-4, rtol=1e-4)
+    # argmax: the value at the reported row must be the extremum; reported row must be the lowest such row
+    s = torch.where(gamma >= 0, 1.0, -1.0).double()
+    t = z * s
+    tv = t.max(dim=1).values
+    first = torch.where(t == tv.unsqueeze(1), torch.arange(N).view(1, N, 1).expand_as(t), N).min(dim=1).values
+    assert torch.equal(arg.cpu().long(), first)
+    assert torch.equal(zstar.cpu().double(), tv * s)
+
+
+@pytest.mark.parametrize("prec", [1, 3])
+def test_conv_bwd_data_mask_addend_stats(dev, prec):
+    ops = _ops()
+    g = torch.Generator().manual_seed(6)
+    B, N, K, C = 2, 200, 128, 64          # layer 64 -> 128; dz has K=128 columns, output C=64
+    dy = ints(g, (B * N, K), -2, 3)
+    zz = ints(g, (B * N, K), -2, 3)
+    ca = ints(g, (K,), 1, 3)
+    cb = ints(g, (K,), -1, 2)
+    cc = ints(g, (K,), -1, 2)
+    w = ints(g, (C, K), -2, 3)             # Keras kernel (Cin=64, Cout=128)
+    addend = ints(g, (B * N, C))
+    zprev = torch.randn(B * N, C, generator=g)
+    msc = torch.randn(C, generator=g)
+    msh = torch.randn(C, generator=g) * 0.2
+    op = _lib().operand(dy.to(dev), ca=ca.to(dev), cc=cc.to(dev), s2=zz.to(dev), cb=cb.to(dev))
+    out, part = ops.conv_bwd_data(op, w.to(dev), B, N, K, C, prec, addend=addend.to(dev), zmask=zprev.to(dev),
+                                  msc=msc.to(dev), msh=msh.to(dev))
+    dz = lazy_ref(dy, ca, cc, zz, cb)
+    da = dz @ w.double().t() + addend.double()
+    mask = (torch.addcmul(msh, msc, zprev) > 0)      # fmaf(msc, z, msh) > 0
+    ref = torch.where(mask, da, torch.zeros_like(da))
+    got = out.cpu().double()
+    bad = (got != ref)
+    # the mask is evaluated with an fma on the GPU; allow disagreement only where msc*z+msh is ~0
+    near0 = (msc * zprev + msh).abs() < 1e-5
+    assert not (bad & ~near0).any(), int((bad & ~near0).sum())
+    s = part.cpu().double().sum(0)
+    assert torch.allclose(s[0], got.sum(0), atol=1e-6)
+    assert torch.allclose(s[1], (got * zprev.double()).sum(0), atol=1e-2, rtol=1e-5)
+
+
+@pytest.mark.parametrize("prec", [1, 3])
+@pytest.mark.parametrize("Ci,Cj,per_cloud", [(64, 64, True), (64, 128, False), (128, 128, False), (64, 512, False),
+                                             (512, 256, False)])
+def test_conv_wgrad_exact_on_integers(dev, prec, Ci, Cj, per_cloud):
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    B, N = 2, 300
+    a = ints(g, (B * N, Ci), -2, 3)
+    dy = ints(g, (B * N, Cj), -2, 3)
+    zz = ints(g, (B * N, Cj), -1, 2)
+    cb = ints(g, (Cj,), -1, 2)
+    cc = ints(g, (Cj,), -1, 2)
+    a_op = _lib().operand(a.to(dev), relu=True)
+    b_op = _lib().operand(dy.to(dev), cc=cc.to(dev), s2=zz.to(dev), cb=cb.to(dev))
+    got = ops.conv_wgrad(a_op, b_op, B, N, Ci, Cj, prec, slab_rows=128, per_cloud=per_cloud).cpu().double()
+    ar = torch.clamp(a.double(), min=0).view(B, N, Ci)
+    dz = lazy_ref(dy, None, cc, zz, cb).view(B, N, Cj)
+    ref = torch.einsum("bni,bnj->bij", ar, dz)
+    if not per_cloud:
+        ref = ref.sum(0)
+    assert torch.equal(got, ref), float((got - ref).abs().max())
+
+
+def test_bn_finalize_and_backward_coefficients(dev):
+    ops = _ops()
+    g = torch.Generator().manual_seed(8)
+    M, C = 1000, 128
+    z = torch.randn(M, C, generator=g) * 2 + 0.5
+    gamma = torch.randn(C, generator=g)
+    beta = torch.randn(C, generator=g)
+    mm = torch.randn(C, generator=g)
+    mv = torch.rand(C, generator=g) + 0.5
+    part = torch.stack([z.sum(0), (z * z).sum(0)]).unsqueeze(0)
+    mm_d, mv_d = mm.to(dev).clone(), mv.to(dev).clone()
+    mean, invstd, scale, shift = ops.bn_finalize(part.to(dev), M, gamma.to(dev), beta.to(dev), mm_d, mv_d)
+    zm = z.double().mean(0)
+    zv = ((z.double() - zm) ** 2).mean(0)
+    assert torch.allclose(mean.cpu().double(), zm, atol=1e-5)
+    assert torch.allclose(invstd.cpu().double(), torch.rsqrt(zv + 1e-3), rtol=1e-4)
+    assert torch.allclose(mm_d.cpu().double(), 0.99 * mm.double() + 0.01 * zm, atol=1e-5)
+    assert torch.allclose(mv_d.cpu().double(), 0.99 * mv.double() + 0.01 * zv, atol=1e-4)
+    # frozen / inference: coefficients from the moving statistics, moving statistics untouched
+    mean2, invstd2, scale2, shift2 = ops.bn_finalize(None, M, gamma.to(dev), beta.to(dev), mm.to(dev), mv.to(dev),
+                                                     use_batch_stats=False, update_moving=False)
+    assert torch.allclose(scale2.cpu().double(), gamma.double() * torch.rsqrt(mv.double() + 1e-3), rtol=1e-5)
+    assert torch.allclose(shift2.cpu().double(), beta.double() - mm.double() * gamma.double() * torch.rsqrt(mv.double() + 1e-3),
+                          atol=1e-5)
+    # backward coefficients: autograd through batch-norm as the reference
+    zt = z.double().requires_grad_(True)
+    gt = gamma.double().requires_grad_(True)
+    bt = beta.double().requires_grad_(True)
+    m_ = zt.mean(0)
+    v_ = ((zt - m_) ** 2).mean(0)
+    y = (zt - m_) * torch.rsqrt(v_ + 1e-3) * gt + bt
+    dy = torch.randn(M, C, generator=g).double()
+    y.backward(dy)
+    bpart = torch.stack([dy.sum(0), (dy * z.double()).sum(0)]).unsqueeze(0).float()
+    dgamma, dbeta, ca, cb, cc = ops.bn_bwd_finalize(bpart.to(dev), M, gamma.to(dev), mean, invstd)
+    dz = ca.cpu().double() * dy + cb.cpu().double() * z.double() + cc.cpu().double()
+    assert torch.allclose(dz, zt.grad, atol=2e-4, rtol=1e-3)
+    assert torch.allclose(dgamma.cpu().double(), gt.grad, atol=2e-3, rtol=1e-3)
+    assert torch.allclose(dbeta.cpu().double(), bt.grad, atol=1e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("B,N,M", [(2, 1000, 64), (1, 5000, 512), (3, 17, 17), (1, 40000, 256), (2, 20000, 100)])
+def test_fps_bit_exact_indices(dev, B, N, M):
+    ops = _ops()
+    rng = np.random.default_rng(9)
+    xyz = rng.uniform(-10, 10, size=(B, N, 3)).astype(np.float32)
+    if N >= 1000:
+        xyz[:, 500:520] = xyz[:, 100:120]           # duplicated points: distance ties -> lowest index
+    idx, md = ops.farthest_point_sample(torch.from_numpy(xyz).to(dev), M, start_idx=0, return_mindist=True)
+    for b in range(B):
+        ri, rmd = SO.fps(xyz[b], M, 0)
+        assert np.array_equal(idx[b].cpu().numpy(), ri), (b, np.flatnonzero(idx[b].cpu().numpy() != ri)[:5])
+        assert np.array_equal(md[b].cpu().numpy(), rmd)
+
+
+def test_voxel_downsample_matches_oracle(dev):
+    ops = _ops()
+    rng = np.random.default_rng(10)
+    N = 20000
+    xyz = rng.uniform(0, 10, size=(N, 3)).astype(np.float32)
+    xyz[1000:1100] = xyz[0:100]                      # exact duplicates share a voxel
+    labels = rng.integers(0, 12, size=N).astype(np.int32)
+    leaf, origin = (0.5, 0.5, 0.25), (-1.0, -1.0, -1.0)
+    cent, cnt, maj = ops.voxel_downsample(torch.from_numpy(xyz).to(dev), leaf, origin, torch.from_numpy(labels).to(dev), 12)
+    rc, rn, rm = SO.voxel_downsample(xyz, leaf, origin, labels, 12)
+    assert cent.shape[0] == rc.shape[0]
+    assert np.array_equal(cnt.cpu().numpy(), rn)
+    assert np.array_equal(maj.cpu().numpy(), rm)
+    assert np.array_equal(cent.cpu().numpy(), rc)
+    assert int(cnt.sum()) == N
+    # idempotence: downsampling the centroids with the same grid keeps one point per voxel
+    c2, n2, _ = ops.voxel_downsample(cent.contiguous(), leaf, origin)
+    assert c2.shape[0] == cent.shape[0] and int(n2.max()) == 1
+
+
+def test_invalid_arguments_raise(dev):
+    ops = _ops()
+    L = _lib()
+    x = torch.zeros(128, 48, device=dev)
+    w = torch.zeros(48, 64, device=dev)
+    with pytest.raises(L.PointNetHipError):
+        ops.conv_fwd(L.operand(x), w, 1, 128, 48, 64, 1)          # K not a multiple of 64
+    with pytest.raises(L.PointNetHipError):
+        ops.farthest_point_sample(torch.zeros(1, 10, 3, device=dev), 4, start_idx=10)
+    with pytest.raises(L.PointNetHipError):
+        ops.normalize(torch.zeros(1, 10, 3))                      # CPU tensor: no CPU fallback
