@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""PointNet training-step benchmark on MI355X:  python bench.py --gpus N --steps K --warmup W
+
+Metric (BASELINE.json): points/sec of the PointNet-cls training step (forward + keras losses + backward +
+gradient all-reduce + Adam) at N=1024 points, batch 32 per GPU, synthetic random clouds -- the reference's
+`classification_pretrain` profile (f15_lidar_config.json:43-69: segmentation head frozen, loss weights 1/0/0;
+both heads are still evaluated in the forward pass, as PointNet.call always does, PointNet.py:250-292).
+For N > 1 GPUs the driver launches this file under torch.distributed.run, one rank per GPU (weak scaling:
+32 clouds per rank), gradients summed with one RCCL all-reduce of the flat buffer.
+
+One JSON line is printed by rank 0.  Extra objects:
+  roofline     the dominant kernel = fused ConvLayer(128->1024)+BN-stats+reduce_max (3 launches per step), timed in
+               the real step with HIP events recorded on the launch stream; achieved = 2*128*1024 FLOP/point *
+               points per launch / mean launch time, against the dense bf16 MFMA peak (2.5 PFLOP/s).  bound = "mfma":
+               with 288 B/point of compulsory traffic this kernel is compute bound, see DESIGN.md.
+  cpu_baseline the CPU oracle (torch-CPU restatement of the reference model; the TF reference itself cannot run
+               here) timed on this host for a bounded number of steps of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CCLS, CSEG = 23, 12     # f15_lidar_config.json:4-42
+MFMA_BF16_PEAK = 2.5e15  # dense bf16 MFMA peak, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
+
+
+def synth_batch(B, N, seed, device):
+    """per cloud scale ~U(1,50) m, offset ~U(-100,100)^3, points = offset + scale*U(-1,1)^3."""
+    g = torch.Generator().manual_seed(seed)
+    s = torch.rand(B, 1, 1, generator=g) * 49 + 1
+    o = (torch.rand(B, 1, 3, generator=g) * 2 - 1) * 100
+    pc = (o + s * (torch.rand(B, N, 3, generator=g) * 2 - 1)).float().contiguous()
+    y_cls = torch.randint(0, CCLS, (B,), generator=g, dtype=torch.int32)
+    y_seg = torch.randint(0, CSEG, (B, N), generator=g, dtype=torch.int32)
+    q, _ = torch.linalg.qr(torch.randn(B, 3, 3, generator=g))
+    se3 = q.float().contiguous()
+    return [t.to(device) for t in (pc, y_cls, y_seg, se3)]
+
+
+def cpu_baseline(B, N, steps=4, warmup=1):
+    from oracle import pointnet_oracle as O          # reported baseline only
+    torch.set_num_threads(os.cpu_count() or 1)
+    p = O.init_params(CCLS, CSEG, seed=1)
+    pc, y_cls, y_seg, se3 = synth_batch(B, N, 20260001, "cpu")
+    tg = {"classification_output": y_cls.long(), "segmentation_output": y_seg.long(), "se3": se3}
+    tr = {b: False for b in O.GROUPS["segmentation_head"]}
+    st = {}
+    lr = {"rate": 1e-4, "decay_steps": 7000, "decay_rate": 0.7}
+    g = torch.Generator().manual_seed(3)
+    keep = {"dropout_1": torch.rand(B, 512, generator=g) >= 0.3, "dropout_2": torch.rand(B, 256, generator=g) >= 0.3}
+    lw = dict(classification=1.0, segmentation=0.0, rotation=0.0)
+    for i in range(warmup):
+        O.train_step(p, pc, tg, lw, tr, st, lr, i, dropout_masks=keep)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        O.train_step(p, pc, tg, lw, tr, st, lr, warmup + i, dropout_masks=keep)
+    dt = time.perf_counter() - t0
+    return {"value": B * N * steps / dt, "unit": "points/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} training steps of the same workload (B={B}, N={N}, fp32) on the torch-CPU oracle, {warmup} warm-up"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
+    ap.add_argument("--points", type=int, default=1024)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--profile", default="classification_pretrain", choices=["classification_pretrain", "final", "all"])
+    ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the PointNet hot path has no CPU compute path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from pointcloudprocessing_amd.optim import KerasAdam
+    from pointcloudprocessing_amd.pointnet.PointNet import PointNet
+    B, N = args.batch, args.points
+    model = PointNet(CCLS, CSEG, 0.3, 42, precision=args.precision, device=dev)
+    if world > 1:
+        dist.broadcast(model.params_flat.data, src=0)
+    lw = {"classification_pretrain": (1.0, 0.0, 0.0), "final": (0.0, 1.0, 0.0), "all": (1.0, 1.0, 1.0)}[args.profile]
+    model.thaw_shared_network(); model.thaw_input_transform()
+    (model.freeze_classification_head if args.profile == "final" else model.thaw_classification_head)()
+    (model.freeze_segmentation_head if args.profile == "classification_pretrain" else model.thaw_segmentation_head)()
+    opt = KerasAdam(model.params_flat.data, 1e-4, 7000, 0.7)
+    pc, y_cls, y_seg, se3 = synth_batch(B, N, 20260001 + rank, dev)
+    keep = ((torch.rand(B, 512, device=dev) >= 0.3).to(torch.uint8), (torch.rand(B, 256, device=dev) >= 0.3).to(torch.uint8))
+
+    def fwd_bwd():
+        # fresh dropout masks every step, generated on the device
+        keep[0].copy_(torch.rand(B, 512, device=dev) >= 0.3)
+        keep[1].copy_(torch.rand(B, 256, device=dev) >= 0.3)
+        model.fused_loss_step(pc, y_cls, y_seg, se3, lw, keep=keep)
+
+    def step_eager():
+        fwd_bwd()
+        if world > 1:
+            dist.all_reduce(model.grads_flat)
+        opt.step(model.grads_flat, 1.0 / world)
+
+    # ---- optional hipGraph of the step (fwd+bwd [+Adam when single GPU]); the all-reduce stays eager ----
+    graph_mode = "eager"
+    step = step_eager
+    if not args.no_graph:
+        try:
+            for _ in range(3):
+                step_eager()
+            torch.cuda.synchronize()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                fwd_bwd()
+                if world == 1:
+                    opt.step(model.grads_flat, 1.0)
+            if world == 1:
+                step = g1.replay
+            else:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    opt.step(model.grads_flat, 1.0 / world)
+
+                def step():
+                    g1.replay()
+                    dist.all_reduce(model.grads_flat)
+                    g2.replay()
+            graph_mode = "hipgraph"
+            torch.cuda.synchronize()
+        except Exception as e:                        # capture unsupported: stay eager, say so in the JSON
+            if rank == 0:
+                print(f"# hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
+            step = step_eager
+            graph_mode = "eager"
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- dominant kernel, timed inside real (eager) steps with HIP events on the launch stream ----
+    import ctypes as C
+    n_prof = min(50, max(10, args.steps))
+    evs = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(n_prof)]
+    for i in range(n_prof):
+        for e in evs[i]:
+            e.record()                                  # materialise the handles
+    torch.cuda.synchronize()
+    orig_io = model._io
+    cur = {"i": 0}
+
+    def io_with_events(pc_, training, fused):
+        io, kp = orig_io(pc_, training, fused)
+        arr = (C.c_void_p * 6)(*[e.cuda_event for e in evs[cur["i"]]])
+        io._ev_keep = arr
+        io.prof_events = C.cast(arr, C.POINTER(C.c_void_p))
+        return io, kp
+    model._io = io_with_events
+    for i in range(n_prof):
+        cur["i"] = i
+        step_eager()
+    torch.cuda.synchronize()
+    model._io = orig_io
+    kt = [evs[i][2 * j].elapsed_time(evs[i][2 * j + 1]) * 1e-3 for i in range(n_prof) for j in range(3)]
+    k_mean = sum(kt) / len(kt)
+    flop_per_launch = 2.0 * 128 * 1024 * B * N
+    bytes_per_launch = (128 * 4 + 2 * 4 * 1024 / 128.0 * 0 + 0) * B * N + 128 * 1024 * 4   # x read once + weights; outputs are O(B*1024)
+    achieved = flop_per_launch / k_mean
+
+    out = {
+        "metric": "points/sec PointNet fwd+bwd N=1024 B=32 at 1/2/4/8 MI355X vs CPU ref",
+        "value": world * B * N * args.steps / dt,
+        "unit": "points/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16" if args.precision == "bf16" else "bf16x3",
+        "data": "synthetic",
+        "config": {"workload": f"PointNet-cls training step (fwd + losses + bwd + grad all-reduce + Adam), N={N} points, "
+                               f"batch {B} per GPU, profile {args.profile}, {CCLS} classes / {CSEG} parts, random-init weights",
+                   "global_batch": world * B, "points_per_cloud": N, "parallelism": f"dp{world}", "launch": graph_mode},
+        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<128,128,FWD,EPI_MAX> (ConvLayer 128->1024 + BN sums + reduce_max)",
+                     "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12 / (3 if args.precision == "bf16x3" else 1),
+                     "unit": "TFLOP/s", "frac": achieved / (MFMA_BF16_PEAK / (3 if args.precision == "bf16x3" else 1)),
+                     "traffic": None, "launch_us": k_mean * 1e6, "launches_timed": len(kt),
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "hbm_frac_if_bandwidth_bound": bytes_per_launch / k_mean / HBM_PEAK},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(B, N)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -230,6 +230,10 @@ typedef struct pn_model_io {
   float* scalars;
   void* workspace;
   size_t workspace_bytes;
+  /* optional: 6 hipEvent_t handles (HOST array), recorded on `stream` immediately before / after the three fused
+   * ConvLayer(128->1024)+reduce_max launches (input_transform, feature_transform, mlp_2_3), in that order; lets a
+   * benchmark time the dominant kernel inside the real step.  NULL = no events.  Do not set while capturing a graph. */
+  void** prof_events;
 } pn_model_io;
 
 int pn_model_num_slots(const pn_model_desc* d);

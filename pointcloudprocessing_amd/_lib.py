@@ -49,7 +49,8 @@ class pn_model_io(C.Structure):
                 ("keep1", C.c_void_p), ("keep2", C.c_void_p), ("labels_cls", C.c_void_p),
                 ("labels_seg", C.c_void_p), ("se3", C.c_void_p), ("loss_weights", C.c_float * 3),
                 ("pad2_", C.c_float), ("out_cls", C.c_void_p), ("out_seg", C.c_void_p), ("out_R", C.c_void_p),
-                ("scalars", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("scalars", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("prof_events", C.POINTER(C.c_void_p))]
 
 
 # every symbol include/pointnet_hip.h declares: name -> (restype, argtypes)

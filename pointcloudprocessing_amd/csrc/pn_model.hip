@@ -339,9 +339,12 @@ struct Run {
                     st));
     return bn_fin(l, r);
   }
-  int fwd_max(CL& l, ML& m, const LRef& r, const pn_operand& x) {
+  int fwd_max(CL& l, ML& m, const LRef& r, const pn_operand& x, int prof_slot) {
     PN_TRY(sign_of(p(r.gamma), r.cout, m.sgn, st));
+    void** ev = io.prof_events;
+    if (ev && ev[2 * prof_slot]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot]), st);
     PN_TRY(conv_fwd_max(&x, p(r.kernel), B, N, r.cin, r.cout, m.sgn, m.pmax, m.pidx, bn_batch(r.block) ? l.part : nullptr, prec, st));
+    if (ev && ev[2 * prof_slot + 1]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot + 1]), st);
     PN_TRY(bn_fin(l, r));
     return max_finalize(m.pmax, m.pidx, B, tpc, r.cout, m.sgn, l.scale, l.shift, m.g, m.zstar, m.arg, st);
   }
@@ -360,7 +363,7 @@ struct Run {
       PN_TRY(fwd_conv(t.c1, r.c1, *x, p(r.c1.kernel), 0, nullptr));
     }
     PN_TRY(fwd_conv(t.c2, r.c2, lazy(t.c1), p(r.c2.kernel), 0, nullptr));
-    PN_TRY(fwd_max(t.c3, t.m3, r.c3, lazy(t.c2)));
+    PN_TRY(fwd_max(t.c3, t.m3, r.c3, lazy(t.c2), r.K == 3 ? 0 : 1));
     PN_TRY(fwd_dense(t.d1, r.d1, t.m3.g, 1, nullptr));
     PN_TRY(fwd_dense(t.d2, r.d2, t.d1.a, 1, nullptr));
     PN_TRY(dense_partial(t.d2.a, 256, p(r.w), B, 256, r.K * r.K, w.dense_part, st));
@@ -389,7 +392,7 @@ struct Run {
     const pn_operand x64 = x64op();
     PN_TRY(fwd_conv(w.m21, L.m21, x64, p(L.m21.kernel), 0, nullptr));
     PN_TRY(fwd_conv(w.m22, L.m22, lazy(w.m21), p(L.m22.kernel), 0, nullptr));
-    PN_TRY(fwd_max(w.m23, w.mm23, L.m23, lazy(w.m22)));
+    PN_TRY(fwd_max(w.m23, w.mm23, L.m23, lazy(w.m22), 2));
     const float* Gf = w.mm23.g;
 
     // classification head (PointNet.py:252-263)
