@@ -45,9 +45,10 @@ def synth_batch(B, N, seed, device):
     return [t.to(device) for t in (pc, y_cls, y_seg, se3)]
 
 
-def cpu_baseline(B, N, steps=4, warmup=1):
+def cpu_baseline(B, N, steps=3, warmup=1):
     from oracle import pointnet_oracle as O          # reported baseline only
-    torch.set_num_threads(os.cpu_count() or 1)
+    # the GPU box gives one GPU a 16-CPU share even though os.cpu_count() reports the whole host
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
     p = O.init_params(CCLS, CSEG, seed=1)
     pc, y_cls, y_seg, se3 = synth_batch(B, N, 20260001, "cpu")
     tg = {"classification_output": y_cls.long(), "segmentation_output": y_seg.long(), "se3": se3}

@@ -71,96 +71,153 @@ __device__ __forceinline__ void cvt_store8(__bf16* hi, __bf16* lo, const float (
   }
 }
 
+// Staging is split into an ISSUE phase (all global loads of both operands, unconditional, from clamped addresses)
+// and a FINISH phase (affine + ReLU/mask select, bf16 split, ds_write_b128).  Between them every loaded register is
+// pinned with an empty asm: without that LLVM sinks a load whose value is only used under the validity select back
+// into a branch and waits vmcnt(0) per load, which serialises the tile (cdna_hip_programming.md section 5, trap 4c).
+
 // ---- "natural" stager: source[(row)*ld + k], k contiguous; coefficients indexed by k ------------------
-template <int TR, int BK, int NS, bool HAS2>
-__device__ __forceinline__ void stage_nat(__bf16* __restrict__ Thi, __bf16* __restrict__ Tlo, const pn_operand& op,
-                                          long long base, int nvalid_rows, int k0, int tid) {
-  constexpr int PITCH = Geo<BK>::PITCH;
-  constexpr int CH = BK / 8;     // 16-byte bf16 chunks per LDS row
-  constexpr int RP = 256 / CH;   // rows per pass
-  const int ch = tid % CH, rin = tid / CH;
-  const int k = k0 + ch * 8;
-  float ca[8], cb[8], cc[8];
+template <int TR, int BK, bool HAS2>
+struct NatStage {
+  static constexpr int CH = BK / 8;     // 16-byte bf16 chunks per LDS row
+  static constexpr int RP = 256 / CH;   // rows per pass
+  static constexpr int P = TR / RP;
+  float4 x[P][2];
+  float4 y[HAS2 ? P : 1][2];
+
+  __device__ __forceinline__ void issue(const pn_operand& op, long long base, int nvalid_rows, int k0, int tid) {
+    const int ch = tid % CH, rin = tid / CH;
+    const int k = k0 + ch * 8;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) { ca[e] = 1.f; cb[e] = 0.f; cc[e] = 0.f; }
-  if (op.ca) {
-    const float4 t0 = *reinterpret_cast<const float4*>(op.ca + k), t1 = *reinterpret_cast<const float4*>(op.ca + k + 4);
-    ca[0] = t0.x; ca[1] = t0.y; ca[2] = t0.z; ca[3] = t0.w; ca[4] = t1.x; ca[5] = t1.y; ca[6] = t1.z; ca[7] = t1.w;
-  }
-  if (HAS2 && op.cb) {
-    const float4 t0 = *reinterpret_cast<const float4*>(op.cb + k), t1 = *reinterpret_cast<const float4*>(op.cb + k + 4);
-    cb[0] = t0.x; cb[1] = t0.y; cb[2] = t0.z; cb[3] = t0.w; cb[4] = t1.x; cb[5] = t1.y; cb[6] = t1.z; cb[7] = t1.w;
-  }
-  if (op.cc) {
-    const float4 t0 = *reinterpret_cast<const float4*>(op.cc + k), t1 = *reinterpret_cast<const float4*>(op.cc + k + 4);
-    cc[0] = t0.x; cc[1] = t0.y; cc[2] = t0.z; cc[3] = t0.w; cc[4] = t1.x; cc[5] = t1.y; cc[6] = t1.z; cc[7] = t1.w;
-  }
-  const float lo = op.lo;
-#pragma unroll
-  for (int p = 0; p < TR / RP; ++p) {
-    const int r = p * RP + rin;
-    float v[8];
-    if (r < nvalid_rows) {
-      const float* s = op.s1 + base + (long long)r * op.ld + k;
-      const float4 x0 = *reinterpret_cast<const float4*>(s), x1 = *reinterpret_cast<const float4*>(s + 4);
-      v[0] = x0.x; v[1] = x0.y; v[2] = x0.z; v[3] = x0.w; v[4] = x1.x; v[5] = x1.y; v[6] = x1.z; v[7] = x1.w;
-      float y[8];
+    for (int p = 0; p < P; ++p) {
+      const int r = p * RP + rin;
+      const long long rr = (r < nvalid_rows) ? r : (nvalid_rows - 1);
+      const float* s = op.s1 + base + rr * op.ld + k;
+      x[p][0] = *reinterpret_cast<const float4*>(s);
+      x[p][1] = *reinterpret_cast<const float4*>(s + 4);
       if (HAS2) {
-        const float* s2 = op.s2 + base + (long long)r * op.ld + k;
-        const float4 y0 = *reinterpret_cast<const float4*>(s2), y1 = *reinterpret_cast<const float4*>(s2 + 4);
-        y[0] = y0.x; y[1] = y0.y; y[2] = y0.z; y[3] = y0.w; y[4] = y1.x; y[5] = y1.y; y[6] = y1.z; y[7] = y1.w;
+        const float* s2 = op.s2 + base + rr * op.ld + k;
+        y[p][0] = *reinterpret_cast<const float4*>(s2);
+        y[p][1] = *reinterpret_cast<const float4*>(s2 + 4);
+      }
+    }
+  }
+  __device__ __forceinline__ void pin() {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        asm volatile("" : "+v"(x[p][q].x), "+v"(x[p][q].y), "+v"(x[p][q].z), "+v"(x[p][q].w));
+        if (HAS2) asm volatile("" : "+v"(y[p][q].x), "+v"(y[p][q].y), "+v"(y[p][q].z), "+v"(y[p][q].w));
+      }
+  }
+  template <int NS>
+  __device__ __forceinline__ void finish(__bf16* __restrict__ Thi, __bf16* __restrict__ Tlo, const pn_operand& op,
+                                         int nvalid_rows, int k0, int tid) {
+    constexpr int PITCH = Geo<BK>::PITCH;
+    const int ch = tid % CH, rin = tid / CH;
+    const int k = k0 + ch * 8;
+    float ca[8], cb[8], cc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { ca[e] = 1.f; cb[e] = 0.f; cc[e] = 0.f; }
+    if (op.ca) {
+      const float4 t0 = *reinterpret_cast<const float4*>(op.ca + k), t1 = *reinterpret_cast<const float4*>(op.ca + k + 4);
+      ca[0] = t0.x; ca[1] = t0.y; ca[2] = t0.z; ca[3] = t0.w; ca[4] = t1.x; ca[5] = t1.y; ca[6] = t1.z; ca[7] = t1.w;
+    }
+    if (HAS2 && op.cb) {
+      const float4 t0 = *reinterpret_cast<const float4*>(op.cb + k), t1 = *reinterpret_cast<const float4*>(op.cb + k + 4);
+      cb[0] = t0.x; cb[1] = t0.y; cb[2] = t0.z; cb[3] = t0.w; cb[4] = t1.x; cb[5] = t1.y; cb[6] = t1.z; cb[7] = t1.w;
+    }
+    if (op.cc) {
+      const float4 t0 = *reinterpret_cast<const float4*>(op.cc + k), t1 = *reinterpret_cast<const float4*>(op.cc + k + 4);
+      cc[0] = t0.x; cc[1] = t0.y; cc[2] = t0.z; cc[3] = t0.w; cc[4] = t1.x; cc[5] = t1.y; cc[6] = t1.z; cc[7] = t1.w;
+    }
+    const float lo = op.lo;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int r = p * RP + rin;
+      const bool rv = r < nvalid_rows;
+      float v[8] = {x[p][0].x, x[p][0].y, x[p][0].z, x[p][0].w, x[p][1].x, x[p][1].y, x[p][1].z, x[p][1].w};
+      float w[8];
+      if (HAS2) {
+        w[0] = y[p][0].x; w[1] = y[p][0].y; w[2] = y[p][0].z; w[3] = y[p][0].w;
+        w[4] = y[p][1].x; w[5] = y[p][1].y; w[6] = y[p][1].z; w[7] = y[p][1].w;
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         float t = fmaf(ca[e], v[e], cc[e]);
-        if (HAS2) t = fmaf(cb[e], y[e], t);
-        v[e] = fmaxf(t, lo);
+        if (HAS2) t = fmaf(cb[e], w[e], t);
+        v[e] = rv ? fmaxf(t, lo) : 0.f;
       }
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = 0.f;
+      cvt_store8(Thi + r * PITCH + ch * 8, Tlo + r * PITCH + ch * 8, v, NS == 3);
     }
-    cvt_store8(Thi + r * PITCH + ch * 8, Tlo + r * PITCH + ch * 8, v, NS == 3);
   }
-}
+};
 
 // ---- "transposed" stager: source[(k)*ld + r], r (= the LDS row / channel) contiguous in memory;
 //      coefficients indexed by r.  Each lane owns one channel and gathers 8 consecutive k for it. -------
-template <int TR, int BK, int NS, bool HAS2>
-__device__ __forceinline__ void stage_trn(__bf16* __restrict__ Thi, __bf16* __restrict__ Tlo, const pn_operand& op,
-                                          long long base, int nvalid_k, int nvalid_r, int coef0, int tid) {
-  constexpr int PITCH = Geo<BK>::PITCH;
-  constexpr int KG = BK / 8;      // k-groups per chunk
-  constexpr int TPG = 256 / TR;   // k-groups covered per pass
+template <int TR, int BK, bool HAS2>
+struct TrnStage {
+  static constexpr int KG = BK / 8;      // k-groups per chunk
+  static constexpr int TPG = 256 / TR;   // k-groups covered per pass
+  static constexpr int P = KG / TPG;
   static_assert(KG % TPG == 0, "tile geometry");
-  const int r = tid % TR, kgin = tid / TR;
-  const bool rv = r < nvalid_r;
-  float ca = 1.f, cb = 0.f, cc = 0.f;
-  if (rv) {
-    if (op.ca) ca = op.ca[coef0 + r];
-    if (HAS2 && op.cb) cb = op.cb[coef0 + r];
-    if (op.cc) cc = op.cc[coef0 + r];
-  }
-  const float lo = op.lo;
+  float x[P][8];
+  float y[HAS2 ? P : 1][8];
+
+  __device__ __forceinline__ void issue(const pn_operand& op, long long base, int nvalid_k, int nvalid_r, int tid) {
+    const int r = tid % TR, kgin = tid / TR;
+    const int rc = (r < nvalid_r) ? r : (nvalid_r - 1);
+    const float* p1 = op.s1 + base + rc;
+    const float* p2 = HAS2 ? (op.s2 + base + rc) : nullptr;
 #pragma unroll
-  for (int p = 0; p < KG / TPG; ++p) {
-    const int kg = p * TPG + kgin;
-    float v[8];
+    for (int p = 0; p < P; ++p) {
+      const int kg = p * TPG + kgin;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int k = kg * 8 + e;
-      float t = 0.f;
-      if (rv && k < nvalid_k) {
-        const long long off = base + (long long)k * op.ld + r;
-        t = fmaf(ca, op.s1[off], cc);
-        if (HAS2) t = fmaf(cb, op.s2[off], t);
-        t = fmaxf(t, lo);
+      for (int e = 0; e < 8; ++e) {
+        const int k = kg * 8 + e;
+        const long long kk = (k < nvalid_k) ? k : (nvalid_k - 1);
+        x[p][e] = p1[kk * op.ld];
+        if (HAS2) y[p][e] = p2[kk * op.ld];
       }
-      v[e] = t;
     }
-    cvt_store8(Thi + r * PITCH + kg * 8, Tlo + r * PITCH + kg * 8, v, NS == 3);
   }
-}
+  __device__ __forceinline__ void pin() {
+#pragma unroll
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        asm volatile("" : "+v"(x[p][e]));
+        if (HAS2) asm volatile("" : "+v"(y[p][e]));
+      }
+  }
+  template <int NS>
+  __device__ __forceinline__ void finish(__bf16* __restrict__ Thi, __bf16* __restrict__ Tlo, const pn_operand& op,
+                                         int nvalid_k, int nvalid_r, int coef0, int tid) {
+    constexpr int PITCH = Geo<BK>::PITCH;
+    const int r = tid % TR, kgin = tid / TR;
+    const bool rv = r < nvalid_r;
+    const int rc = rv ? r : (nvalid_r - 1);
+    float ca = 1.f, cb = 0.f, cc = 0.f;
+    if (op.ca) ca = op.ca[coef0 + rc];
+    if (HAS2 && op.cb) cb = op.cb[coef0 + rc];
+    if (op.cc) cc = op.cc[coef0 + rc];
+    const float lo = op.lo;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int kg = p * TPG + kgin;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = kg * 8 + e;
+        float t = fmaf(ca, x[p][e], cc);
+        if (HAS2) t = fmaf(cb, y[p][e], t);
+        v[e] = (rv && k < nvalid_k) ? fmaxf(t, lo) : 0.f;
+      }
+      cvt_store8(Thi + r * PITCH + kg * 8, Tlo + r * PITCH + kg * 8, v, NS == 3);
+    }
+  }
+};
 
 // ---- MFMA over one staged chunk ------------------------------------------------------------------------
 template <int MT, int NT, int BK, int NS>
@@ -237,8 +294,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     for (int r0 = rbeg; r0 < rend; r0 += BK) {
       const long long rowbase = (long long)cloud * g.N + r0;
       const int nk = min(BK, rend - r0);
-      stage_trn<BM, BK, NS, A2>(Ahi, Alo, g.a, rowbase * g.a.ld + i0, nk, g.Ci - i0, i0, tid);
-      stage_trn<BN, BK, NS, B2>(Bhi, Blo, g.b, rowbase * g.b.ld + j0, nk, g.C - j0, j0, tid);
+      TrnStage<BM, BK, A2> sa;
+      TrnStage<BN, BK, B2> sb;
+      sa.issue(g.a, rowbase * g.a.ld + i0, nk, g.Ci - i0, tid);
+      sb.issue(g.b, rowbase * g.b.ld + j0, nk, g.C - j0, tid);
+      sa.pin();
+      sa.template finish<NS>(Ahi, Alo, g.a, nk, g.Ci - i0, i0, tid);
+      sb.pin();
+      sb.template finish<NS>(Bhi, Blo, g.b, nk, g.C - j0, j0, tid);
       __syncthreads();
       mma_chunk<MT, NT, BK, NS>(acc, Ahi, Alo, Bhi, Blo, wrow0, wcol0, lane);
       __syncthreads();
@@ -272,11 +335,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   wop.ld = (MODE == MODE_FWD) ? g.C : g.K;
 
   for (int k0 = 0; k0 < g.K; k0 += BK) {
-    stage_nat<BM, BK, NS, A2>(Ahi, Alo, g.a, row0 * g.a.ld, nrows, k0, tid);
-    if (MODE == MODE_FWD)
-      stage_trn<BN, BK, NS, false>(Bhi, Blo, wop, wbase + (long long)k0 * g.C + col0, BK, g.C - col0, 0, tid);
-    else
-      stage_nat<BN, BK, NS, false>(Bhi, Blo, wop, wbase + (long long)col0 * g.K, g.C - col0, k0, tid);
+    NatStage<BM, BK, A2> sa;
+    sa.issue(g.a, row0 * g.a.ld, nrows, k0, tid);
+    if (MODE == MODE_FWD) {
+      TrnStage<BN, BK, false> sb;
+      sb.issue(wop, wbase + (long long)k0 * g.C + col0, BK, g.C - col0, tid);
+      sa.pin();
+      sa.template finish<NS>(Ahi, Alo, g.a, nrows, k0, tid);
+      sb.pin();
+      sb.template finish<NS>(Bhi, Blo, wop, BK, g.C - col0, 0, tid);
+    } else {
+      NatStage<BN, BK, false> sb;
+      sb.issue(wop, wbase + (long long)col0 * g.K, g.C - col0, k0, tid);
+      sa.pin();
+      sa.template finish<NS>(Ahi, Alo, g.a, nrows, k0, tid);
+      sb.pin();
+      sb.template finish<NS>(Bhi, Blo, wop, g.C - col0, k0, tid);
+    }
     __syncthreads();
     mma_chunk<MT, NT, BK, NS>(acc, Ahi, Alo, Bhi, Blo, wrow0, wcol0, lane);
     __syncthreads();
@@ -295,26 +370,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
       if (jv && g.cloud_bias) bias = g.cloud_bias[(long long)cloud * g.C + j];
       if (jv && g.zmask) { msc = g.msc[j]; msh = g.msh[j]; }
       float a1 = 0.f, a2 = 0.f;
+      const int jc = jv ? j : (g.C - 1);
 #pragma unroll
-      for (int m = 0; m < MT; ++m)
+      for (int m = 0; m < MT; ++m) {
+        float ad[16], zm[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {      // unconditional, clamped loads first so they are all in flight together
+          const int il = wrow0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          const long long oc = (row0 + (il < nrows ? il : nrows - 1)) * g.C + jc;
+          ad[e] = g.addend ? g.addend[oc] : 0.f;
+          zm[e] = g.zmask ? g.zmask[oc] : 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          asm volatile("" : "+v"(ad[e]));
+          asm volatile("" : "+v"(zm[e]));
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const int il = wrow0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
           if (il < nrows && jv) {
             const long long o = (row0 + il) * g.C + j;
-            float v = acc[m][n][e] + bias;
-            if (g.addend) v += g.addend[o];
+            float v = acc[m][n][e] + bias + ad[e];
             float w2 = v;
             if (g.zmask) {
-              const float z = g.zmask[o];
-              if (!(fmaf(msc, z, msh) > 0.f)) v = 0.f;
-              w2 = z;
+              if (!(fmaf(msc, zm[e], msh) > 0.f)) v = 0.f;
+              w2 = zm[e];
             }
             if (g.out) g.out[o] = v;
             a1 += v;
             a2 = fmaf(v, w2, a2);
           }
         }
+      }
       s1[n] = a1 + __shfl_xor(a1, 32, 64);
       s2[n] = a2 + __shfl_xor(a2, 32, 64);
     }
@@ -341,7 +429,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     for (int n = 0; n < NT; ++n) {
       const int j = col0 + wcol0 + n * 32 + r;
       const bool jv = j < g.C;
-      const float sg = jv ? g.sgn[j] : 1.f;
+      const float sg = (jv && g.sgn[j] < 0.f) ? -1.f : 1.f;   // g.sgn may be gamma itself: only its sign is used
       float a1 = 0.f, a2 = 0.f, best = -INFINITY;
       int besti = 0x7fffffff;
 #pragma unroll

@@ -41,6 +41,7 @@ int dense_bwd_pre(const float* da, const float* z, int R, int C, const float* ga
                   float* dbeta, float* dbias, hipStream_t st);
 int dense_wgrad(const float* x, int ldx, const float* dz, int R, int K, int C, float* dw, hipStream_t st);
 int transpose(const float* in, int R, int C, float* out, hipStream_t st);
+int transpose2(const float* in, int R, int C, const float* rowscale, float* out, float* out2, hipStream_t st);
 int softmax_xent_rows(const float* logits, int R, int C, const int* labels, float grad_scale, float* probs, float* dlogits,
                       float* loss_sum, float* correct, hipStream_t st);
 int softmax_bwd_rows(const float* probs, const float* dprobs, long long R, int C, float* dlogits, hipStream_t st);

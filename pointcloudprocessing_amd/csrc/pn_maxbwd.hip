@@ -16,7 +16,7 @@
 
 namespace pn {
 
-// one thread per channel: h, S1, S2 -> hs (B,C), e, f, dgamma, dbeta
+// block = 32 channels x 8 partitions of the clouds: h, S1, S2 -> hs (B,C), e, f, dgamma, dbeta
 __global__ __launch_bounds__(256) void maxbwd_prep_kernel(const float* __restrict__ dg, const float* __restrict__ g,
                                                           const float* __restrict__ zstar, int B, int C,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
@@ -24,17 +24,27 @@ __global__ __launch_bounds__(256) void maxbwd_prep_kernel(const float* __restric
                                                           float* __restrict__ hs, float* __restrict__ e, float* __restrict__ nege,
                                                           float* __restrict__ f, float* __restrict__ dgamma,
                                                           float* __restrict__ dbeta) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const float sc = scale[c], mu = mean[c], is = invstd[c];
+  __shared__ double red[8][2][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
+  float sc = 0.f, mu = 0.f, is = 0.f;
   double S1 = 0.0, S2 = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const long long o = (long long)b * C + c;
-    const float h = g[o] > 0.f ? dg[o] : 0.f;
-    hs[o] = sc * h;
-    S1 += (double)h;
-    S2 += (double)h * (double)((zstar[o] - mu) * is);
+  if (c < C) {
+    sc = scale[c]; mu = mean[c]; is = invstd[c];
+    for (int b = ty; b < B; b += 8) {
+      const long long o = (long long)b * C + c;
+      const float h = g[o] > 0.f ? dg[o] : 0.f;
+      hs[o] = sc * h;
+      S1 += (double)h;
+      S2 += (double)h * (double)((zstar[o] - mu) * is);
+    }
   }
+  red[ty][0][tx] = S1;
+  red[ty][1][tx] = S2;
+  __syncthreads();
+  if (ty != 0 || c >= C) return;
+  S1 = 0.0; S2 = 0.0;
+  for (int q = 0; q < 8; ++q) { S1 += red[q][0][tx]; S2 += red[q][1][tx]; }
   if (batch_stats) {
     if (dgamma) dgamma[c] = (float)S2;
     if (dbeta) dbeta[c] = (float)S1;
@@ -98,35 +108,83 @@ __global__ __launch_bounds__(64) void maxbwd_q_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) q[k] = s;
 }
 
-// D[m][k] = q[k] + sum_{c : arg[b][c] == m} hs[b][c] * Wt[c][k]     block per 128-row tile, fixed (ascending c)
-// order => bitwise reproducible.  K <= 128.
+// D[m][k] = q[k] + sum_{c : arg[b][c] == m} hs[b][c] * Wt[c][k]     block per 128-row tile, processed as two 64-row
+// halves.  Per half the (at most C) hits are first compacted into LDS in ascending channel order (per-thread counts +
+// block scan), then applied in that order => bitwise reproducible, no atomics.  K <= 128, threads <-> k.
 __global__ __launch_bounds__(128) void maxbwd_scatter_kernel(const int* __restrict__ arg, const float* __restrict__ hs,
                                                              const float* __restrict__ wt, const float* __restrict__ q, int N,
                                                              int K, int C, int tiles_per_cloud, float* __restrict__ D) {
-  __shared__ float tile[128][128];
+  constexpr int CHUNK = 1024;                 // channels examined per compaction round (8 per thread)
+  __shared__ float tile[64][128];             // 32 KB
+  __shared__ int hit_pk[CHUNK];               // (row << 16) | channel-in-chunk
+  __shared__ float hit_h[CHUNK];
+  __shared__ int cnt[129];
   const int bx = blockIdx.x, cloud = bx / tiles_per_cloud, tin = bx - cloud * tiles_per_cloud;
-  const int k = threadIdx.x;
+  const int t = threadIdx.x, k = t;
   const int r0 = tin * 128, nrows = min(128, N - r0);
   const float qk = (k < K) ? q[k] : 0.f;
-  for (int r = 0; r < 128; ++r) tile[r][k] = qk;
   const int* ab = arg + (long long)cloud * C;
   const float* hb = hs + (long long)cloud * C;
-  for (int c = 0; c < C; ++c) {
-    const int m = ab[c] - r0;
-    if (m >= 0 && m < nrows) {
-      const float h = hb[c];
-      if (k < K) tile[m][k] = fmaf(h, wt[(long long)c * K + k], tile[m][k]);
+  for (int half = 0; half < 2; ++half) {
+    const int rbase = r0 + 64 * half;
+    const int nr = min(64, nrows - 64 * half);
+    if (nr <= 0) break;                        // block-uniform
+    for (int r = 0; r < 64; ++r) tile[r][k] = qk;
+    for (int c0 = 0; c0 < C; c0 += CHUNK) {
+      int mine[8];
+      int n = 0;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int c = c0 + 8 * t + i;
+        const int m = (c < C) ? (ab[c] - rbase) : -1;
+        mine[i] = (m >= 0 && m < nr) ? m : -1;
+        n += (mine[i] >= 0) ? 1 : 0;
+      }
+      __syncthreads();                         // previous round's hit list fully consumed
+      cnt[t + 1] = n;
+      if (t == 0) cnt[0] = 0;
+      __syncthreads();
+      if (t == 0)
+        for (int i = 1; i <= 128; ++i) cnt[i] += cnt[i - 1];
+      __syncthreads();
+      int o = cnt[t];
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        if (mine[i] >= 0) {
+          hit_pk[o] = (mine[i] << 16) | (8 * t + i);
+          hit_h[o] = hb[c0 + 8 * t + i];
+          ++o;
+        }
+      __syncthreads();
+      const int nh = cnt[128];
+      if (k < K) {
+        int i = 0;
+        for (; i + 3 < nh; i += 4) {
+          const int p0 = hit_pk[i], p1 = hit_pk[i + 1], p2 = hit_pk[i + 2], p3 = hit_pk[i + 3];
+          const float w0 = wt[(long long)(c0 + (p0 & 0xffff)) * K + k], w1 = wt[(long long)(c0 + (p1 & 0xffff)) * K + k];
+          const float w2 = wt[(long long)(c0 + (p2 & 0xffff)) * K + k], w3 = wt[(long long)(c0 + (p3 & 0xffff)) * K + k];
+          tile[p0 >> 16][k] = fmaf(hit_h[i], w0, tile[p0 >> 16][k]);
+          tile[p1 >> 16][k] = fmaf(hit_h[i + 1], w1, tile[p1 >> 16][k]);
+          tile[p2 >> 16][k] = fmaf(hit_h[i + 2], w2, tile[p2 >> 16][k]);
+          tile[p3 >> 16][k] = fmaf(hit_h[i + 3], w3, tile[p3 >> 16][k]);
+        }
+        for (; i < nh; ++i) {
+          const int p0 = hit_pk[i];
+          tile[p0 >> 16][k] = fmaf(hit_h[i], wt[(long long)(c0 + (p0 & 0xffff)) * K + k], tile[p0 >> 16][k]);
+        }
+      }
     }
+    if (k < K)
+      for (int r = 0; r < nr; ++r) D[((long long)cloud * N + rbase + r) * K + k] = tile[r][k];
+    __syncthreads();
   }
-  if (k < K)
-    for (int r = 0; r < nrows; ++r) D[((long long)cloud * N + r0 + r) * K + k] = tile[r][k];
 }
 
 int maxbwd_prep(const float* dg, const float* g, const float* zstar, int B, int C, const float* mean, const float* invstd,
                 const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege, float* f, float* dgamma,
                 float* dbeta, hipStream_t st) {
   PN_CHECK_ARG(dg && g && zstar && mean && invstd && scale && hs && e && nege && f, "maxbwd_prep: null pointer");
-  hipLaunchKernelGGL(maxbwd_prep_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, dg, g, zstar, B, C, mean, invstd, scale, batch_stats,
+  hipLaunchKernelGGL(maxbwd_prep_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, dg, g, zstar, B, C, mean, invstd, scale, batch_stats,
                      1.0 / (double)count, hs, e, nege, f, dgamma, dbeta);
   PN_CHECK_LAUNCH();
   return PN_OK;

@@ -120,7 +120,7 @@ struct CL {   // per-point conv layer state
   int C = 0;
 };
 struct ML {   // extra state of a max-pooled layer
-  float *sgn, *pmax, *g, *zstar, *hs, *e, *nege, *f, *a1part, *a1, *gram, *GW, *Pm, *q, *D, *Wt, *dG;
+  float *sgn, *pmax, *g, *zstar, *hs, *e, *nege, *f, *a1part, *a1, *gram, *GW, *Pm, *q, *D, *Wt, *We, *dG;
   int *pidx, *arg;
 };
 struct DLs {  // dense layer state (rows = B)
@@ -202,6 +202,7 @@ static void plan_ml(Arena& A, ML& m, const char* nm, int B, long long M, int T, 
     m.q = A.get<float>((n + ".q").c_str(), K);
     m.D = A.get<float>((n + ".D").c_str(), (size_t)M * K);
     m.Wt = A.get<float>((n + ".Wt").c_str(), (size_t)K * C);
+    m.We = A.get<float>((n + ".We").c_str(), (size_t)K * C);
     m.dG = A.get<float>((n + ".dG").c_str(), (size_t)B * C);
   }
 }
@@ -286,6 +287,8 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
     }
     const size_t c3f = (size_t)T * 3 * 64;
     if (c3f > sf) sf = c3f;
+    const size_t pmf = wgrad_slab_floats(1, 1024, 128, 128);    // W diag(e) W^T of the max-pooled layers
+    if (pmf > sf) sf = pmf;
     w.slab_floats = sf;
     w.slabs = A.get<float>("slabs", sf);
   }
@@ -340,7 +343,7 @@ struct Run {
     return bn_fin(l, r);
   }
   int fwd_max(CL& l, ML& m, const LRef& r, const pn_operand& x, int prof_slot) {
-    PN_TRY(sign_of(p(r.gamma), r.cout, m.sgn, st));
+    m.sgn = p(r.gamma);   // only the sign is used (sgn(gamma) = sgn(BN scale))
     void** ev = io.prof_events;
     if (ev && ev[2 * prof_slot]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot]), st);
     PN_TRY(conv_fwd_max(&x, p(r.kernel), B, N, r.cin, r.cout, m.sgn, m.pmax, m.pidx, bn_batch(r.block) ? l.part : nullptr, prec, st));
@@ -454,14 +457,17 @@ struct Run {
 
   // ---------------- backward pieces ----------------
   int wgrad_to(const pn_operand& a, const pn_operand& b, int Ci, int Cj, float* out, bool per_cloud) {
+    return wgrad_general(a, b, B, N, Ci, Cj, out, per_cloud, prec);
+  }
+  int wgrad_general(const pn_operand& a, const pn_operand& b, int Bq, int Nq, int Ci, int Cj, float* out, bool per_cloud, int pr) {
     int spc;
-    const int rows = (int)wgrad_slab_rows(B, N, Ci, Cj, &spc);
-    if ((size_t)B * spc * Ci * Cj > w.slab_floats) {
+    const int rows = (int)wgrad_slab_rows(Bq, Nq, Ci, Cj, &spc);
+    if ((size_t)Bq * spc * Ci * Cj > w.slab_floats) {
       set_error("wgrad: slab scratch too small");
       return PN_ERR_WORKSPACE;
     }
-    PN_TRY(conv_wgrad(&a, &b, B, N, Ci, Cj, rows, w.slabs, prec, st));
-    return slab_reduce(w.slabs, B * spc, per_cloud ? spc : B * spc, (long long)Ci * Cj, out, st);
+    PN_TRY(conv_wgrad(&a, &b, Bq, Nq, Ci, Cj, rows, w.slabs, pr, st));
+    return slab_reduce(w.slabs, Bq * spc, per_cloud ? spc : Bq * spc, (long long)Ci * Cj, out, st);
   }
   int bn_bwd_fin(const CL& l, const LRef& r, const float* part) {
     const int bs = bn_batch(r.block) ? 1 : 0;
@@ -490,11 +496,11 @@ struct Run {
       PN_TRY(conv_fwd(&gop, p(r.kernel), 0, 1, K, K, C, nullptr, m.GW, nullptr, PN_PREC_BF16X3, st));
       PN_TRY(maxbwd_dw(&xop, m.arg, m.hs, B, N, K, C, m.a1, m.f, m.e, m.GW, gr(r.kernel), st));
     }
-    pn_operand wop = plain(p(r.kernel), C);
-    wop.ca = m.nege;
-    PN_TRY(conv_bwd_data(&wop, p(r.kernel), 0, 1, K, C, K, nullptr, nullptr, nullptr, nullptr, m.Pm, nullptr, PN_PREC_BF16X3, st));
+    // Pm[k'][k] = sum_c (-e_c) W[k'][c] W[k][c]: the contraction runs over the 1024 channels, so it is laid out as a
+    // weight-gradient problem over "rows" c (16 slabs of 64 channels -> 16 workgroups) instead of one 128x128 tile
+    PN_TRY(transpose2(p(r.kernel), K, C, m.nege, m.Wt, m.We, st));
+    PN_TRY(wgrad_general(plain(m.We, K), plain(m.Wt, K), 1, C, K, K, m.Pm, false, PN_PREC_BF16X3));
     PN_TRY(maxbwd_q(p(r.kernel), m.f, K, C, m.q, st));
-    PN_TRY(transpose(p(r.kernel), K, C, m.Wt, st));
     PN_TRY(maxbwd_scatter(m.arg, m.hs, m.Wt, m.q, B, N, K, C, m.D, st));
     return conv_bwd_data(&xop, m.Pm, 0, B, N, K, K, m.D, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st);
   }

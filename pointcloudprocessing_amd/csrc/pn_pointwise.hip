@@ -151,21 +151,37 @@ int conv3_wgrad(const float* x3, const pn_operand* dz, int B, int N, int C, floa
 // ------------------------------------------------------------------------------------------------------
 // fixed-order slab reduction: out[g][e] = sum_s slabs[g*per_group+s][e]
 // ------------------------------------------------------------------------------------------------------
+// block = 64 consecutive elements x 4 partitions of the slab range; each partition is summed with 4 independent
+// accumulators, partitions are combined in a fixed order -> bitwise reproducible
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int per_group, long long elems,
                                                           float* __restrict__ out) {
-  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-  if (e >= elems) return;
+  __shared__ float red[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const long long e = (long long)blockIdx.x * 64 + tx;
   const int grp = blockIdx.y;
-  const float* s = slabs + (long long)grp * per_group * elems + e;
   float acc = 0.f;
-  for (int i = 0; i < per_group; ++i) acc += s[(long long)i * elems];
-  out[(long long)grp * elems + e] = acc;
+  if (e < elems) {
+    const float* s = slabs + (long long)grp * per_group * elems + e;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int i = ty;
+    for (; i + 12 < per_group; i += 16) {
+      a0 += s[(long long)i * elems];
+      a1 += s[(long long)(i + 4) * elems];
+      a2 += s[(long long)(i + 8) * elems];
+      a3 += s[(long long)(i + 12) * elems];
+    }
+    for (; i < per_group; i += 4) a0 += s[(long long)i * elems];
+    acc = (a0 + a1) + (a2 + a3);
+  }
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && e < elems) out[(long long)grp * elems + e] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
 
 int slab_reduce(const float* slabs, int n_slabs, int per_group, long long elems, float* out, hipStream_t st) {
   PN_CHECK_ARG(slabs && out, "pn_slab_reduce: null pointer");
   PN_CHECK_ARG(n_slabs > 0 && per_group > 0 && n_slabs % per_group == 0 && elems > 0, "pn_slab_reduce: bad sizes");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdivll(elems, 256), n_slabs / per_group), dim3(256), 0, st, slabs,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdivll(elems, 64), n_slabs / per_group), dim3(256), 0, st, slabs,
                      per_group, elems, out);
   PN_CHECK_LAUNCH();
   return PN_OK;
@@ -174,21 +190,36 @@ int slab_reduce(const float* slabs, int n_slabs, int per_group, long long elems,
 // ------------------------------------------------------------------------------------------------------
 // BatchNormalization coefficient finalisers (keras BatchNormalization semantics, see pointnet_hip.h)
 // ------------------------------------------------------------------------------------------------------
+// block = 32 channels x 8 partitions of the tile range; fp64 combine in a fixed order
+__device__ __forceinline__ void reduce_tiles_2(const float* __restrict__ part, int n_tiles, int C, int c, int ty, double (*red)[2][32],
+                                               int tx, double& s1, double& s2) {
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (int t = ty; t < n_tiles; t += 8) {
+      a += (double)part[(long long)t * 2 * C + c];
+      b += (double)part[(long long)t * 2 * C + C + c];
+    }
+  red[ty][0][tx] = a;
+  red[ty][1][tx] = b;
+  __syncthreads();
+  s1 = 0.0; s2 = 0.0;
+  for (int q = 0; q < 8; ++q) { s1 += red[q][0][tx]; s2 += red[q][1][tx]; }
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int n_tiles, int C, double inv_count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ mm, float* __restrict__ mv, float momentum,
                                                           float eps, int use_batch, int update, float* __restrict__ mean_o,
                                                           float* __restrict__ invstd_o, float* __restrict__ scale_o,
                                                           float* __restrict__ shift_o) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[8][2][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
+  double s1 = 0.0, s2 = 0.0;
+  if (use_batch) reduce_tiles_2(part, n_tiles, C, c, ty, red, tx, s1, s2);
+  if (ty != 0 || c >= C) return;
   float mean, var;
   if (use_batch) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int t = 0; t < n_tiles; ++t) {
-      s1 += (double)part[(long long)t * 2 * C + c];
-      s2 += (double)part[(long long)t * 2 * C + C + c];
-    }
     const double m = s1 * inv_count;
     double v = s2 * inv_count - m * m;
     if (v < 0.0) v = 0.0;
@@ -216,7 +247,7 @@ int bn_finalize(const float* part, int n_tiles, int C, long long count, const fl
   PN_CHECK_ARG(gamma && beta && mm && mv && scale && shift, "pn_bn_finalize: null pointer");
   PN_CHECK_ARG(C > 0, "pn_bn_finalize: C must be positive");
   PN_CHECK_ARG(!use_batch || (part && n_tiles > 0 && count > 0), "pn_bn_finalize: batch statistics need partials");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, n_tiles, C, 1.0 / (double)(count > 0 ? count : 1),
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, part, n_tiles, C, 1.0 / (double)(count > 0 ? count : 1),
                      gamma, beta, mm, mv, momentum, eps, use_batch, update, mean, invstd, scale, shift);
   PN_CHECK_LAUNCH();
   return PN_OK;
@@ -228,17 +259,16 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               int batch_stats, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ ca,
                                                               float* __restrict__ cb, float* __restrict__ cc) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[8][2][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx;
+  double s1 = 0.0, s2 = 0.0;
+  if (batch_stats) reduce_tiles_2(part, n_tiles, C, c, ty, red, tx, s1, s2);
+  if (ty != 0 || c >= C) return;
   const float a = gamma[c] * invstd[c];
   if (!batch_stats) {
     ca[c] = a; cb[c] = 0.f; cc[c] = 0.f;
     return;
-  }
-  double s1 = 0.0, s2 = 0.0;
-  for (int t = 0; t < n_tiles; ++t) {
-    s1 += (double)part[(long long)t * 2 * C + c];
-    s2 += (double)part[(long long)t * 2 * C + C + c];
   }
   // S1 = sum dy_hat ; S2 = sum dy_hat * zhat, zhat = (z - mean) * invstd
   const double S1 = s1;
@@ -256,7 +286,7 @@ int bn_bwd_finalize(const float* part, int n_tiles, int C, long long count, cons
                     hipStream_t st) {
   PN_CHECK_ARG(gamma && invstd && ca && cb && cc, "pn_bn_bwd_finalize: null pointer");
   PN_CHECK_ARG(!batch_stats || (part && mean && n_tiles > 0 && count > 0), "pn_bn_bwd_finalize: batch statistics need partials");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, part, n_tiles, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, part, n_tiles, C,
                      1.0 / (double)(count > 0 ? count : 1), gamma, mean, invstd, batch_stats, dgamma, dbeta, ca, cb, cc);
   PN_CHECK_LAUNCH();
   return PN_OK;
@@ -291,7 +321,7 @@ __global__ __launch_bounds__(256) void max_finalize_kernel(const float* __restri
     const int i = pidx[o];
     if (v > best || (v == best && i < bi)) { best = v; bi = i; }
   }
-  const float zs = sgn[c] * best;
+  const float zs = (sgn[c] < 0.f ? -1.f : 1.f) * best;   // sgn may be gamma itself
   const long long o = (long long)b * C + c;
   g[o] = fmaxf(fmaf(scale[c], zs, shift[c]), 0.f);
   if (zstar) zstar[o] = zs;
