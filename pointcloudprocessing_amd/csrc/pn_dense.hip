@@ -8,7 +8,7 @@ namespace pn {
 
 constexpr int DENSE_KS = 32;   // k staged per LDS step
 constexpr int DENSE_RC = 32;   // rows per register chunk
-constexpr int DENSE_MAX_SPLITS = 32;
+constexpr int DENSE_MAX_SPLITS = 16;
 
 // k per split: a multiple of DENSE_KS, at most DENSE_MAX_SPLITS splits
 static inline int dense_split_len(int K) {
@@ -64,15 +64,16 @@ __global__ __launch_bounds__(256) void dense_finalize_kernel(const float* __rest
                                                              int act, const unsigned char* __restrict__ keep, float keep_scale,
                                                              float* __restrict__ z_out, float* __restrict__ a_out,
                                                              float* __restrict__ mean_o, float* __restrict__ invstd_o) {
-  __shared__ float red[8][32];
-  __shared__ float bc[2][32];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int j = blockIdx.x * 32 + tx;
+  constexpr int RP = 16;   // row partitions
+  __shared__ float red[RP][16];
+  __shared__ float bc[2][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int j = blockIdx.x * 16 + tx;
   const bool jv = j < C;
   const float b = (jv && bias) ? bias[j] : 0.f;
   float s1 = 0.f;
   if (jv)
-    for (int r = ty; r < R; r += 8) {
+    for (int r = ty; r < R; r += RP) {
       float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
       int ks = 0;
       for (; ks + 3 < nks; ks += 4) {
@@ -94,14 +95,14 @@ __global__ __launch_bounds__(256) void dense_finalize_kernel(const float* __rest
       __syncthreads();
       if (ty == 0) {
         float t = 0.f;
-        for (int q = 0; q < 8; ++q) t += red[q][tx];
+        for (int q = 0; q < RP; ++q) t += red[q][tx];
         bc[0][tx] = t / (float)R;
       }
       __syncthreads();
       mean = bc[0][tx];
       float s2 = 0.f;
       if (jv)
-        for (int r = ty; r < R; r += 8) {
+        for (int r = ty; r < R; r += RP) {
           const float d = z_out[(long long)r * C + j] - mean;   // written by this thread above
           s2 = fmaf(d, d, s2);
         }
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void dense_finalize_kernel(const float* __rest
       __syncthreads();
       if (ty == 0) {
         float t = 0.f;
-        for (int q = 0; q < 8; ++q) t += red[q][tx];
+        for (int q = 0; q < RP; ++q) t += red[q][tx];
         bc[1][tx] = t / (float)R;
       }
       __syncthreads();
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void dense_finalize_kernel(const float* __rest
     }
   }
   if (a_out && jv) {
-    for (int r = ty; r < R; r += 8) {
+    for (int r = ty; r < R; r += RP) {
       float y = fmaf(sc, z_out[(long long)r * C + j], sh);
       if (act == 1) y = fmaxf(y, 0.f);
       if (keep) y = keep[(long long)r * C + j] ? y * keep_scale : 0.f;
@@ -205,31 +206,35 @@ __global__ __launch_bounds__(256) void dense_bwd_pre_kernel(const float* __restr
   }
 }
 
-// dw[k][j] = sum_r x[r][k] * dz[r][j]
+// dw[k][j] = sum_r x[r][k] * dz[r][j]     thread <-> column j, block <-> 16 consecutive k; rows in chunks of 32 whose
+// dz values are loaded up front (unconditional, clamped) so they are all in flight together
 __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, int R,
                                                           int K, int C, float* __restrict__ dw) {
   constexpr int KT = 16;
-  constexpr int WRC = 16;
-  __shared__ float xs[KT][WRC + 1];
+  constexpr int WRC = 32;
+  __shared__ float xs[KT][WRC];
   const int j = blockIdx.x * 256 + threadIdx.x;
+  const int jc = j < C ? j : C - 1;
   const int k0 = blockIdx.y * KT;
   float acc[KT];
 #pragma unroll
   for (int k = 0; k < KT; ++k) acc[k] = 0.f;
   for (int rc = 0; rc < R; rc += WRC) {
     const int nr = min(WRC, R - rc);
+    float d[WRC];
+#pragma unroll
+    for (int r = 0; r < WRC; ++r) d[r] = dz[(long long)(rc + min(r, nr - 1)) * C + jc];
     __syncthreads();
     for (int t = threadIdx.x; t < KT * WRC; t += 256) {
       const int k = t / WRC, r = t % WRC;
       xs[k][r] = (r < nr && k0 + k < K) ? x[(long long)(rc + r) * ldx + k0 + k] : 0.f;
     }
     __syncthreads();
-    if (j < C) {
-      for (int r = 0; r < nr; ++r) {
-        const float d = dz[(long long)(rc + r) * C + j];
 #pragma unroll
-        for (int k = 0; k < KT; ++k) acc[k] = fmaf(xs[k][r], d, acc[k]);
-      }
+    for (int r = 0; r < WRC; ++r) {
+      const float dv = (r < nr) ? d[r] : 0.f;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) acc[k] = fmaf(xs[k][r], dv, acc[k]);
     }
   }
   if (j < C) {
@@ -352,7 +357,7 @@ int dense_finalize(const float* partial, int nks, int R, int C, const float* bia
                    float* mv, float momentum, float eps, int bn_mode, int act, const unsigned char* keep, float keep_scale,
                    float* z_out, float* a_out, float* mean_o, float* invstd_o, hipStream_t st) {
   PN_CHECK_ARG(partial && z_out, "dense_finalize: null pointer");
-  hipLaunchKernelGGL(dense_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, partial, nks, R, C, bias, gamma, beta, mm, mv,
+  hipLaunchKernelGGL(dense_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nks, R, C, bias, gamma, beta, mm, mv,
                      momentum, eps, bn_mode, act, keep, keep_scale, z_out, a_out, mean_o, invstd_o);
   PN_CHECK_LAUNCH();
   return PN_OK;

@@ -67,34 +67,62 @@ __global__ __launch_bounds__(256) void colsum_lazy_kernel(const pn_operand x, in
   const float ca = x.ca ? x.ca[c] : 1.f, cc = x.cc ? x.cc[c] : 0.f;
   const int r0 = tin * 128 + wave * 32, r1 = min(N, r0 + 32);
   float s = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    const long long row = (long long)cloud * N + r;
-    s += fmaxf(fmaf(ca, x.s1[row * x.ld + c], cc), x.lo);
+  for (int rb = r0; rb < r1; rb += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x.s1[((long long)cloud * N + min(rb + u, r1 - 1)) * x.ld + c];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (rb + u < r1) ? fmaxf(fmaf(ca, v[u], cc), x.lo) : 0.f;
   }
   red[wave][lane] = s;
   __syncthreads();
   if (threadIdx.x < 64) part[(long long)bx * C + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
-// dW[k][c] = sum_b A[row(b,c)][k]*hs[b,c] + a1[k]*f[c] - e[c]*GW[k][c]     block per channel c, thread per k
+// dW[k][c] = sum_b A[row(b,c)][k]*hs[b,c] + a1[k]*f[c] - e[c]*GW[k][c]     block per channel c, thread per k.
+// The B (row, weight) pairs of the channel are staged in LDS first so the gathered rows can be loaded 8 at a time.
 __global__ __launch_bounds__(128) void maxbwd_dw_kernel(const pn_operand x, const int* __restrict__ arg, const float* __restrict__ hs,
                                                         int B, int N, int K, int C, const float* __restrict__ a1,
                                                         const float* __restrict__ f, const float* __restrict__ e,
                                                         const float* __restrict__ GW, float* __restrict__ dW) {
+  __shared__ long long srow[128];
+  __shared__ float sw[128];
   const int c = blockIdx.x;
   const float fc = f[c], ec = e[c];
-  for (int k = threadIdx.x; k < K; k += 128) {
-    const float ca = x.ca ? x.ca[k] : 1.f, cc = x.cc ? x.cc[k] : 0.f;
-    float acc = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float w = hs[(long long)b * C + c];
-      const long long row = (long long)b * N + arg[(long long)b * C + c];
-      const float a = fmaxf(fmaf(ca, x.s1[row * x.ld + k], cc), x.lo);
-      acc = fmaf(a, w, acc);
+  float acc[2] = {0.f, 0.f};        // K <= 256
+  for (int b0 = 0; b0 < B; b0 += 128) {
+    const int nb = min(128, B - b0);
+    __syncthreads();
+    if ((int)threadIdx.x < nb) {
+      const int b = b0 + threadIdx.x;
+      srow[threadIdx.x] = ((long long)b * N + arg[(long long)b * C + c]) * x.ld;
+      sw[threadIdx.x] = hs[(long long)b * C + c];
     }
-    acc = fmaf(a1[k], fc, acc);
-    acc = fmaf(-ec, GW[(long long)k * C + c], acc);
-    dW[(long long)k * C + c] = acc;
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const int k = threadIdx.x + 128 * kk;
+      if (k < K) {
+        const float ca = x.ca ? x.ca[k] : 1.f, cc = x.cc ? x.cc[k] : 0.f;
+        for (int bb = 0; bb < nb; bb += 8) {
+          float v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = x.s1[srow[min(bb + u, nb - 1)] + k];
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (bb + u < nb) acc[kk] = fmaf(fmaxf(fmaf(ca, v[u], cc), x.lo), sw[bb + u], acc[kk]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int k = threadIdx.x + 128 * kk;
+    if (k < K) {
+      float a = fmaf(a1[k], fc, acc[kk]);
+      a = fmaf(-ec, GW[(long long)k * C + c], a);
+      dW[(long long)k * C + c] = a;
+    }
   }
 }
 
@@ -108,75 +136,70 @@ __global__ __launch_bounds__(64) void maxbwd_q_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) q[k] = s;
 }
 
-// D[m][k] = q[k] + sum_{c : arg[b][c] == m} hs[b][c] * Wt[c][k]     block per 128-row tile, processed as two 64-row
-// halves.  Per half the (at most C) hits are first compacted into LDS in ascending channel order (per-thread counts +
-// block scan), then applied in that order => bitwise reproducible, no atomics.  K <= 128, threads <-> k.
-__global__ __launch_bounds__(128) void maxbwd_scatter_kernel(const int* __restrict__ arg, const float* __restrict__ hs,
+// D[m][k] = q[k] + sum_{c : arg[b][c] == m} hs[b][c] * Wt[c][k]        one block per 32-row quarter tile.
+// Critical points are few: the 1024 arg-max rows of a cloud concentrate on a handful of points, so a tile can
+// receive anything from 0 to C contributions, many of them on the same row.  Contributions are therefore accumulated
+// with LDS atomics in 2^-40 FIXED POINT (int64): integer addition is associative, so the result does not depend on
+// the order in which the four waves process the hits -> full parallelism AND bitwise reproducibility.
+// |hs*W| < 2^22 is assumed (the products are gradient-sized).  K <= 128, K % 4 == 0.
+__global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restrict__ arg, const float* __restrict__ hs,
                                                              const float* __restrict__ wt, const float* __restrict__ q, int N,
-                                                             int K, int C, int tiles_per_cloud, float* __restrict__ D) {
-  constexpr int CHUNK = 1024;                 // channels examined per compaction round (8 per thread)
-  __shared__ float tile[64][128];             // 32 KB
-  __shared__ int hit_pk[CHUNK];               // (row << 16) | channel-in-chunk
-  __shared__ float hit_h[CHUNK];
-  __shared__ int cnt[129];
-  const int bx = blockIdx.x, cloud = bx / tiles_per_cloud, tin = bx - cloud * tiles_per_cloud;
-  const int t = threadIdx.x, k = t;
-  const int r0 = tin * 128, nrows = min(128, N - r0);
-  const float qk = (k < K) ? q[k] : 0.f;
+                                                             int K, int C, int quarters_per_cloud, float* __restrict__ D) {
+  constexpr int CHUNK = 1024;                  // channels examined per round (4 per thread)
+  constexpr double FX = 1099511627776.0;       // 2^40
+  __shared__ unsigned long long tile[32][128]; // 32 KB
+  __shared__ int hit_pk[CHUNK];                // (row << 16) | channel-in-chunk, unordered
+  __shared__ int nhit;
+  const int bx = blockIdx.x, cloud = bx / quarters_per_cloud, qin = bx - cloud * quarters_per_cloud;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int rbase = qin * 32, nr = min(32, N - rbase);
   const int* ab = arg + (long long)cloud * C;
   const float* hb = hs + (long long)cloud * C;
-  for (int half = 0; half < 2; ++half) {
-    const int rbase = r0 + 64 * half;
-    const int nr = min(64, nrows - 64 * half);
-    if (nr <= 0) break;                        // block-uniform
-    for (int r = 0; r < 64; ++r) tile[r][k] = qk;
-    for (int c0 = 0; c0 < C; c0 += CHUNK) {
-      int mine[8];
-      int n = 0;
+  for (int i = t; i < 32 * 128; i += 256) (&tile[0][0])[i] = 0ull;
+  if (t == 0) nhit = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < C; c0 += CHUNK) {
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int c = c0 + 8 * t + i;
-        const int m = (c < C) ? (ab[c] - rbase) : -1;
-        mine[i] = (m >= 0 && m < nr) ? m : -1;
-        n += (mine[i] >= 0) ? 1 : 0;
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + 4 * t + i;
+      const int m = (c < C) ? (ab[c] - rbase) : -1;
+      if (m >= 0 && m < nr) hit_pk[atomicAdd(&nhit, 1)] = (m << 16) | (4 * t + i);
+    }
+    __syncthreads();
+    const int total = nhit;
+    // wave w takes hits w, w+4, ...; four of them (8 row loads per lane) are in flight at a time
+    for (int i0 = wave; i0 < total; i0 += 16) {
+      int pk[4];
+      float h[4], w0[4], w1[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = min(i0 + 4 * u, total - 1);
+        pk[u] = hit_pk[i];
+        const int c = c0 + (pk[u] & 0xffff);
+        h[u] = hb[c];
+        w0[u] = wt[(long long)c * K + min(lane, K - 1)];
+        w1[u] = wt[(long long)c * K + min(lane + 64, K - 1)];
       }
-      __syncthreads();                         // previous round's hit list fully consumed
-      cnt[t + 1] = n;
-      if (t == 0) cnt[0] = 0;
-      __syncthreads();
-      if (t == 0)
-        for (int i = 1; i <= 128; ++i) cnt[i] += cnt[i - 1];
-      __syncthreads();
-      int o = cnt[t];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        if (mine[i] >= 0) {
-          hit_pk[o] = (mine[i] << 16) | (8 * t + i);
-          hit_h[o] = hb[c0 + 8 * t + i];
-          ++o;
-        }
-      __syncthreads();
-      const int nh = cnt[128];
-      if (k < K) {
-        int i = 0;
-        for (; i + 3 < nh; i += 4) {
-          const int p0 = hit_pk[i], p1 = hit_pk[i + 1], p2 = hit_pk[i + 2], p3 = hit_pk[i + 3];
-          const float w0 = wt[(long long)(c0 + (p0 & 0xffff)) * K + k], w1 = wt[(long long)(c0 + (p1 & 0xffff)) * K + k];
-          const float w2 = wt[(long long)(c0 + (p2 & 0xffff)) * K + k], w3 = wt[(long long)(c0 + (p3 & 0xffff)) * K + k];
-          tile[p0 >> 16][k] = fmaf(hit_h[i], w0, tile[p0 >> 16][k]);
-          tile[p1 >> 16][k] = fmaf(hit_h[i + 1], w1, tile[p1 >> 16][k]);
-          tile[p2 >> 16][k] = fmaf(hit_h[i + 2], w2, tile[p2 >> 16][k]);
-          tile[p3 >> 16][k] = fmaf(hit_h[i + 3], w3, tile[p3 >> 16][k]);
-        }
-        for (; i < nh; ++i) {
-          const int p0 = hit_pk[i];
-          tile[p0 >> 16][k] = fmaf(hit_h[i], wt[(long long)(c0 + (p0 & 0xffff)) * K + k], tile[p0 >> 16][k]);
+      for (int u = 0; u < 4; ++u) {
+        if (i0 + 4 * u < total) {              // wave-uniform
+          const int m = pk[u] >> 16;
+          if (lane < K) atomicAdd(&tile[m][lane], (unsigned long long)__double2ll_rn((double)(h[u] * w0[u]) * FX));
+          if (lane + 64 < K) atomicAdd(&tile[m][lane + 64], (unsigned long long)__double2ll_rn((double)(h[u] * w1[u]) * FX));
         }
       }
     }
-    if (k < K)
-      for (int r = 0; r < nr; ++r) D[((long long)cloud * N + rbase + r) * K + k] = tile[r][k];
     __syncthreads();
+    if (t == 0) nhit = 0;
+    __syncthreads();
+  }
+  {
+    const int k = t & 127, r0 = (t >> 7) * 16;
+    if (k < K) {
+      const float qk = q[k];
+      for (int r = r0; r < min(r0 + 16, nr); ++r)
+        D[((long long)cloud * N + rbase + r) * K + k] = (float)((double)(long long)tile[r][k] * (1.0 / FX)) + qk;
+    }
   }
 }
 
@@ -216,8 +239,8 @@ int maxbwd_scatter(const int* arg, const float* hs, const float* wt, const float
                    hipStream_t st) {
   PN_CHECK_ARG(arg && hs && wt && q && D, "maxbwd_scatter: null pointer");
   PN_CHECK_ARG(K <= 128, "maxbwd_scatter: K must be <= 128 (K=%d)", K);
-  const int tpc = cdiv(N, 128);
-  hipLaunchKernelGGL(maxbwd_scatter_kernel, dim3(B * tpc), dim3(128), 0, st, arg, hs, wt, q, N, K, C, tpc, D);
+  const int qpc = cdiv(N, 32);
+  hipLaunchKernelGGL(maxbwd_scatter_kernel, dim3(B * qpc), dim3(256), 0, st, arg, hs, wt, q, N, K, C, qpc, D);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

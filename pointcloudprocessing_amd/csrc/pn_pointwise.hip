@@ -121,14 +121,25 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restric
   const int r0 = tin * 128 + wave * 32;
   const int r1 = min(N, r0 + 32);
   float g0 = 0.f, g1 = 0.f, g2 = 0.f;
-  for (int r = r0; r < r1; ++r) {
-    const long long row = (long long)cloud * N + r;
-    float d = fmaf(ca, dz.s1[row * dz.ld + c], cc);
-    if (dz.s2) d = fmaf(cb, dz.s2[row * dz.ld + c], d);
-    d = fmaxf(d, dz.lo);
-    g0 = fmaf(x3[row * 3], d, g0);
-    g1 = fmaf(x3[row * 3 + 1], d, g1);
-    g2 = fmaf(x3[row * 3 + 2], d, g2);
+  const bool two = dz.s2 != nullptr;
+  for (int rb = r0; rb < r1; rb += 8) {
+    float y[8], zz[8], xa[8], xb[8], xc[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {            // 8 rows in flight; rows past the end are clamped and masked below
+      const long long row = (long long)cloud * N + min(rb + u, r1 - 1);
+      y[u] = dz.s1[row * dz.ld + c];
+      zz[u] = two ? dz.s2[row * dz.ld + c] : 0.f;
+      xa[u] = x3[row * 3]; xb[u] = x3[row * 3 + 1]; xc[u] = x3[row * 3 + 2];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float d = fmaf(ca, y[u], cc);
+      d = fmaf(cb, zz[u], d);
+      d = (rb + u < r1) ? fmaxf(d, dz.lo) : 0.f;
+      g0 = fmaf(xa[u], d, g0);
+      g1 = fmaf(xb[u], d, g1);
+      g2 = fmaf(xc[u], d, g2);
+    }
   }
   red[wave][0][lane] = g0; red[wave][1][lane] = g1; red[wave][2][lane] = g2;
   __syncthreads();
@@ -151,37 +162,37 @@ int conv3_wgrad(const float* x3, const pn_operand* dz, int B, int N, int C, floa
 // ------------------------------------------------------------------------------------------------------
 // fixed-order slab reduction: out[g][e] = sum_s slabs[g*per_group+s][e]
 // ------------------------------------------------------------------------------------------------------
-// block = 64 consecutive elements x 4 partitions of the slab range; each partition is summed with 4 independent
+// block = 32 consecutive elements x 8 partitions of the slab range; each partition is summed with 4 independent
 // accumulators, partitions are combined in a fixed order -> bitwise reproducible
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int per_group, long long elems,
                                                           float* __restrict__ out) {
-  __shared__ float red[4][64];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-  const long long e = (long long)blockIdx.x * 64 + tx;
+  __shared__ float red[8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const long long e = (long long)blockIdx.x * 32 + tx;
   const int grp = blockIdx.y;
   float acc = 0.f;
   if (e < elems) {
     const float* s = slabs + (long long)grp * per_group * elems + e;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int i = ty;
-    for (; i + 12 < per_group; i += 16) {
-      a0 += s[(long long)i * elems];
-      a1 += s[(long long)(i + 4) * elems];
-      a2 += s[(long long)(i + 8) * elems];
-      a3 += s[(long long)(i + 12) * elems];
+    for (; i + 24 < per_group; i += 32) {
+      const float x0 = s[(long long)i * elems], x1 = s[(long long)(i + 8) * elems];
+      const float x2 = s[(long long)(i + 16) * elems], x3 = s[(long long)(i + 24) * elems];
+      a0 += x0; a1 += x1; a2 += x2; a3 += x3;
     }
-    for (; i < per_group; i += 4) a0 += s[(long long)i * elems];
+    for (; i < per_group; i += 8) a0 += s[(long long)i * elems];
     acc = (a0 + a1) + (a2 + a3);
   }
   red[ty][tx] = acc;
   __syncthreads();
-  if (ty == 0 && e < elems) out[(long long)grp * elems + e] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+  if (ty == 0 && e < elems)
+    out[(long long)grp * elems + e] = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
 }
 
 int slab_reduce(const float* slabs, int n_slabs, int per_group, long long elems, float* out, hipStream_t st) {
   PN_CHECK_ARG(slabs && out, "pn_slab_reduce: null pointer");
   PN_CHECK_ARG(n_slabs > 0 && per_group > 0 && n_slabs % per_group == 0 && elems > 0, "pn_slab_reduce: bad sizes");
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdivll(elems, 64), n_slabs / per_group), dim3(256), 0, st, slabs,
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdivll(elems, 32), n_slabs / per_group), dim3(256), 0, st, slabs,
                      per_group, elems, out);
   PN_CHECK_LAUNCH();
   return PN_OK;
@@ -190,20 +201,31 @@ int slab_reduce(const float* slabs, int n_slabs, int per_group, long long elems,
 // ------------------------------------------------------------------------------------------------------
 // BatchNormalization coefficient finalisers (keras BatchNormalization semantics, see pointnet_hip.h)
 // ------------------------------------------------------------------------------------------------------
-// block = 32 channels x 8 partitions of the tile range; fp64 combine in a fixed order
-__device__ __forceinline__ void reduce_tiles_2(const float* __restrict__ part, int n_tiles, int C, int c, int ty, double (*red)[2][32],
+// block = 16 channels x 16 partitions of the tile range, 4 tiles in flight per thread; fp64 combine in a fixed order
+__device__ __forceinline__ void reduce_tiles_2(const float* __restrict__ part, int n_tiles, int C, int c, int ty, double (*red)[2][16],
                                                int tx, double& s1, double& s2) {
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (int t = ty; t < n_tiles; t += 8) {
-      a += (double)part[(long long)t * 2 * C + c];
-      b += (double)part[(long long)t * 2 * C + C + c];
+  if (c < C) {
+    const float* p = part + c;
+    int t = ty;
+    for (; t + 48 < n_tiles; t += 64) {
+      const float x0 = p[(long long)t * 2 * C], y0 = p[(long long)t * 2 * C + C];
+      const float x1 = p[(long long)(t + 16) * 2 * C], y1 = p[(long long)(t + 16) * 2 * C + C];
+      const float x2 = p[(long long)(t + 32) * 2 * C], y2 = p[(long long)(t + 32) * 2 * C + C];
+      const float x3 = p[(long long)(t + 48) * 2 * C], y3 = p[(long long)(t + 48) * 2 * C + C];
+      a += (double)x0; a += (double)x1; a += (double)x2; a += (double)x3;
+      b += (double)y0; b += (double)y1; b += (double)y2; b += (double)y3;
     }
+    for (; t < n_tiles; t += 16) {
+      a += (double)p[(long long)t * 2 * C];
+      b += (double)p[(long long)t * 2 * C + C];
+    }
+  }
   red[ty][0][tx] = a;
   red[ty][1][tx] = b;
   __syncthreads();
   s1 = 0.0; s2 = 0.0;
-  for (int q = 0; q < 8; ++q) { s1 += red[q][0][tx]; s2 += red[q][1][tx]; }
+  for (int q = 0; q < 16; ++q) { s1 += red[q][0][tx]; s2 += red[q][1][tx]; }
 }
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int n_tiles, int C, double inv_count,
@@ -212,9 +234,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float eps, int use_batch, int update, float* __restrict__ mean_o,
                                                           float* __restrict__ invstd_o, float* __restrict__ scale_o,
                                                           float* __restrict__ shift_o) {
-  __shared__ double red[8][2][32];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tx;
+  __shared__ double red[16][2][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + tx;
   double s1 = 0.0, s2 = 0.0;
   if (use_batch) reduce_tiles_2(part, n_tiles, C, c, ty, red, tx, s1, s2);
   if (ty != 0 || c >= C) return;
@@ -247,7 +269,7 @@ int bn_finalize(const float* part, int n_tiles, int C, long long count, const fl
   PN_CHECK_ARG(gamma && beta && mm && mv && scale && shift, "pn_bn_finalize: null pointer");
   PN_CHECK_ARG(C > 0, "pn_bn_finalize: C must be positive");
   PN_CHECK_ARG(!use_batch || (part && n_tiles > 0 && count > 0), "pn_bn_finalize: batch statistics need partials");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, part, n_tiles, C, 1.0 / (double)(count > 0 ? count : 1),
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, part, n_tiles, C, 1.0 / (double)(count > 0 ? count : 1),
                      gamma, beta, mm, mv, momentum, eps, use_batch, update, mean, invstd, scale, shift);
   PN_CHECK_LAUNCH();
   return PN_OK;
@@ -259,9 +281,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               int batch_stats, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ ca,
                                                               float* __restrict__ cb, float* __restrict__ cc) {
-  __shared__ double red[8][2][32];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tx;
+  __shared__ double red[16][2][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + tx;
   double s1 = 0.0, s2 = 0.0;
   if (batch_stats) reduce_tiles_2(part, n_tiles, C, c, ty, red, tx, s1, s2);
   if (ty != 0 || c >= C) return;
@@ -286,7 +308,7 @@ int bn_bwd_finalize(const float* part, int n_tiles, int C, long long count, cons
                     hipStream_t st) {
   PN_CHECK_ARG(gamma && invstd && ca && cb && cc, "pn_bn_bwd_finalize: null pointer");
   PN_CHECK_ARG(!batch_stats || (part && mean && n_tiles > 0 && count > 0), "pn_bn_bwd_finalize: batch statistics need partials");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, part, n_tiles, C,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, part, n_tiles, C,
                      1.0 / (double)(count > 0 ? count : 1), gamma, mean, invstd, batch_stats, dgamma, dbeta, ca, cb, cc);
   PN_CHECK_LAUNCH();
   return PN_OK;

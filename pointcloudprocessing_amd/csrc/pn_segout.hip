@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void seg_out_fwd_kernel(const pn_operand x, co
 #pragma unroll
     for (int c = 0; c < SEG_CM; ++c) acc[c] = (c < C && bias) ? bias[c] : 0.f;
     const float* src = x.s1 + row * x.ld;
+#pragma unroll 4
     for (int k = 0; k < K; k += 4) {
       const float4 v = *reinterpret_cast<const float4*>(src + k);
       const float a0 = fmaxf(fmaf(ca[k], v.x, cc[k]), x.lo), a1 = fmaxf(fmaf(ca[k + 1], v.y, cc[k + 1]), x.lo);
