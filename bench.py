@@ -106,51 +106,13 @@ def main():
     (model.freeze_segmentation_head if args.profile == "classification_pretrain" else model.thaw_segmentation_head)()
     opt = KerasAdam(model.params_flat.data, 1e-4, 7000, 0.7)
     pc, y_cls, y_seg, se3 = synth_batch(B, N, 20260001 + rank, dev)
-    keep = ((torch.rand(B, 512, device=dev) >= 0.3).to(torch.uint8), (torch.rand(B, 256, device=dev) >= 0.3).to(torch.uint8))
-
-    def fwd_bwd():
-        # fresh dropout masks every step, generated on the device
-        keep[0].copy_(torch.rand(B, 512, device=dev) >= 0.3)
-        keep[1].copy_(torch.rand(B, 256, device=dev) >= 0.3)
-        model.fused_loss_step(pc, y_cls, y_seg, se3, lw, keep=keep)
-
-    def step_eager():
-        fwd_bwd()
-        if world > 1:
-            dist.all_reduce(model.grads_flat)
-        opt.step(model.grads_flat, 1.0 / world)
-
-    # ---- optional hipGraph of the step (fwd+bwd [+Adam when single GPU]); the all-reduce stays eager ----
-    graph_mode = "eager"
-    step = step_eager
-    if not args.no_graph:
-        try:
-            for _ in range(3):
-                step_eager()
-            torch.cuda.synchronize()
-            g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                fwd_bwd()
-                if world == 1:
-                    opt.step(model.grads_flat, 1.0)
-            if world == 1:
-                step = g1.replay
-            else:
-                g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2):
-                    opt.step(model.grads_flat, 1.0 / world)
-
-                def step():
-                    g1.replay()
-                    dist.all_reduce(model.grads_flat)
-                    g2.replay()
-            graph_mode = "hipgraph"
-            torch.cuda.synchronize()
-        except Exception as e:                        # capture unsupported: stay eager, say so in the JSON
-            if rank == 0:
-                print(f"# hipGraph capture failed ({type(e).__name__}: {e}); running eager", file=sys.stderr)
-            step = step_eager
-            graph_mode = "eager"
+    from pointcloudprocessing_amd.engine import TrainStep
+    ts = TrainStep(model, opt, B, N, lw, use_graph=not args.no_graph)      # hipGraph replay of the whole step
+    ts.load(pc, y_cls, y_seg, se3)
+    step, step_eager = ts.run, ts._eager
+    for _ in range(3):
+        step()            # two eager steps, then the step is captured into a hipGraph
+    graph_mode = ts.mode
 
     for _ in range(args.warmup):
         step()

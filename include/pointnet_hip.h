@@ -111,6 +111,14 @@ int pn_conv_fwd(const pn_operand* x, const float* w, int64_t w_cloud_stride, int
 int pn_conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C, const float* sgn,
                     float* pmax, int32_t* pidx, float* stat_partials, int prec, pn_stream stream);
 
+/* --- the same layer as a ROW-PANEL kernel (the one the model plan uses): a workgroup owns 64 point rows for ALL C channels,
+ * the activation panel is staged into LDS once and the kernel is streamed from a bf16 channel-major copy made by
+ * pn_weights_prep (wb_hi[c][k] = bf16(W[k][c]); wb_lo = bf16(W - hi), needed for PN_PREC_BF16X3 only).
+ * K in {64, 128}; tiles are 64 rows: n_tiles = B*ceil(N/64) for pmax / pidx / stat_partials. */
+int pn_weights_prep(const float* w, int K, int C, void* wb_hi, void* wb_lo, pn_stream stream);
+int pn_conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C,
+                          const float* sgn, float* pmax, int32_t* pidx, float* stat_partials, int prec, pn_stream stream);
+
 /* --- data gradient of a ConvLayer: out = [relu-mask] (dz . W^T + addend), plus the two partial sums
  * BatchNormalization's backward needs (sum dy_hat, sum dy_hat*z) per channel.
  *   dz      lazy operand over (B*N, K)   (K = the layer's output width)

@@ -38,6 +38,13 @@ int pn_conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, in
                     float* part, int prec, pn_stream stream) {
   return conv_fwd_max(x, w, B, N, K, C, sgn, pmax, pidx, part, prec, S(stream));
 }
+int pn_weights_prep(const float* w, int K, int C, void* wb_hi, void* wb_lo, pn_stream stream) {
+  return weights_prep(w, K, C, wb_hi, wb_lo, S(stream));
+}
+int pn_conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C, const float* sgn,
+                          float* pmax, int32_t* pidx, float* part, int prec, pn_stream stream) {
+  return conv_fwd_max_panel(x, wb_hi, wb_lo, B, N, K, C, sgn, pmax, pidx, part, prec, S(stream));
+}
 int pn_conv_bwd_data(const pn_operand* dz, const float* w, int64_t wcs, int B, int N, int K, int C, const float* addend,
                      const float* zmask, const float* msc, const float* msh, float* out, float* part, int prec, pn_stream stream) {
   return conv_bwd_data(dz, w, wcs, B, N, K, C, addend, zmask, msc, msh, out, part, prec, S(stream));

@@ -253,9 +253,51 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT][NT], const __bf16* A
   }
 }
 
+// ---- STORE epilogue for one (m-block, n-block) pair of accumulator registers; all uniform options are template
+//      parameters so that the unrolled body has no branches at all (a scalar branch per element serialises the wave)
+template <bool FULL, bool HAS_ADD, bool HAS_MASK, bool HAS_OUT>
+__device__ __forceinline__ void epi_store_block(const f32x16& acc, const GemmArgs& g, long long row0, int il0, int nrows, int j, bool jv,
+                                                float bias, float msc, float msh, float& a1, float& a2) {
+  float ad[16], zm[16];
+  const int jc = jv ? j : (g.C - 1);
+  if (HAS_ADD || HAS_MASK) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {          // unconditional, clamped loads first so they are all in flight together
+      const int il = il0 + (e & 3) + 8 * (e >> 2);
+      const long long oc = (row0 + (FULL || il < nrows ? il : nrows - 1)) * g.C + jc;
+      if (HAS_ADD) ad[e] = g.addend[oc];
+      if (HAS_MASK) zm[e] = g.zmask[oc];
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (HAS_ADD) asm volatile("" : "+v"(ad[e]));
+      if (HAS_MASK) asm volatile("" : "+v"(zm[e]));
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int il = il0 + (e & 3) + 8 * (e >> 2);
+    const bool ok = FULL || (il < nrows && jv);
+    float v = acc[e] + bias;
+    if (HAS_ADD) v += ad[e];
+    float w2 = v;
+    if (HAS_MASK) {
+      v = (fmaf(msc, zm[e], msh) > 0.f) ? v : 0.f;
+      w2 = zm[e];
+    }
+    if (!FULL) v = ok ? v : 0.f;
+    if (HAS_OUT) {
+      if (FULL) g.out[(row0 + il) * g.C + j] = v;
+      else if (ok) g.out[(row0 + il) * g.C + j] = v;
+    }
+    a1 += v;
+    a2 = fmaf(v, w2, a2);
+  }
+}
+
 // ---- the kernel ----------------------------------------------------------------------------------------
 // 256 threads = 4 waves arranged 2 (rows) x 2 (cols); wave tile (BM/2) x (BN/2) = MT x NT MFMA tiles.
-template <int BM, int BN, int NS, int MODE, bool A2, bool B2, int EPI>
+template <int BM, int BN, int NS, int MODE, bool A2, bool B2, int EPI, bool ADD = false, bool MASK = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   constexpr int BK = (NS == 3) ? 32 : 64;
   constexpr int PITCH = Geo<BK>::PITCH;
@@ -358,6 +400,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   }
 
   const int r = lane & 31, h = lane >> 5;
+  const bool full = (nrows == BM) && (col0 + BN <= g.C);   // block-uniform: whole tile valid
   float* red = reinterpret_cast<float*>(lds_raw);  // tiles are dead after the final barrier
 
   if (EPI == EPI_STORE) {
@@ -370,37 +413,15 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
       if (jv && g.cloud_bias) bias = g.cloud_bias[(long long)cloud * g.C + j];
       if (jv && g.zmask) { msc = g.msc[j]; msh = g.msh[j]; }
       float a1 = 0.f, a2 = 0.f;
-      const int jc = jv ? j : (g.C - 1);
 #pragma unroll
       for (int m = 0; m < MT; ++m) {
-        float ad[16], zm[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {      // unconditional, clamped loads first so they are all in flight together
-          const int il = wrow0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          const long long oc = (row0 + (il < nrows ? il : nrows - 1)) * g.C + jc;
-          ad[e] = g.addend ? g.addend[oc] : 0.f;
-          zm[e] = g.zmask ? g.zmask[oc] : 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          asm volatile("" : "+v"(ad[e]));
-          asm volatile("" : "+v"(zm[e]));
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int il = wrow0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (il < nrows && jv) {
-            const long long o = (row0 + il) * g.C + j;
-            float v = acc[m][n][e] + bias + ad[e];
-            float w2 = v;
-            if (g.zmask) {
-              if (!(fmaf(msc, zm[e], msh) > 0.f)) v = 0.f;
-              w2 = zm[e];
-            }
-            if (g.out) g.out[o] = v;
-            a1 += v;
-            a2 = fmaf(v, w2, a2);
-          }
+        const int il0 = wrow0 + m * 32 + 4 * h;
+        if (full) {
+          if (g.out) epi_store_block<true, ADD, MASK, true>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
+          else epi_store_block<true, ADD, MASK, false>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
+        } else {
+          if (g.out) epi_store_block<false, ADD, MASK, true>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
+          else epi_store_block<false, ADD, MASK, false>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
         }
       }
       s1[n] = a1 + __shfl_xor(a1, 32, 64);
@@ -435,23 +456,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
       for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
+        for (int e = 0; e < 16; ++e) {       // branch-free: rows outside the cloud are neutralised with selects
           const int il = wrow0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (il < nrows) {
-            const float v = acc[m][n][e];
-            a1 += v;
-            a2 = fmaf(v, v, a2);
-            const float t = sg * v;
-            const int idx = row_in_cloud0 + il;
-            if (t > best || (t == best && idx < besti)) { best = t; besti = idx; }
-          }
+          const bool ok = full || il < nrows;
+          const float v = ok ? acc[m][n][e] : 0.f;
+          a1 += v;
+          a2 = fmaf(v, v, a2);
+          const float t = ok ? sg * v : -INFINITY;
+          const bool better = t > best;          // rows ascend with (m, e): first maximum wins
+          best = better ? t : best;
+          besti = better ? (row_in_cloud0 + il) : besti;
         }
       s1[n] = a1 + __shfl_xor(a1, 32, 64);
       s2[n] = a2 + __shfl_xor(a2, 32, 64);
       const float ob = __shfl_xor(best, 32, 64);
       const int oi = __shfl_xor(besti, 32, 64);
-      if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }
-      bv[n] = best; bi[n] = besti;
+      const bool take = ob > best || (ob == best && oi < besti);
+      bv[n] = take ? ob : best; bi[n] = take ? oi : besti;
     }
     if (h == 0) {
 #pragma unroll
@@ -481,9 +502,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 }
 
 // ---- host-side dispatch ----------------------------------------------------------------------------------
-template <int BM, int BN, int NS, int MODE, bool A2, bool B2, int EPI>
+template <int BM, int BN, int NS, int MODE, bool A2, bool B2, int EPI, bool ADD = false, bool MASK = false>
 static int launch(const GemmArgs& g, dim3 grid, hipStream_t st) {
-  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS, MODE, A2, B2, EPI>), grid, dim3(256), 0, st, g);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, NS, MODE, A2, B2, EPI, ADD, MASK>), grid, dim3(256), 0, st, g);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -499,7 +520,7 @@ static int check_operand(const pn_operand* o, const char* name) {
   return PN_OK;
 }
 
-template <int MODE, bool A2, int EPI>
+template <int MODE, bool A2, int EPI, bool ADD = false, bool MASK = false>
 static int dispatch_rows(const GemmArgs& g, int prec, hipStream_t st) {
   const bool wide = (g.C % 128 == 0);
   if (EPI == EPI_MAX) {
@@ -509,12 +530,21 @@ static int dispatch_rows(const GemmArgs& g, int prec, hipStream_t st) {
   }
   if (wide) {
     dim3 grid(g.B * g.tiles_per_cloud, g.C / 128);
-    if (prec == PN_PREC_BF16X3) return launch<128, 128, 3, MODE, A2, false, EPI>(g, grid, st);
-    return launch<128, 128, 1, MODE, A2, false, EPI>(g, grid, st);
+    if (prec == PN_PREC_BF16X3) return launch<128, 128, 3, MODE, A2, false, EPI, ADD, MASK>(g, grid, st);
+    return launch<128, 128, 1, MODE, A2, false, EPI, ADD, MASK>(g, grid, st);
   }
   dim3 grid(g.B * g.tiles_per_cloud, cdiv(g.C, 64));
-  if (prec == PN_PREC_BF16X3) return launch<128, 64, 3, MODE, A2, false, EPI>(g, grid, st);
-  return launch<128, 64, 1, MODE, A2, false, EPI>(g, grid, st);
+  if (prec == PN_PREC_BF16X3) return launch<128, 64, 3, MODE, A2, false, EPI, ADD, MASK>(g, grid, st);
+  return launch<128, 64, 1, MODE, A2, false, EPI, ADD, MASK>(g, grid, st);
+}
+
+template <bool A2>
+static int dispatch_bwd(const GemmArgs& g, int prec, hipStream_t st) {
+  const bool ha = g.addend != nullptr, hm = g.zmask != nullptr;
+  if (ha && hm) return dispatch_rows<MODE_BWD, A2, EPI_STORE, true, true>(g, prec, st);
+  if (ha) return dispatch_rows<MODE_BWD, A2, EPI_STORE, true, false>(g, prec, st);
+  if (hm) return dispatch_rows<MODE_BWD, A2, EPI_STORE, false, true>(g, prec, st);
+  return dispatch_rows<MODE_BWD, A2, EPI_STORE, false, false>(g, prec, st);
 }
 
 int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, int K, int C, const float* cloud_bias,
@@ -569,8 +599,8 @@ int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, in
   g.a = *dz; g.w = w; g.w_cloud_stride = wcs; g.B = B; g.N = N; g.K = K; g.C = C;
   g.tiles_per_cloud = cdiv(N, 128);
   g.out = out; g.addend = addend; g.zmask = zmask; g.msc = msc; g.msh = msh; g.stat_partials = stat_partials;
-  if (dz->s2) return dispatch_rows<MODE_BWD, true, EPI_STORE>(g, prec, st);
-  return dispatch_rows<MODE_BWD, false, EPI_STORE>(g, prec, st);
+  if (dz->s2) return dispatch_bwd<true>(g, prec, st);
+  return dispatch_bwd<false>(g, prec, st);
 }
 
 template <int BM, int BN>

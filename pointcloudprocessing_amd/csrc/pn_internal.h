@@ -15,6 +15,11 @@ int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, in
 int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, int Cj, int slab_rows, float* slabs, int prec,
                hipStream_t st);
 
+// pn_panel.hip
+int weights_prep(const float* w, int K, int C, void* hi, void* lo, hipStream_t st);
+int conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C, const float* sgn,
+                       float* pmax, int* pidx, float* stat_partials, int prec, hipStream_t st);
+
 // pn_pointwise.hip
 int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st);
 int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st);

@@ -122,6 +122,8 @@ struct CL {   // per-point conv layer state
 struct ML {   // extra state of a max-pooled layer
   float *sgn, *pmax, *g, *zstar, *hs, *e, *nege, *f, *a1part, *a1, *gram, *GW, *Pm, *q, *D, *Wt, *We, *dG;
   int *pidx, *arg;
+  unsigned short *wb_hi, *wb_lo;   // bf16 channel-major copies of the kernel for the panel kernel
+  int T64, tpc64;
 };
 struct DLs {  // dense layer state (rows = B)
   float *z, *a, *mean, *invstd, *dz, *Wt, *din;
@@ -181,11 +183,15 @@ static void plan_cl(Arena& A, CL& l, const char* nm, long long M, int T, int C, 
     l.dy = store_z ? A.get<float>((n + ".dy").c_str(), (size_t)M * C) : nullptr;
   }
 }
-static void plan_ml(Arena& A, ML& m, const char* nm, int B, long long M, int T, int K, int C, bool training) {
+static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, int T, int K, int C, bool training) {
   std::string n(nm);
+  m.tpc64 = cdiv(N, 64);
+  m.T64 = B * m.tpc64;
   m.sgn = A.get<float>((n + ".sgn").c_str(), C);
-  m.pmax = A.get<float>((n + ".pmax").c_str(), (size_t)T * C);
-  m.pidx = A.get<int>((n + ".pidx").c_str(), (size_t)T * C);
+  m.pmax = A.get<float>((n + ".pmax").c_str(), (size_t)m.T64 * C);
+  m.pidx = A.get<int>((n + ".pidx").c_str(), (size_t)m.T64 * C);
+  m.wb_hi = A.get<unsigned short>((n + ".wb_hi").c_str(), (size_t)K * C);
+  m.wb_lo = A.get<unsigned short>((n + ".wb_lo").c_str(), (size_t)K * C);
   m.g = A.get<float>((n + ".g").c_str(), (size_t)B * C);
   m.zstar = A.get<float>((n + ".zstar").c_str(), (size_t)B * C);
   m.arg = A.get<int>((n + ".arg").c_str(), (size_t)B * C);
@@ -219,12 +225,12 @@ static void plan_dl(Arena& A, DLs& d, const char* nm, int B, int K, int C, bool 
     d.din = A.get<float>((n + ".din").c_str(), (size_t)B * K);
   }
 }
-static void plan_tn(Arena& A, TN& t, const char* nm, int B, long long M, int T, int K, bool training) {
+static void plan_tn(Arena& A, TN& t, const char* nm, int B, int N, long long M, int T, int K, bool training) {
   std::string n(nm);
   plan_cl(A, t.c1, (n + ".c1").c_str(), M, T, 64, true, training);
   plan_cl(A, t.c2, (n + ".c2").c_str(), M, T, 128, true, training);
-  plan_cl(A, t.c3, (n + ".c3").c_str(), M, T, 1024, false, training);
-  plan_ml(A, t.m3, (n + ".m3").c_str(), B, M, T, 128, 1024, training);
+  plan_cl(A, t.c3, (n + ".c3").c_str(), M, B * cdiv(N, 64), 1024, false, training);   // 64-row panel tiles
+  plan_ml(A, t.m3, (n + ".m3").c_str(), B, N, M, T, 128, 1024, training);
   plan_dl(A, t.d1, (n + ".d1").c_str(), B, 1024, 512, training);
   plan_dl(A, t.d2, (n + ".d2").c_str(), B, 512, 256, training);
   t.R = A.get<float>((n + ".R").c_str(), (size_t)B * K * K);
@@ -242,15 +248,15 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
   w.cent = A.get<float>("centroid", (size_t)B * 3);
   w.scl = A.get<float>("scale", B);
   if (!d.vanilla) {
-    plan_tn(A, w.iT, "iT", B, M, T, 3, training);
-    plan_tn(A, w.fT, "fT", B, M, T, 64, training);
+    plan_tn(A, w.iT, "iT", B, N, M, T, 3, training);
+    plan_tn(A, w.fT, "fT", B, N, M, T, 64, training);
   }
   plan_cl(A, w.m11, "m11", M, T, 64, true, training);
   plan_cl(A, w.m12, "m12", M, T, 64, true, training);
   plan_cl(A, w.m21, "m21", M, T, 64, true, training);
   plan_cl(A, w.m22, "m22", M, T, 128, true, training);
-  plan_cl(A, w.m23, "m23", M, T, 1024, false, training);
-  plan_ml(A, w.mm23, "mm23", B, M, T, 128, 1024, training);
+  plan_cl(A, w.m23, "m23", M, B * cdiv(N, 64), 1024, false, training);                // 64-row panel tiles
+  plan_ml(A, w.mm23, "mm23", B, N, M, T, 128, 1024, training);
   plan_cl(A, w.s1, "s1", M, T, 512, true, training);
   plan_cl(A, w.s2, "s2", M, T, 256, true, training);
   plan_cl(A, w.s3, "s3", M, T, 128, true, training);
@@ -332,9 +338,9 @@ struct Run {
   }
 
   // ---------------- forward pieces ----------------
-  int bn_fin(const CL& l, const LRef& r) {
+  int bn_fin(const CL& l, const LRef& r, int n_tiles = -1) {
     const int ub = bn_batch(r.block) ? 1 : 0;
-    return bn_finalize(l.part, T, r.cout, M, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub, ub, l.mean,
+    return bn_finalize(l.part, n_tiles < 0 ? T : n_tiles, r.cout, M, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub, ub, l.mean,
                        l.invstd, l.scale, l.shift, st);
   }
   int fwd_conv(CL& l, const LRef& r, const pn_operand& x, const float* W, long long wcs, const float* cloud_bias) {
@@ -344,12 +350,14 @@ struct Run {
   }
   int fwd_max(CL& l, ML& m, const LRef& r, const pn_operand& x, int prof_slot) {
     m.sgn = p(r.gamma);   // only the sign is used (sgn(gamma) = sgn(BN scale))
+    PN_TRY(weights_prep(p(r.kernel), r.cin, r.cout, m.wb_hi, prec == PN_PREC_BF16X3 ? m.wb_lo : nullptr, st));
     void** ev = io.prof_events;
     if (ev && ev[2 * prof_slot]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot]), st);
-    PN_TRY(conv_fwd_max(&x, p(r.kernel), B, N, r.cin, r.cout, m.sgn, m.pmax, m.pidx, bn_batch(r.block) ? l.part : nullptr, prec, st));
+    PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.sgn, m.pmax, m.pidx, bn_batch(r.block) ? l.part : nullptr,
+                              prec, st));
     if (ev && ev[2 * prof_slot + 1]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot + 1]), st);
-    PN_TRY(bn_fin(l, r));
-    return max_finalize(m.pmax, m.pidx, B, tpc, r.cout, m.sgn, l.scale, l.shift, m.g, m.zstar, m.arg, st);
+    PN_TRY(bn_fin(l, r, m.T64));
+    return max_finalize(m.pmax, m.pidx, B, m.tpc64, r.cout, m.sgn, l.scale, l.shift, m.g, m.zstar, m.arg, st);
   }
   int fwd_dense(DLs& dl, const LRef& r, const float* x, int act, const unsigned char* keep) {
     PN_TRY(dense_partial(x, r.cin, p(r.kernel), B, r.cin, r.cout, w.dense_part, st));

@@ -1,0 +1,96 @@
+"""Training-step executor: forward + fused Keras losses + backward + (RCCL all-reduce) + Adam, replayed from hipGraphs.
+
+A PointNet training step is ~200 short kernels; launched eagerly the host (ctypes + hipLaunchKernel, ~7 us each) is
+the bottleneck.  The native plan never allocates or synchronises, so the whole step is captured once per input shape
+and replayed: graph 1 = dropout masks + forward + losses + backward, then the gradient all-reduce (eager, on the same
+stream), then graph 2 = Adam.  With one GPU both graphs are fused into one.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+from .optim import KerasAdam
+
+
+class TrainStep:
+    def __init__(self, model, optimizer: KerasAdam, batch: int, points: int, loss_weights: Sequence[float], use_graph: bool = True):
+        import torch.distributed as dist
+        self.model, self.opt = model, optimizer
+        self.B, self.N = batch, points
+        self.lw = tuple(float(w) for w in loss_weights)
+        self.dist = dist
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        dev = model.params_flat.device
+        self.dev = dev
+        # static inputs: a graph replays fixed addresses
+        self.pc = torch.zeros(batch, points, 3, device=dev)
+        self.y_cls = torch.zeros(batch, dtype=torch.int32, device=dev)
+        self.y_seg = torch.zeros(batch, points, dtype=torch.int32, device=dev)
+        self.se3 = torch.zeros(batch, 3, 3, device=dev)
+        self.keep = (torch.ones(batch, 512, dtype=torch.uint8, device=dev), torch.ones(batch, 256, dtype=torch.uint8, device=dev))
+        self.mode = "eager"
+        self._g1 = self._g2 = None
+        self._use_graph = use_graph
+        self._calls = 0           # the first two steps run eagerly (they warm up allocator / lazy init), then the step is captured
+
+    # -- pieces ---------------------------------------------------------------------------------------------
+    def _fwd_bwd(self):
+        rate = self.model._dropout_rate
+        if rate > 0:
+            self.keep[0].copy_(torch.rand(self.B, 512, device=self.dev) >= rate)
+            self.keep[1].copy_(torch.rand(self.B, 256, device=self.dev) >= rate)
+        self.model.fused_loss_step(self.pc, self.y_cls, self.y_seg, self.se3, self.lw, keep=self.keep if rate > 0 else None)
+
+    def _eager(self):
+        self._fwd_bwd()
+        if self.world > 1:
+            self.dist.all_reduce(self.model.grads_flat)        # RCCL sum over xGMI
+        self.opt.step(self.model.grads_flat, 1.0 / self.world)
+
+    def _capture(self):
+        try:
+            torch.cuda.synchronize()
+            g1 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._fwd_bwd()
+                if self.world == 1:
+                    self.opt.step(self.model.grads_flat, 1.0)
+            g2 = None
+            if self.world > 1:
+                g2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g2):
+                    self.opt.step(self.model.grads_flat, 1.0 / self.world)
+            torch.cuda.synchronize()
+            self._g1, self._g2, self.mode = g1, g2, "hipgraph"
+        except Exception as e:                                  # capture unsupported: stay eager (a speed matter only)
+            import sys
+            print(f"# hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly", file=sys.stderr)
+            self._g1 = self._g2 = None
+            self.mode = "eager"
+
+    # -- API ------------------------------------------------------------------------------------------------
+    def load(self, pc, y_cls, y_seg, se3):
+        self.pc.copy_(pc, non_blocking=True)
+        self.y_cls.copy_(y_cls, non_blocking=True)
+        self.y_seg.copy_(y_seg.reshape(self.B, self.N), non_blocking=True)
+        self.se3.copy_(se3, non_blocking=True)
+
+    def run(self):
+        """one training step on the currently loaded batch; results in model.scalars / model.grads_flat"""
+        self._calls += 1
+        if self._use_graph and self._g1 is None and self._calls == 3:
+            self._capture()                                     # capture only records; the replay below executes step 3
+            self._use_graph = self._g1 is not None
+        if self._g1 is None:
+            self._eager()
+            return
+        self._g1.replay()
+        if self.world > 1:
+            self.dist.all_reduce(self.model.grads_flat)
+            self._g2.replay()
+
+    def __call__(self, pc, y_cls, y_seg, se3):
+        self.load(pc, y_cls, y_seg, se3)
+        self.run()

@@ -125,6 +125,7 @@ class HipEngine:
         self.n_steps = 0
         self.B = None
         self.N = None
+        self._steps = {}          # (B, N) -> engine.TrainStep (hipGraph replay of the whole step)
 
     def get_layer_trainability(self):
         return self.model.get_layer_trainability()
@@ -140,15 +141,15 @@ class HipEngine:
         self.n_steps = 0
 
     def train_step(self, x, y):
-        x = x.to(self.device).contiguous()
+        from .engine import TrainStep
         self.B, self.N = x.shape[0], x.shape[1]
         yc, ys, yr = self._targets(y)
-        m = self.model
-        m.fused_loss_step(x, yc, ys, yr, self.loss_weights)
-        if self.world > 1:
-            self.dist.all_reduce(m.grads_flat)               # RCCL sum over xGMI: one 16.8 MB message
-        self.opt.step(m.grads_flat, 1.0 / self.world)
-        self.acc += m.scalars
+        key = (self.B, self.N)
+        if key not in self._steps:
+            self._steps[key] = TrainStep(self.model, self.opt, self.B, self.N, self.loss_weights)
+        # forward + fused losses + backward (graph), one RCCL all-reduce of the flat 16.8 MB gradient buffer, Adam (graph)
+        self._steps[key](x.to(self.device), yc, ys, yr)
+        self.acc += self.model.scalars
         self.n_steps += 1
 
     def eval_step(self, x, y):
