@@ -109,7 +109,7 @@ def main():
     from pointcloudprocessing_amd.engine import TrainStep
     ts = TrainStep(model, opt, B, N, lw, use_graph=not args.no_graph)      # hipGraph replay of the whole step
     ts.load(pc, y_cls, y_seg, se3)
-    step, step_eager = ts.run, ts._eager
+    step, step_eager = ts.run, ts.run_eager
     for _ in range(3):
         step()            # two eager steps, then the step is captured into a hipGraph
     graph_mode = ts.mode
@@ -157,7 +157,7 @@ def main():
     kt = [evs[i][2 * j].elapsed_time(evs[i][2 * j + 1]) * 1e-3 for i in range(n_prof) for j in range(3)]
     k_mean = sum(kt) / len(kt)
     flop_per_launch = 2.0 * 128 * 1024 * B * N
-    bytes_per_launch = (128 * 4 + 2 * 4 * 1024 / 128.0 * 0 + 0) * B * N + 128 * 1024 * 4   # x read once + weights; outputs are O(B*1024)
+    bytes_per_launch = 128 * 4 * B * N + 128 * 1024 * 4   # pre-BN input rows read once (fp32) + the bf16 hi/lo kernel; outputs are O(B*1024)
     achieved = flop_per_launch / k_mean
 
     out = {
@@ -176,7 +176,7 @@ def main():
         "config": {"workload": f"PointNet-cls training step (fwd + losses + bwd + grad all-reduce + Adam), N={N} points, "
                                f"batch {B} per GPU, profile {args.profile}, {CCLS} classes / {CSEG} parts, random-init weights",
                    "global_batch": world * B, "points_per_cloud": N, "parallelism": f"dp{world}", "launch": graph_mode},
-        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<128,128,FWD,EPI_MAX> (ConvLayer 128->1024 + BN sums + reduce_max)",
+        "roofline": {"bound": "mfma", "kernel": "panel_max_kernel<NS,128> (ConvLayer 128->1024 + BN sums + reduce_max, 3 launches per step)",
                      "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12 / (3 if args.precision == "bf16x3" else 1),
                      "unit": "TFLOP/s", "frac": achieved / (MFMA_BF16_PEAK / (3 if args.precision == "bf16x3" else 1)),
                      "traffic": None, "launch_us": k_mean * 1e6, "launches_timed": len(kt),

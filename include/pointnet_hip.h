@@ -251,6 +251,10 @@ size_t pn_model_workspace_bytes(const pn_model_desc* d, int B, int N, int traini
 /* byte offset / size of a named intermediate inside the workspace (introspection for tests) */
 int pn_model_ws_lookup(const pn_model_desc* d, int B, int N, int training, const char* name, int64_t* offset, int64_t* bytes);
 
+/* enumerate the workspace directory: returns PN_OK and fills name/offset/bytes, or 1 when index is past the end */
+int pn_model_ws_entry(const pn_model_desc* d, int B, int N, int training, int index, char* name_out, int name_cap,
+                      int64_t* offset, int64_t* bytes);
+
 int pn_model_forward(const pn_model_desc* d, const pn_model_io* io, pn_stream stream);
 /* backward of the last forward on the same workspace.  d_cls / d_seg / d_R are optional upstream gradients w.r.t.
  * the three outputs; when NULL the gradients of the fused loss requested in the forward are used. */

@@ -88,6 +88,7 @@ SIGNATURES = {
     "pn_model_slot_info": (_I, [_DESC, _I, C.POINTER(pn_slot_info)]),
     "pn_model_workspace_bytes": (C.c_size_t, [_DESC, _I, _I, _I]),
     "pn_model_ws_lookup": (_I, [_DESC, _I, _I, _I, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pn_model_ws_entry": (_I, [_DESC, _I, _I, _I, _I, C.c_char_p, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pn_model_forward": (_I, [_DESC, _IO, _P]),
     "pn_model_backward": (_I, [_DESC, _IO, _P, _P, _P, _P]),
     "pn_adam_step": (_I, [_P, _P, _P, _P, _I64, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P]),

@@ -70,7 +70,7 @@ int pn_bn_bwd_finalize(const float* part, int n_tiles, int C, int64_t count, con
 int pn_sign(const float* gamma, int C, float* sgn, pn_stream stream) { return sign_of(gamma, C, sgn, S(stream)); }
 int pn_max_finalize(const float* pmax, const int32_t* pidx, int B, int tpc, int C, const float* sgn, const float* scale,
                     const float* shift, float* g, float* zstar, int32_t* arg, pn_stream stream) {
-  return max_finalize(pmax, pidx, B, tpc, C, sgn, scale, shift, g, zstar, arg, S(stream));
+  return max_finalize(pmax, pidx, B, tpc, C, 0x7fffffff, sgn, scale, shift, g, zstar, arg, S(stream));
 }
 size_t pn_fps_workspace_bytes(int B, int N) { return fps_workspace_bytes(B, N); }
 int pn_fps(const float* xyz, int B, int N, int M, int start_idx, int32_t* idx_out, float* mindist, void* ws, size_t ws_bytes,

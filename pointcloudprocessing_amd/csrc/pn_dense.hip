@@ -8,7 +8,8 @@ namespace pn {
 
 constexpr int DENSE_KS = 32;   // k staged per LDS step
 constexpr int DENSE_RC = 32;   // rows per register chunk
-constexpr int DENSE_MAX_SPLITS = 16;
+constexpr int DENSE_MAX_SPLITS = 32;
+constexpr int DENSE_TB = 128;        // columns (threads) per block of the partial kernel
 
 // k per split: a multiple of DENSE_KS, at most DENSE_MAX_SPLITS splits
 static inline int dense_split_len(int K) {
@@ -17,10 +18,10 @@ static inline int dense_split_len(int K) {
 }
 
 // partial[ks][r][j] = sum_{k in split ks} x[r][k] * w[k][j]        x: (R, K) ld = ldx ; w: (K, C)
-__global__ __launch_bounds__(256) void dense_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+__global__ __launch_bounds__(DENSE_TB) void dense_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
                                                             int R, int K, int C, int split_len, float* __restrict__ partial) {
   __shared__ float xs[DENSE_KS][DENSE_RC];   // [k][r]: a row chunk's value for one k is read as a broadcast
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = blockIdx.x * DENSE_TB + threadIdx.x;
   const int jc = j < C ? j : C - 1;          // clamped: weight loads are unconditional (no load under a lane-dependent branch)
   const int ks = blockIdx.y;
   const int kbeg = ks * split_len, kend = min(K, kbeg + split_len);
@@ -36,7 +37,7 @@ __global__ __launch_bounds__(256) void dense_partial_kernel(const float* __restr
 #pragma unroll
       for (int k = 0; k < DENSE_KS; ++k) wv[k] = w[(long long)(k0 + (k < nk ? k : nk - 1)) * C + jc];
       __syncthreads();
-      for (int t = threadIdx.x; t < DENSE_RC * DENSE_KS; t += 256) {
+      for (int t = threadIdx.x; t < DENSE_RC * DENSE_KS; t += DENSE_TB) {
         const int r = t / DENSE_KS, k = t % DENSE_KS;
         xs[k][r] = (r < nr && k < nk) ? x[(long long)(rc + r) * ldx + k0 + k] : 0.f;
       }
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
 int dense_partial(const float* x, int ldx, const float* w, int R, int K, int C, float* partial, hipStream_t st) {
   PN_CHECK_ARG(x && w && partial && R > 0 && K > 0 && C > 0, "dense_partial: bad arguments");
   const int len = dense_split_len(K);
-  hipLaunchKernelGGL(dense_partial_kernel, dim3(cdiv(C, 256), cdiv(K, len)), dim3(256), 0, st, x, ldx, w, R, K, C, len, partial);
+  hipLaunchKernelGGL(dense_partial_kernel, dim3(cdiv(C, DENSE_TB), cdiv(K, len)), dim3(DENSE_TB), 0, st, x, ldx, w, R, K, C, len, partial);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -32,7 +32,7 @@ int bn_bwd_finalize(const float* part, int n_tiles, int C, long long count, cons
                     const float* invstd, int batch_stats, float* dgamma, float* dbeta, float* ca, float* cb, float* cc,
                     hipStream_t st);
 int sign_of(const float* gamma, int C, float* sgn, hipStream_t st);
-int max_finalize(const float* pmax, const int* pidx, int B, int tpc, int C, const float* sgn, const float* scale,
+int max_finalize(const float* pmax, const int* pidx, int B, int tpc, int C, int n_rows, const float* sgn, const float* scale,
                  const float* shift, float* g, float* zstar, int* arg, hipStream_t st);
 
 // pn_dense.hip
@@ -89,6 +89,7 @@ int fold3_fwd(const float* R, const float* W, int B, int C, float* Weff, hipStre
 int fold3_bwd(const float* dWeff, const float* R, const float* W, int B, int C, float* dR, float* dW, hipStream_t st);
 int fill_eye3(float* out, int B, hipStream_t st);
 int axpy(const float* x, float a, float* y, long long n, hipStream_t st);
+int zero_fill(float* p, long long n, hipStream_t st);
 int cloud_bias_grad(const float* bwd_part, const float* fwd_part, int B, int tpc, int N, int C, const float* ca, const float* cb,
                     const float* cc, float* dgb, hipStream_t st);
 

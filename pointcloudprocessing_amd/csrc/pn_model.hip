@@ -13,6 +13,8 @@
 //     per-cloud-weight contraction on the MFMA engine;
 //   * tile+concat in front of seg_l1 is never formed: seg_l1's kernel is split into its 64 per-point rows and
 //     its 1024 global rows, the latter applied once per cloud and added as a per-cloud bias.
+#include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 #include "pn_internal.h"
@@ -103,10 +105,15 @@ static Layout make_layout(const pn_model_desc& d) {
 struct Arena {
   char* base = nullptr;
   size_t off = 0;
+  size_t guard = ws_guard_bytes();   // debug: PN_WS_GUARD=<bytes> leaves an untouched gap after every entry (tools/ws_guard.py)
   std::vector<std::pair<std::string, std::pair<size_t, size_t>>>* dir = nullptr;
+  static size_t ws_guard_bytes() {
+    const char* e = getenv("PN_WS_GUARD");
+    return e ? ((size_t)atoll(e) + 255) & ~(size_t)255 : 0;
+  }
   template <class T>
   T* get(const char* name, size_t count) {
-    const size_t bytes = (count * sizeof(T) + 255) & ~(size_t)255;
+    const size_t bytes = ((count * sizeof(T) + 255) & ~(size_t)255) + guard;
     const size_t o = off;
     off += bytes;
     if (dir) dir->push_back({name, {o, count * sizeof(T)}});
@@ -357,7 +364,7 @@ struct Run {
                               prec, st));
     if (ev && ev[2 * prof_slot + 1]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot + 1]), st);
     PN_TRY(bn_fin(l, r, m.T64));
-    return max_finalize(m.pmax, m.pidx, B, m.tpc64, r.cout, m.sgn, l.scale, l.shift, m.g, m.zstar, m.arg, st);
+    return max_finalize(m.pmax, m.pidx, B, m.tpc64, r.cout, N, m.sgn, l.scale, l.shift, m.g, m.zstar, m.arg, st);
   }
   int fwd_dense(DLs& dl, const LRef& r, const float* x, int act, const unsigned char* keep) {
     PN_TRY(dense_partial(x, r.cin, p(r.kernel), B, r.cin, r.cout, w.dense_part, st));
@@ -564,10 +571,7 @@ struct Run {
       set_error("pn_model_backward: grads buffer is NULL");
       return PN_ERR_INVALID_ARGUMENT;
     }
-    if (hipMemsetAsync(G, 0, (size_t)L.total * sizeof(float), st) != hipSuccess) {
-      set_error("pn_model_backward: memset failed");
-      return PN_ERR_LAUNCH;
-    }
+    PN_TRY(zero_fill(G, L.total, st));
     const pn_operand x64 = x64op();
     const float* Ws1 = p(L.s1.kernel);
     const bool fused = io.labels_cls != nullptr || io.labels_seg != nullptr;
@@ -615,7 +619,7 @@ struct Run {
       have_dGcls = true;
     }
     float* dG = w.mm23.dG;
-    if (hipMemsetAsync(dG, 0, (size_t)B * 1024 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return PN_ERR_LAUNCH; }
+    PN_TRY(zero_fill(dG, (long long)B * 1024, st));
     if (have_dGcls) PN_TRY(axpy(w.dGcls, 1.f, dG, (long long)B * 1024, st));
     if (have_dGseg) PN_TRY(axpy(w.dGseg, 1.f, dG, (long long)B * 1024, st));
 
@@ -640,7 +644,7 @@ struct Run {
     }
     if (!d.vanilla) {
       // ---- feature transform: X_64 = A_12 . R_64 ----
-      if (hipMemsetAsync(w.fT.dR, 0, (size_t)B * 4096 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return PN_ERR_LAUNCH; }
+      PN_TRY(zero_fill(w.fT.dR, (long long)B * 4096, st));
       const pn_operand a12 = lazy(w.m12);
       const bool have_dx = has_seg || has_cls;
       if (have_dx) {
@@ -664,7 +668,7 @@ struct Run {
       return PN_OK;
     }
     PN_TRY(slab_reduce(w.slabs, T, tpc, 3 * 64, w.dWeff1, st));
-    if (hipMemsetAsync(w.iT.dR, 0, (size_t)B * 9 * sizeof(float), st) != hipSuccess) { set_error("memset failed"); return PN_ERR_LAUNCH; }
+    PN_TRY(zero_fill(w.iT.dR, (long long)B * 9, st));
     PN_TRY(fold3_bwd(w.dWeff1, w.iT.R, p(L.m11.kernel), B, 64, w.iT.dR, tr(BLK_M11) ? gr(L.m11.kernel) : nullptr, st));
     // ---- input transform ----
     if (d_R) PN_TRY(axpy(d_R, 1.f, w.iT.dR, (long long)B * 9, st));
@@ -754,6 +758,22 @@ int pn_model_ws_lookup(const pn_model_desc* d, int B, int N, int training, const
     }
   set_error("pn_model_ws_lookup: no workspace buffer named '%s'", name);
   return PN_ERR_INVALID_ARGUMENT;
+}
+int pn_model_ws_entry(const pn_model_desc* d, int B, int N, int training, int index, char* name_out, int name_cap, int64_t* offset,
+                      int64_t* bytes) {
+  PN_TRY(check_desc(d));
+  PN_CHECK_ARG(name_out && name_cap > 0 && offset && bytes && B > 0 && N > 0, "pn_model_ws_entry: bad arguments");
+  Arena A;
+  WS w;
+  std::vector<std::pair<std::string, std::pair<size_t, size_t>>> dir;
+  A.dir = &dir;
+  plan_ws(A, w, *d, B, N, training != 0);
+  if (index < 0 || index >= (int)dir.size()) return 1;   // past the end
+  strncpy(name_out, dir[index].first.c_str(), name_cap - 1);
+  name_out[name_cap - 1] = 0;
+  *offset = (int64_t)dir[index].second.first;
+  *bytes = (int64_t)dir[index].second.second;
+  return PN_OK;
 }
 int pn_model_forward(const pn_model_desc* d, const pn_model_io* io, pn_stream stream) {
   Run* r = nullptr;

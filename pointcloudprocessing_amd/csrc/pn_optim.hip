@@ -195,6 +195,26 @@ int fold3_bwd(const float* dWeff, const float* R, const float* W, int B, int C, 
   }
   return PN_OK;
 }
+// Zero fill as an ordinary kernel.  hipMemsetAsync is avoided on purpose: captured into a hipGraph (ROCm 7.2) the
+// 16 MiB memset node of the gradient buffer replayed with a garbage fill pattern once another model had launched
+// work between two replays (tools/graph_hunt.py); a kernel node has no such state.
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, long long n) {
+  const long long n4 = n >> 2;
+  float4* p4 = reinterpret_cast<float4*>(p);
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = 0.f;
+}
+
+int zero_fill(float* p, long long n, hipStream_t st) {
+  PN_CHECK_ARG(p && n >= 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0, "zero_fill: null or unaligned buffer");
+  if (n == 0) return PN_OK;
+  const long long blocks = cdivll(cdivll(n, 4), 256);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, p, n);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
 int axpy(const float* x, float a, float* y, long long n, hipStream_t st) {
   hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, st, x, a, y, n);
   PN_CHECK_LAUNCH();

@@ -329,7 +329,7 @@ int sign_of(const float* gamma, int C, float* sgn, hipStream_t st) {
 // finish tf.reduce_max (PointNet.py:248, 429)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void max_finalize_kernel(const float* __restrict__ pmax, const int* __restrict__ pidx,
-                                                           int tiles_per_cloud, int C, const float* __restrict__ sgn,
+                                                           int tiles_per_cloud, int C, int n_rows, const float* __restrict__ sgn,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            float* __restrict__ g, float* __restrict__ zstar,
                                                            int* __restrict__ arg) {
@@ -347,14 +347,14 @@ __global__ __launch_bounds__(256) void max_finalize_kernel(const float* __restri
   const long long o = (long long)b * C + c;
   g[o] = fmaxf(fmaf(scale[c], zs, shift[c]), 0.f);
   if (zstar) zstar[o] = zs;
-  if (arg) arg[o] = bi;
+  if (arg) arg[o] = (bi >= 0 && bi < n_rows) ? bi : 0;   // NaN inputs leave no winner: keep the index in range
 }
 
-int max_finalize(const float* pmax, const int* pidx, int B, int tpc, int C, const float* sgn, const float* scale,
+int max_finalize(const float* pmax, const int* pidx, int B, int tpc, int C, int n_rows, const float* sgn, const float* scale,
                  const float* shift, float* g, float* zstar, int* arg, hipStream_t st) {
   PN_CHECK_ARG(pmax && pidx && sgn && scale && shift && g, "pn_max_finalize: null pointer");
   PN_CHECK_ARG(B > 0 && tpc > 0 && C > 0, "pn_max_finalize: bad sizes");
-  hipLaunchKernelGGL(max_finalize_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, st, pmax, pidx, tpc, C, sgn, scale, shift, g,
+  hipLaunchKernelGGL(max_finalize_kernel, dim3(cdiv(C, 256), B), dim3(256), 0, st, pmax, pidx, tpc, C, n_rows, sgn, scale, shift, g,
                      zstar, arg);
   PN_CHECK_LAUNCH();
   return PN_OK;

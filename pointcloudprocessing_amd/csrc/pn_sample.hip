@@ -7,6 +7,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 
 namespace pn {
+int zero_fill(float* p, long long n, hipStream_t st);   // pn_optim.hip
 
 // ------------------------------------------------------------------------------------------------------
 // FPS.  M sequential rounds, each a full argmax over the cloud: latency bound, not bandwidth bound.  A
@@ -141,10 +142,7 @@ int fps(const float* xyz, int B, int N, int M, int start_idx, int* idx_out, floa
   PN_CHECK_ARG(ws && ws_bytes >= fps_workspace_bytes(B, N), "pn_fps: workspace too small");
   int* err = reinterpret_cast<int*>(ws);
   unsigned long long* xchg = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(ws) + 16);
-  if (hipMemsetAsync(ws, 0, fps_workspace_bytes(B, N), st) != hipSuccess) {
-    set_error("pn_fps: hipMemsetAsync failed");
-    return PN_ERR_LAUNCH;
-  }
+  PN_TRY(zero_fill(reinterpret_cast<float*>(ws), (long long)(fps_workspace_bytes(B, N) / 4), st));
   // blocks of one cloud must be co-resident (they wait for each other): at most 128 blocks per launch
   const int clouds_per_launch = bpc > 1 ? (128 / bpc > 0 ? 128 / bpc : 1) : B;
   for (int b0 = 0; b0 < B; b0 += clouds_per_launch) {
@@ -284,7 +282,7 @@ int voxel_downsample(const float* xyz, const int* labels, int N, const float* le
   int* iin = reinterpret_cast<int*>(w + L.idx_in);
   int* iout = reinterpret_cast<int*>(w + L.idx_out);
   int* seg = reinterpret_cast<int*>(w + L.seg);
-  if (hipMemsetAsync(err, 0, 4, st) != hipSuccess) { set_error("pn_voxel_downsample: memset failed"); return PN_ERR_LAUNCH; }
+  PN_TRY(zero_fill(reinterpret_cast<float*>(err), 1, st));
   hipLaunchKernelGGL(voxel_keys_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, xyz, N, leaf[0], leaf[1], leaf[2], origin[0],
                      origin[1], origin[2], kin, iin, err);
   PN_CHECK_LAUNCH();

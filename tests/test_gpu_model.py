@@ -304,3 +304,103 @@ def test_no_cpu_fallback(dev):
     m = PointNet(CCLS, CSEG, 0.3, 42, device="cpu")
     with pytest.raises(PointNetHipError):
         m(torch.zeros(1, 64, 3), training=False)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# memory safety without a GPU sanitizer: guard bands around every workspace entry and every boundary buffer
+# ---------------------------------------------------------------------------------------------------------------------
+GUARD_PAT = 0xA5
+
+
+def _ws_entries(m, B, N, training):
+    import ctypes as C
+    from pointcloudprocessing_amd._lib import lib
+    name = C.create_string_buffer(128); off = C.c_int64(); nb = C.c_int64()
+    out, i = [], 0
+    while lib().pn_model_ws_entry(C.byref(m._desc), B, N, int(training), i, name, 128, C.byref(off), C.byref(nb)) == 0:
+        out.append((name.value.decode(), off.value, nb.value)); i += 1
+    return out
+
+
+@pytest.mark.parametrize("vanilla", [False, True])
+@pytest.mark.parametrize("B,N", [(3, 100), (16, 136), (5, 2048)])
+def test_workspace_entries_are_never_overrun(dev, monkeypatch, vanilla, B, N):
+    """PN_WS_GUARD plans the workspace with an untouched gap after every entry; after a training step and an inference
+    call every gap byte must still hold the fill pattern (ragged shapes: partial tiles, odd batch)."""
+    monkeypatch.setenv("PN_WS_GUARD", "32768")
+    from pointcloudprocessing_amd.pointnet.PointNet import PointNet
+    m = PointNet(23, 12, 0.3, 42, vanilla=vanilla, precision="bf16", device=dev)
+    g = torch.Generator().manual_seed(B * N)
+    pc = (torch.rand(B, N, 3, generator=g) * 10).to(dev)
+    y_cls = torch.randint(0, 23, (B,), generator=g, dtype=torch.int32).to(dev)
+    y_seg = torch.randint(0, 12, (B, N), generator=g, dtype=torch.int32).to(dev)
+    se3 = torch.eye(3).expand(B, 3, 3).contiguous().to(dev)
+    keep = (torch.ones(B, 512, dtype=torch.uint8, device=dev), torch.ones(B, 256, dtype=torch.uint8, device=dev))
+    for training in (True, False):
+        m._workspace(B, N, training).fill_(GUARD_PAT)
+    m.fused_loss_step(pc, y_cls, y_seg, se3, (1.0, 1.0, 1.0), keep=keep)
+    m(pc, training=False)
+    torch.cuda.synchronize()
+    for training in (True, False):
+        ws = m._workspace(B, N, training)
+        ent = _ws_entries(m, B, N, training)
+        assert len(ent) > 50
+        for i, (n, o, nb) in enumerate(ent):
+            end = ent[i + 1][1] if i + 1 < len(ent) else ws.numel()
+            assert end - (o + nb) >= 32768
+            assert bool((ws[o + nb: end] == GUARD_PAT).all()), f"guard after workspace entry {n} was overwritten (training={training})"
+
+
+@pytest.mark.parametrize("vanilla", [False, True])
+def test_boundary_buffers_are_never_overrun(dev, vanilla):
+    """every buffer handed over the C ABI (inputs, labels, masks, parameters, gradients, Adam state, scalars, outputs) is
+    carved from one patterned arena: forward + backward + Adam may not touch a gap byte or modify a read-only input."""
+    import ctypes as C
+    from pointcloudprocessing_amd._lib import check, current_stream, lib
+    from pointcloudprocessing_amd.pointnet.PointNet import PointNet
+    B, N, GAP = 5, 200, 8192
+    m = PointNet(23, 12, 0.3, 42, vanilla=vanilla, precision="bf16", device=dev)
+    P = m.params_flat.numel()
+    arena = torch.full((16 * 2**20 + 4 * P * 4,), GUARD_PAT, dtype=torch.uint8, device=dev)
+    cur, carved = [GAP], {}
+
+    def carve(name, src=None, nbytes=None):
+        nb = src.numel() * src.element_size() if src is not None else nbytes
+        o = cur[0]
+        t = arena[o:o + nb]
+        if src is not None:
+            t.copy_(src.contiguous().view(torch.uint8).reshape(-1))
+        carved[name] = (o, nb)
+        cur[0] = (o + nb + GAP + 255) & ~255
+        return t
+
+    g = torch.Generator().manual_seed(5)
+    ins = dict(pc=torch.rand(B, N, 3, generator=g) * 10, y_cls=torch.randint(0, 23, (B,), generator=g, dtype=torch.int32),
+               y_seg=torch.randint(0, 12, (B, N), generator=g, dtype=torch.int32), se3=torch.eye(3).expand(B, 3, 3).contiguous(),
+               keep1=(torch.rand(B, 512, generator=g) > 0.3).to(torch.uint8), keep2=(torch.rand(B, 256, generator=g) > 0.3).to(torch.uint8))
+    tin = {k: carve(k, v.to(dev)) for k, v in ins.items()}
+    t_params = carve("params", m.params_flat.data)
+    t_grads = carve("grads", nbytes=P * 4)
+    t_m, t_v = carve("adam_m", torch.zeros(P)), carve("adam_v", torch.zeros(P))
+    t_it, t_al = carve("iterations", torch.zeros(1, dtype=torch.int32)), carve("alpha", torch.zeros(2))
+    t_sc = carve("scalars", torch.zeros(16))
+    t_cls, t_seg, t_R = carve("out_cls", nbytes=B * 23 * 4), carve("out_seg", nbytes=B * N * 12 * 4), carve("out_R", nbytes=B * 9 * 4)
+    snap = {k: tin[k].clone() for k in tin}
+    fused = dict(labels_cls=tin["y_cls"].view(torch.int32), labels_seg=tin["y_seg"].view(torch.int32), se3=tin["se3"].view(torch.float32),
+                 loss_weights=(1.0, 1.0, 1.0), keep=(tin["keep1"], tin["keep2"]))
+    io, _ = m._io(tin["pc"].view(torch.float32).view(B, N, 3), True, fused)
+    io.params, io.grads, io.scalars = t_params.data_ptr(), t_grads.data_ptr(), t_sc.data_ptr()
+    io.out_cls, io.out_seg, io.out_R = t_cls.data_ptr(), t_seg.data_ptr(), t_R.data_ptr()
+    for _ in range(2):
+        check(lib().pn_model_forward(C.byref(m._desc), C.byref(io), current_stream()), "pn_model_forward")
+        check(lib().pn_model_backward(C.byref(m._desc), C.byref(io), None, None, None, current_stream()), "pn_model_backward")
+        check(lib().pn_adam_step(t_params.data_ptr(), t_grads.data_ptr(), t_m.data_ptr(), t_v.data_ptr(), P, t_it.data_ptr(),
+                                 t_al.data_ptr(), 1e-3, 0.7, 7000.0, 0.9, 0.999, 1e-7, 1.0, current_stream()), "pn_adam_step")
+    torch.cuda.synchronize()
+    mask = torch.ones_like(arena, dtype=torch.bool)
+    for k, (o, nb) in carved.items():
+        mask[o:o + nb] = False
+    assert int(((arena != GUARD_PAT) & mask).sum()) == 0
+    for k in tin:
+        assert torch.equal(tin[k], snap[k]), f"read-only input {k} was modified"
+    assert bool(torch.isfinite(t_grads.view(torch.float32)).all()) and int(t_it.view(torch.int32)[0]) == 2

@@ -40,9 +40,13 @@ def test_native_train_step_learns_and_graph_matches_eager(dev):
     y_cls = torch.randint(0, 23, (B,), generator=g, dtype=torch.int32).to(dev)
     y_seg = torch.randint(0, 12, (B, N), generator=g, dtype=torch.int32).to(dev)
     se3 = torch.eye(3).expand(B, 3, 3).contiguous().to(dev)
-    finals = []
+    finals, w0 = [], None
     for use_graph in (False, True):
         m = PointNet(23, 12, 0.0, 42, precision="bf16x3", device=dev)     # dropout 0: deterministic step
+        if w0 is None:
+            w0 = m.params_flat.data.clone()
+        else:
+            m.params_flat.data.copy_(w0)       # the classification head is unseeded (PointNet.py:186-206): share the start
         opt = KerasAdam(m.params_flat.data, 1e-3, 7000, 0.7)
         ts = TrainStep(m, opt, B, N, (1.0, 1.0, 1.0), use_graph=use_graph)
         losses = []
@@ -54,3 +58,37 @@ def test_native_train_step_learns_and_graph_matches_eager(dev):
         assert int(opt.iterations) == 62
         assert ts.mode == ("hipgraph" if use_graph else "eager")
     assert torch.equal(finals[0], finals[1])
+
+
+def test_interleaved_models_graph_replay_is_exact(dev):
+    """regression: a graph-replayed model must stay bit-identical to its eagerly stepped twin while an unrelated model
+    (different weights) trains in the same process between the replays, and the gradient slots nobody writes (moving
+    statistics) must stay exactly zero.  (A captured hipMemsetAsync node used to replay with a garbage pattern here.)"""
+    from pointcloudprocessing_amd.engine import TrainStep
+    from pointcloudprocessing_amd.optim import KerasAdam
+    from pointcloudprocessing_amd.pointnet.PointNet import PointNet
+    B, N = 8, 256
+    g = torch.Generator().manual_seed(1)
+    pc = (torch.rand(B, N, 3, generator=g) * 10).to(dev)
+    y_cls = torch.randint(0, 23, (B,), generator=g, dtype=torch.int32).to(dev)
+    y_seg = torch.randint(0, 12, (B, N), generator=g, dtype=torch.int32).to(dev)
+    se3 = torch.eye(3).expand(B, 3, 3).contiguous().to(dev)
+    arms = []
+    for tag, use_graph in (("other", False), ("eager", False), ("graph", True), ("other2", True)):
+        m = PointNet(23, 12, 0.0, 42, precision="bf16x3", device=dev)
+        if tag == "graph":
+            m.params_flat.data.copy_(arms[1][0].params_flat.data)
+        opt = KerasAdam(m.params_flat.data, 1e-3, 7000, 0.7)
+        arms.append((m, opt, TrainStep(m, opt, B, N, (1.0, 1.0, 1.0), use_graph=use_graph)))
+    moving = [s for n, s in arms[0][0]._weights.slots.items() if n.endswith("moving_mean") or n.endswith("moving_var")]
+    for step in range(10):
+        for m, opt, ts in arms:
+            ts(pc, y_cls, y_seg, se3)
+        torch.cuda.synchronize()
+        for m, opt, ts in arms:
+            assert bool(torch.isfinite(m.grads_flat).all()), (step, ts.mode)
+            for s in moving:
+                assert not bool(m.grads_flat[s["offset"]: s["offset"] + s["rows"] * s["cols"]].any()), (step, ts.mode)
+        assert torch.equal(arms[1][0].grads_flat, arms[2][0].grads_flat), step
+        assert torch.equal(arms[1][0].params_flat.data, arms[2][0].params_flat.data), step
+    assert arms[2][2].mode == "hipgraph" and arms[3][2].mode == "hipgraph"
