@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--profile", default="classification_pretrain", choices=["classification_pretrain", "final", "all"])
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--caller-stream", action="store_true", help="A/B: run the step on torch's current (null) stream instead of its own")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -107,9 +108,11 @@ def main():
     opt = KerasAdam(model.params_flat.data, 1e-4, 7000, 0.7)
     pc, y_cls, y_seg, se3 = synth_batch(B, N, 20260001 + rank, dev)
     from pointcloudprocessing_amd.engine import TrainStep
-    ts = TrainStep(model, opt, B, N, lw, use_graph=not args.no_graph)      # hipGraph replay of the whole step
+    ts = TrainStep(model, opt, B, N, lw, use_graph=not args.no_graph,
+                   stream=torch.cuda.current_stream() if args.caller_stream else None)      # hipGraph replay of the whole step
     ts.load(pc, y_cls, y_seg, se3)
     step, step_eager = ts.run, ts.run_eager
+    torch.cuda.set_stream(ts.stream)     # the loop lives on the step's stream: no cross-stream fences (engine.TrainStep)
     for _ in range(3):
         step()            # two eager steps, then the step is captured into a hipGraph
     graph_mode = ts.mode

@@ -28,6 +28,7 @@ with a log line.
 from __future__ import annotations
 
 import datetime
+import contextlib
 import json
 import logging
 import math
@@ -126,6 +127,10 @@ class HipEngine:
         self.B = None
         self.N = None
         self._steps = {}          # (B, N) -> engine.TrainStep (hipGraph replay of the whole step)
+        self.stream = torch.cuda.Stream(device=self.device)   # every launch of this engine; see engine.TrainStep
+
+    def stream_context(self):
+        return self.torch.cuda.stream(self.stream)
 
     def get_layer_trainability(self):
         return self.model.get_layer_trainability()
@@ -146,7 +151,7 @@ class HipEngine:
         yc, ys, yr = self._targets(y)
         key = (self.B, self.N)
         if key not in self._steps:
-            self._steps[key] = TrainStep(self.model, self.opt, self.B, self.N, self.loss_weights)
+            self._steps[key] = TrainStep(self.model, self.opt, self.B, self.N, self.loss_weights, stream=self.stream)
         # forward + fused losses + backward (graph), one RCCL all-reduce of the flat 16.8 MB gradient buffer, Adam (graph)
         self._steps[key](x.to(self.device), yc, ys, yr)
         self.acc += self.model.scalars
@@ -347,38 +352,40 @@ class TrainProfile:
                 steps, vsteps = min(steps, self._max_steps), min(vsteps, self._max_steps)
             steps, vsteps = max(steps, 1), max(vsteps, 1)
 
-            for epoch in range(self._epochs):
-                engine.reset_metrics()
-                for _ in range(steps):
-                    x, y = next(train_it)
-                    engine.train_step(x, y)
-                logs = engine.metrics()
-                engine.sync_moving_statistics()
-                engine.reset_metrics()
-                for _ in range(vsteps):
-                    x, y = next(val_it)
-                    engine.eval_step(x, y)
-                logs.update({"val_" + k: v for k, v in engine.metrics().items()})
-                for k in history:
-                    history[k].append(logs[k])
-                self._log.info(f"Epoch {epoch + 1}/{self._epochs} - " + " - ".join(f"{k}: {logs[k]:.4f}" for k in history))
+            # the whole loop (data pipeline, steps, metric reads) runs on the engine's stream: no per-step cross-stream fences
+            with getattr(engine, 'stream_context', contextlib.nullcontext)():
+                for epoch in range(self._epochs):
+                    engine.reset_metrics()
+                    for _ in range(steps):
+                        x, y = next(train_it)
+                        engine.train_step(x, y)
+                    logs = engine.metrics()
+                    engine.sync_moving_statistics()
+                    engine.reset_metrics()
+                    for _ in range(vsteps):
+                        x, y = next(val_it)
+                        engine.eval_step(x, y)
+                    logs.update({"val_" + k: v for k, v in engine.metrics().items()})
+                    for k in history:
+                        history[k].append(logs[k])
+                    self._log.info(f"Epoch {epoch + 1}/{self._epochs} - " + " - ".join(f"{k}: {logs[k]:.4f}" for k in history))
 
-                cur = logs.get(monitor, logs["val_loss"])
-                if cur < best:                      # ModelCheckpoint(save_best_only) + EarlyStopping bookkeeping, mode='min'
-                    self._log.info(f"Epoch {epoch + 1}: {monitor} improved from {best:.5f} to {cur:.5f}, saving model to {ckpt_path}")
-                    best, wait = cur, 0
-                    best_weights = engine.get_weights()
-                    engine.save(ckpt_path)
-                else:
-                    wait += 1
-                    if wait >= self._patience:
-                        self._log.info(f"Epoch {epoch + 1}: early stopping")
+                    cur = logs.get(monitor, logs["val_loss"])
+                    if cur < best:                      # ModelCheckpoint(save_best_only) + EarlyStopping bookkeeping, mode='min'
+                        self._log.info(f"Epoch {epoch + 1}: {monitor} improved from {best:.5f} to {cur:.5f}, saving model to {ckpt_path}")
+                        best, wait = cur, 0
+                        best_weights = engine.get_weights()
+                        engine.save(ckpt_path)
+                    else:
+                        wait += 1
+                        if wait >= self._patience:
+                            self._log.info(f"Epoch {epoch + 1}: early stopping")
+                            break
+                    keyboard_interrupt.on_epoch_end(epoch, logs)
+                    if keyboard_interrupt.stop_training:
                         break
-                keyboard_interrupt.on_epoch_end(epoch, logs)
-                if keyboard_interrupt.stop_training:
-                    break
-            if best_weights is not None:
-                engine.set_weights(best_weights)    # EarlyStopping(restore_best_weights=True)
+                if best_weights is not None:
+                    engine.set_weights(best_weights)    # EarlyStopping(restore_best_weights=True)
 
             if self._rank == 0:
                 with open(f"{self._model_path}{pd['path']}{self._name}_{prof}_history.json", 'w') as j:
