@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--profile", default="classification_pretrain", choices=["classification_pretrain", "final", "all"])
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--aux", action="store_true", help="A/B: parameter-gradient kernels on a second stream")
     ap.add_argument("--caller-stream", action="store_true", help="A/B: run the step on torch's current (null) stream instead of its own")
     args = ap.parse_args()
 
@@ -109,7 +110,7 @@ def main():
     pc, y_cls, y_seg, se3 = synth_batch(B, N, 20260001 + rank, dev)
     from pointcloudprocessing_amd.engine import TrainStep
     ts = TrainStep(model, opt, B, N, lw, use_graph=not args.no_graph,
-                   stream=torch.cuda.current_stream() if args.caller_stream else None)      # hipGraph replay of the whole step
+                   stream=torch.cuda.current_stream() if args.caller_stream else None, aux=args.aux)      # hipGraph replay of the whole step
     ts.load(pc, y_cls, y_seg, se3)
     step, step_eager = ts.run, ts.run_eager
     torch.cuda.set_stream(ts.stream)     # the loop lives on the step's stream: no cross-stream fences (engine.TrainStep)
@@ -160,7 +161,13 @@ def main():
     kt = [evs[i][2 * j].elapsed_time(evs[i][2 * j + 1]) * 1e-3 for i in range(n_prof) for j in range(3)]
     k_mean = sum(kt) / len(kt)
     flop_per_launch = 2.0 * 128 * 1024 * B * N
-    bytes_per_launch = 128 * 4 * B * N + 128 * 1024 * 4   # pre-BN input rows read once (fp32) + the bf16 hi/lo kernel; outputs are O(B*1024)
+    # algorithmic bytes: pre-BN input rows read once (fp32) + the bf16 kernel copy + per-(cloud, channel) max/argmax/2 sums
+    bytes_per_launch = 128 * 4 * B * N + 128 * 1024 * 2 * (2 if args.precision == "bf16x3" else 1) + B * 1024 * 16
+    traffic = None        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/, corrected per the guide)
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1", "r1b_panel_pmc.json")
+    if os.path.exists(pmc_file) and (B, N, args.precision) == (32, 1024, "bf16"):
+        with open(pmc_file) as f:
+            traffic = json.load(f)["traffic_bytes_per_launch"]
     achieved = flop_per_launch / k_mean
 
     out = {
@@ -182,7 +189,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "panel_max_kernel<NS,128> (ConvLayer 128->1024 + BN sums + reduce_max, 3 launches per step)",
                      "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12 / (3 if args.precision == "bf16x3" else 1),
                      "unit": "TFLOP/s", "frac": achieved / (MFMA_BF16_PEAK / (3 if args.precision == "bf16x3" else 1)),
-                     "traffic": None, "launch_us": k_mean * 1e6, "launches_timed": len(kt),
+                     "traffic": traffic, "launch_us": k_mean * 1e6, "launches_timed": len(kt),
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "hbm_frac_if_bandwidth_bound": bytes_per_launch / k_mean / HBM_PEAK},
     }

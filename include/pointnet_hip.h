@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 1
+#define PN_ABI_VERSION 2
 
 typedef enum {
   PN_OK = 0,
@@ -242,6 +242,10 @@ typedef struct pn_model_io {
    * ConvLayer(128->1024)+reduce_max launches (input_transform, feature_transform, mlp_2_3), in that order; lets a
    * benchmark time the dominant kernel inside the real step.  NULL = no events.  Do not set while capturing a graph. */
   void** prof_events;
+  /* optional: a second hipStream_t.  pn_model_backward then launches the parameter-gradient kernels (nothing on the
+   * data-gradient chain reads them) on it, forked from and joined back into `stream` with events -- graph edges when
+   * the call is being captured.  NULL (or == stream) = everything on `stream`.  Results are bit-identical either way. */
+  void* aux_stream;
 } pn_model_io;
 
 int pn_model_num_slots(const pn_model_desc* d);

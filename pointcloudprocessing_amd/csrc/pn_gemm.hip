@@ -51,6 +51,7 @@ struct GemmArgs {
   const float* sgn;         // MAX
   float* pmax;              // MAX [tiles][C]
   int* pidx;                // MAX [tiles][C]
+  int dbg;                  // PN_GEMM_DBG ablations (tools/gemm_probe.py): 1 no output stores, 2 no statistics, 4 no A loads, 8 no W loads
 };
 
 template <int BK>
@@ -378,10 +379,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 
   for (int k0 = 0; k0 < g.K; k0 += BK) {
     NatStage<BM, BK, A2> sa;
-    sa.issue(g.a, row0 * g.a.ld, nrows, k0, tid);
+    if (!(g.dbg & 4)) sa.issue(g.a, row0 * g.a.ld, nrows, k0, tid);
     if (MODE == MODE_FWD) {
       TrnStage<BN, BK, false> sb;
-      sb.issue(wop, wbase + (long long)k0 * g.C + col0, BK, g.C - col0, tid);
+      if (!(g.dbg & 8)) sb.issue(wop, wbase + (long long)k0 * g.C + col0, BK, g.C - col0, tid);
       sa.pin();
       sa.template finish<NS>(Ahi, Alo, g.a, nrows, k0, tid);
       sb.pin();
@@ -417,7 +418,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
       for (int m = 0; m < MT; ++m) {
         const int il0 = wrow0 + m * 32 + 4 * h;
         if (full) {
-          if (g.out) epi_store_block<true, ADD, MASK, true>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
+          if (g.out && !(g.dbg & 1)) epi_store_block<true, ADD, MASK, true>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
           else epi_store_block<true, ADD, MASK, false>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
         } else {
           if (g.out) epi_store_block<false, ADD, MASK, true>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
       s1[n] = a1 + __shfl_xor(a1, 32, 64);
       s2[n] = a2 + __shfl_xor(a2, 32, 64);
     }
-    if (g.stat_partials) {
+    if (g.stat_partials && !(g.dbg & 2)) {
       if (h == 0) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -522,7 +523,8 @@ static int check_operand(const pn_operand* o, const char* name) {
 
 template <int MODE, bool A2, int EPI, bool ADD = false, bool MASK = false>
 static int dispatch_rows(const GemmArgs& g, int prec, hipStream_t st) {
-  const bool wide = (g.C % 128 == 0);
+  static const bool narrow = getenv("PN_GEMM_NARROW") != nullptr;   // experiment: 128x64 tiles everywhere (2x the blocks)
+  const bool wide = (g.C % 128 == 0) && !narrow;
   if (EPI == EPI_MAX) {
     dim3 grid(g.B * g.tiles_per_cloud, cdiv(g.C, 128));
     if (prec == PN_PREC_BF16X3) return launch<128, 128, 3, MODE, A2, false, EPI>(g, grid, st);
@@ -562,6 +564,8 @@ int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, i
   g.a = *x; g.w = w; g.w_cloud_stride = wcs; g.B = B; g.N = N; g.K = K; g.C = C;
   g.tiles_per_cloud = cdiv(N, 128);
   g.out = z; g.cloud_bias = cloud_bias; g.stat_partials = stat_partials;
+  static const int dbg = getenv("PN_GEMM_DBG") ? atoi(getenv("PN_GEMM_DBG")) : 0;
+  g.dbg = dbg;
   return dispatch_rows<MODE_FWD, false, EPI_STORE>(g, prec, st);
 }
 

@@ -14,6 +14,7 @@
 //   * tile+concat in front of seg_l1 is never formed: seg_l1's kernel is split into its 64 per-point rows and
 //     its 1024 global rows, the latter applied once per cloud and added as a per-cloud bias.
 #include <cstdlib>
+#include <functional>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -150,8 +151,8 @@ struct WS {
   ML mm23;
   DLs c1, c2, c3;
   float *Weff1, *dWeff1, *X64, *dX64, *tmpA12, *gb, *dgb, *gbWt, *dGseg, *dGcls;
-  float *cls_logits, *cls_dlogits, *seg_dlogits, *seg_part, *dense_part, *slabs, *bpart, *s5slab, *R3eye, *regpart;
-  size_t slab_floats;
+  float *cls_logits, *cls_dlogits, *seg_dlogits, *seg_part, *dense_part, *slabs, *slabs_main, *bpart, *s5slab, *R3eye, *regpart;
+  size_t slab_floats, slab_main_floats;
 };
 
 static long long wgrad_slab_rows(int B, int N, int Ci, int Cj, int* spc_out) {
@@ -279,7 +280,8 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
   w.dense_part = A.get<float>("dense_part", (size_t)32 * B * 4096);
   w.R3eye = A.get<float>("R3eye", (size_t)B * 9);
   w.regpart = A.get<float>("regpart", (size_t)2 * B);
-  w.slab_floats = 0;
+  w.slab_floats = w.slab_main_floats = 0;
+  w.slabs = w.slabs_main = nullptr;
   if (training) {
     w.dWeff1 = A.get<float>("dWeff1", (size_t)B * 3 * 64);
     w.dX64 = A.get<float>("dX64", (size_t)M * 64);
@@ -304,6 +306,14 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
     if (pmf > sf) sf = pmf;
     w.slab_floats = sf;
     w.slabs = A.get<float>("slabs", sf);
+    // the weight-gradient-shaped jobs ON the data-gradient path (W diag(e) W^T, d(R_64), d(W_eff1)) get their own scratch, so the
+    // parameter-gradient jobs can run beside them on the auxiliary stream
+    size_t mf = pmf;
+    if (c3f > mf) mf = c3f;
+    const size_t rf = wgrad_slab_floats(B, N, 64, 64);
+    if (rf > mf) mf = rf;
+    w.slab_main_floats = mf;
+    w.slabs_main = A.get<float>("slabs_main", mf);
   }
 }
 
@@ -319,6 +329,63 @@ struct Run {
   bool training;
   float* P;
   float* G;
+  // Parameter gradients are off the data-gradient chain: nothing reads them before the optimizer.  With an auxiliary
+  // stream (pn_model_io.aux_stream) their launches are deferred and flushed to it at every layer boundary, behind an
+  // event recorded on the main stream, so they overlap the chain; without one they run in place.  Under stream
+  // capture the events become graph edges (two branches, joined at the end of pn_model_backward).
+  hipStream_t aux = nullptr;
+  std::vector<std::function<int()>> deferred;
+  int n_flush = 0;
+  bool on_aux = false;
+  float* cur_slabs() const { return on_aux || !aux ? w.slabs : w.slabs_main; }
+
+  static hipEvent_t pooled_event(int i) {
+    static thread_local std::vector<hipEvent_t> pool;
+    while ((int)pool.size() <= i) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+      pool.push_back(e);
+    }
+    return pool[i];
+  }
+  // run f on the auxiliary stream once the main stream reaches the next flush point (or right now without one)
+  int side(std::function<int()> f) {
+    if (!aux) return f();
+    deferred.push_back(std::move(f));
+    return PN_OK;
+  }
+  int n_sites = 0;
+  int flush(bool force = false) {
+    if (!aux || deferred.empty()) return PN_OK;
+    static const int every = getenv("PN_AUX_FLUSH_EVERY") ? atoi(getenv("PN_AUX_FLUSH_EVERY")) : 1;
+    if (!force && (++n_sites % every) != 0) return PN_OK;
+    hipEvent_t e = pooled_event(n_flush++);
+    if (!e || hipEventRecord(e, st) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) {
+      set_error("pn_model_backward: fork to the auxiliary stream failed");
+      return PN_ERR_LAUNCH;
+    }
+    const hipStream_t main_st = st;
+    st = aux; on_aux = true;
+    int rc = PN_OK;
+    for (auto& f : deferred) {
+      rc = f();
+      if (rc != PN_OK) break;
+    }
+    st = main_st; on_aux = false;
+    deferred.clear();
+    return rc;
+  }
+  int join() {
+    if (!aux) return PN_OK;
+    PN_TRY(flush(true));
+    if (n_flush == 0) return PN_OK;
+    hipEvent_t e = pooled_event(n_flush++);
+    if (!e || hipEventRecord(e, aux) != hipSuccess || hipStreamWaitEvent(st, e, 0) != hipSuccess) {
+      set_error("pn_model_backward: join of the auxiliary stream failed");
+      return PN_ERR_LAUNCH;
+    }
+    return PN_OK;
+  }
 
   bool tr(int block) const { return io.trainable ? io.trainable[block] != 0 : true; }
   bool bn_batch(int block) const { return training && tr(block); }
@@ -477,12 +544,13 @@ struct Run {
   int wgrad_general(const pn_operand& a, const pn_operand& b, int Bq, int Nq, int Ci, int Cj, float* out, bool per_cloud, int pr) {
     int spc;
     const int rows = (int)wgrad_slab_rows(Bq, Nq, Ci, Cj, &spc);
-    if ((size_t)Bq * spc * Ci * Cj > w.slab_floats) {
+    float* sl = cur_slabs();
+    if ((size_t)Bq * spc * Ci * Cj > (sl == w.slabs ? w.slab_floats : w.slab_main_floats)) {
       set_error("wgrad: slab scratch too small");
       return PN_ERR_WORKSPACE;
     }
-    PN_TRY(conv_wgrad(&a, &b, Bq, Nq, Ci, Cj, rows, w.slabs, pr, st));
-    return slab_reduce(w.slabs, Bq * spc, per_cloud ? spc : Bq * spc, (long long)Ci * Cj, out, st);
+    PN_TRY(conv_wgrad(&a, &b, Bq, Nq, Ci, Cj, rows, sl, pr, st));
+    return slab_reduce(sl, Bq * spc, per_cloud ? spc : Bq * spc, (long long)Ci * Cj, out, st);
   }
   int bn_bwd_fin(const CL& l, const LRef& r, const float* part) {
     const int bs = bn_batch(r.block) ? 1 : 0;
@@ -493,7 +561,12 @@ struct Run {
   int bwd_step(CL& cur, const LRef& rc, CL& prev, const pn_operand& prev_act) {
     PN_TRY(bn_bwd_fin(cur, rc, w.bpart));
     const pn_operand dz = dzop(cur);
-    if (tr(rc.block) && G) PN_TRY(wgrad_to(prev_act, dz, rc.cin, rc.cout, gr(rc.kernel), false));
+    if (tr(rc.block) && G) {
+      float* out = gr(rc.kernel);
+      const int ci = rc.cin, cj = rc.cout;
+      PN_TRY(side([=] { return wgrad_to(prev_act, dz, ci, cj, out, false); }));
+      PN_TRY(flush());
+    }
     return conv_bwd_data(&dz, p(rc.kernel), 0, B, N, rc.cout, rc.cin, nullptr, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st);
   }
   // backward of a max-pooled layer: dG (B,C) -> prev.dy (+stats in w.bpart), this layer's parameter gradients
@@ -504,12 +577,18 @@ struct Run {
     PN_TRY(maxbwd_prep(dG, m.g, m.zstar, B, C, l.mean, l.invstd, l.scale, bs, M, m.hs, m.e, m.nege, m.f, wg ? gr(r.gamma) : nullptr,
                        wg ? gr(r.beta) : nullptr, st));
     if (wg) {
-      PN_TRY(wgrad_to(xop, xop, K, K, m.gram, false));
-      PN_TRY(colsum_lazy(&xop, B, N, K, m.a1part, st));
-      PN_TRY(slab_reduce(m.a1part, T, T, K, m.a1, st));
-      const pn_operand gop = plain(m.gram, K);
-      PN_TRY(conv_fwd(&gop, p(r.kernel), 0, 1, K, K, C, nullptr, m.GW, nullptr, PN_PREC_BF16X3, st));
-      PN_TRY(maxbwd_dw(&xop, m.arg, m.hs, B, N, K, C, m.a1, m.f, m.e, m.GW, gr(r.kernel), st));
+      const ML mm = m;
+      float* dw = gr(r.kernel);
+      const float* Wk = p(r.kernel);
+      PN_TRY(side([=] {
+        PN_TRY(wgrad_to(xop, xop, K, K, mm.gram, false));
+        PN_TRY(colsum_lazy(&xop, B, N, K, mm.a1part, st));
+        PN_TRY(slab_reduce(mm.a1part, T, T, K, mm.a1, st));
+        const pn_operand gop = plain(mm.gram, K);
+        PN_TRY(conv_fwd(&gop, Wk, 0, 1, K, K, C, nullptr, mm.GW, nullptr, PN_PREC_BF16X3, st));
+        return maxbwd_dw(&xop, mm.arg, mm.hs, B, N, K, C, mm.a1, mm.f, mm.e, mm.GW, dw, st);
+      }));
+      PN_TRY(flush());
     }
     // Pm[k'][k] = sum_c (-e_c) W[k'][c] W[k][c]: the contraction runs over the 1024 channels, so it is laid out as a
     // weight-gradient problem over "rows" c (16 slabs of 64 channels -> 16 workgroups) instead of one 128x128 tile
@@ -527,7 +606,13 @@ struct Run {
     PN_TRY(dense_bwd_pre(da, dl.z, B, r.cout, p(r.gamma), p(r.beta), dl.mean, dl.invstd, mode, act, keep, ks, dl.dz,
                          (wg && mode == 1) ? gr(r.gamma) : nullptr, (wg && mode == 1) ? gr(r.beta) : nullptr,
                          (wg && mode == 0) ? gr(r.bias) : nullptr, st));
-    if (wg) PN_TRY(dense_wgrad(xin, r.cin, dl.dz, B, r.cin, r.cout, gr(r.kernel), st));
+    if (wg) {
+      const float* dzp = dl.dz;
+      float* out = gr(r.kernel);
+      const int ci = r.cin, cj = r.cout;
+      PN_TRY(side([=] { return dense_wgrad(xin, ci, dzp, B, ci, cj, out, st); }));
+      PN_TRY(flush());
+    }
     if (dx_out) {
       PN_TRY(transpose(p(r.kernel), r.cin, r.cout, dl.Wt, st));
       PN_TRY(dense_partial(dl.dz, r.cout, dl.Wt, B, r.cout, r.cin, w.dense_part, st));
@@ -541,8 +626,13 @@ struct Run {
     const int KK = r.K * r.K;
     const bool wg = tr(r.c1.block) && G;
     if (wg) {
-      PN_TRY(sum_partials(t.dR, B, KK, KK, gr(r.b), st));                      // db = sum_b dR
-      PN_TRY(dense_wgrad(t.d2.a, 256, t.dR, B, 256, KK, gr(r.w), st));          // dw = a2^T dR
+      const float *dR = t.dR, *a2 = t.d2.a;
+      float *gb = gr(r.b), *gw = gr(r.w);
+      PN_TRY(side([=] {
+        PN_TRY(sum_partials(dR, B, KK, KK, gb, st));                      // db = sum_b dR
+        return dense_wgrad(a2, 256, dR, B, 256, KK, gw, st);               // dw = a2^T dR
+      }));
+      PN_TRY(flush());
     }
     PN_TRY(transpose(p(r.w), 256, KK, t.wT, st));
     PN_TRY(dense_partial(t.dR, KK, t.wT, B, KK, 256, w.dense_part, st));
@@ -556,12 +646,17 @@ struct Run {
     PN_TRY(bn_bwd_fin(t.c1, r.c1, w.bpart));
     const pn_operand dz1 = dzop(t.c1);
     if (wg) {
+      float* out = gr(r.c1.kernel);
       if (r.K == 3) {
-        PN_TRY(conv3_wgrad(w.pcn, &dz1, B, N, 64, w.slabs, st));
-        PN_TRY(slab_reduce(w.slabs, T, T, 3 * 64, gr(r.c1.kernel), st));
+        PN_TRY(side([=] {
+          PN_TRY(conv3_wgrad(w.pcn, &dz1, B, N, 64, cur_slabs(), st));
+          return slab_reduce(cur_slabs(), T, T, 3 * 64, out, st);
+        }));
       } else {
-        PN_TRY(wgrad_to(*x, dz1, 64, 64, gr(r.c1.kernel), false));
+        const pn_operand xin = *x;
+        PN_TRY(side([=] { return wgrad_to(xin, dz1, 64, 64, out, false); }));
       }
+      PN_TRY(flush());
     }
     return PN_OK;
   }
@@ -587,8 +682,11 @@ struct Run {
       const pn_operand a4 = lazy(w.s4);
       PN_TRY(seg_out_bwd(&a4, p(L.s5.kernel), w.seg_dlogits, B, N, 128, d.cseg, w.s4.dy, w.bpart, w.s5slab, st));
       if (tr(BLK_S5)) {
-        PN_TRY(slab_reduce(w.s5slab, T, T, (long long)128 * d.cseg, gr(L.s5.kernel), st));
-        PN_TRY(sum_partials(w.seg_dlogits, (int)M, d.cseg, d.cseg, gr(L.s5.bias), st));
+        PN_TRY(side([=] {
+          PN_TRY(slab_reduce(w.s5slab, T, T, (long long)128 * d.cseg, gr(L.s5.kernel), st));
+          return sum_partials(w.seg_dlogits, (int)M, d.cseg, d.cseg, gr(L.s5.bias), st);
+        }));
+        PN_TRY(flush());
       }
       PN_TRY(bwd_step(w.s4, L.s4, w.s3, lazy(w.s3)));
       PN_TRY(bwd_step(w.s3, L.s3, w.s2, lazy(w.s2)));
@@ -597,8 +695,11 @@ struct Run {
       const pn_operand dz1 = dzop(w.s1);
       PN_TRY(cloud_bias_grad(w.bpart, w.s1.part, B, tpc, N, 512, w.s1.ca, w.s1.cb, w.s1.cc, w.dgb, st));
       if (tr(BLK_S1)) {
-        PN_TRY(wgrad_to(x64, dz1, 64, 512, gr(L.s1.kernel), false));
-        PN_TRY(dense_wgrad(w.mm23.g, 1024, w.dgb, B, 1024, 512, gr(L.s1.kernel) + 64 * 512, st));
+        PN_TRY(side([=] {
+          PN_TRY(wgrad_to(x64, dz1, 64, 512, gr(L.s1.kernel), false));
+          return dense_wgrad(w.mm23.g, 1024, w.dgb, B, 1024, 512, gr(L.s1.kernel) + 64 * 512, st);
+        }));
+        PN_TRY(flush());
       }
       PN_TRY(transpose(Ws1 + 64 * 512, 1024, 512, w.gbWt, st));
       PN_TRY(dense_partial(w.dgb, 512, w.gbWt, B, 512, 1024, w.dense_part, st));
@@ -633,7 +734,10 @@ struct Run {
       PN_TRY(bwd_step(w.m22, L.m22, w.m21, lazy(w.m21)));
       PN_TRY(bn_bwd_fin(w.m21, L.m21, w.bpart));
       const pn_operand dz21 = dzop(w.m21);
-      if (tr(BLK_M21)) PN_TRY(wgrad_to(x64, dz21, 64, 64, gr(L.m21.kernel), false));
+      if (tr(BLK_M21)) {
+        PN_TRY(side([=] { return wgrad_to(x64, dz21, 64, 64, gr(L.m21.kernel), false); }));
+        PN_TRY(flush());
+      }
       if (d.vanilla) {
         PN_TRY(conv_bwd_data(&dz21, p(L.m21.kernel), 0, B, N, 64, 64, have_dx64 ? w.dX64 : nullptr, w.m12.Z, w.m12.scale, w.m12.shift,
                              w.m12.dy, w.bpart, prec, st));
@@ -662,12 +766,12 @@ struct Run {
     PN_TRY(bwd_step(w.m12, L.m12, w.m11, lazy(w.m11)));
     PN_TRY(bn_bwd_fin(w.m11, L.m11, w.bpart));
     const pn_operand dz11 = dzop(w.m11);
-    PN_TRY(conv3_wgrad(w.pcn, &dz11, B, N, 64, w.slabs, st));
+    PN_TRY(conv3_wgrad(w.pcn, &dz11, B, N, 64, cur_slabs(), st));
     if (d.vanilla) {
-      if (tr(BLK_M11)) PN_TRY(slab_reduce(w.slabs, T, T, 3 * 64, gr(L.m11.kernel), st));
+      if (tr(BLK_M11)) PN_TRY(slab_reduce(cur_slabs(), T, T, 3 * 64, gr(L.m11.kernel), st));
       return PN_OK;
     }
-    PN_TRY(slab_reduce(w.slabs, T, tpc, 3 * 64, w.dWeff1, st));
+    PN_TRY(slab_reduce(cur_slabs(), T, tpc, 3 * 64, w.dWeff1, st));
     PN_TRY(zero_fill(w.iT.dR, (long long)B * 9, st));
     PN_TRY(fold3_bwd(w.dWeff1, w.iT.R, p(L.m11.kernel), B, 64, w.iT.dR, tr(BLK_M11) ? gr(L.m11.kernel) : nullptr, st));
     // ---- input transform ----
@@ -699,6 +803,8 @@ static int make_run(const pn_model_desc* d, const pn_model_io* io, hipStream_t s
   r->tpc = cdiv(io->N, 128); r->T = io->B * r->tpc;
   r->prec = d->prec; r->st = st; r->training = io->training != 0;
   r->P = io->params; r->G = io->grads;
+  r->aux = reinterpret_cast<hipStream_t>(io->aux_stream);
+  if (r->aux == st) r->aux = nullptr;
   Arena A;
   A.base = reinterpret_cast<char*>(io->workspace);
   plan_ws(A, r->w, *d, io->B, io->N, r->training);
@@ -792,6 +898,8 @@ int pn_model_backward(const pn_model_desc* d, const pn_model_io* io, const float
     rc = PN_ERR_INVALID_ARGUMENT;
   } else {
     rc = r->backward(d_cls, d_seg, d_R);
+    const int rj = r->join();            // also on error: never leave the auxiliary stream forked
+    if (rc == PN_OK) rc = rj;
   }
   delete r;
   return rc;

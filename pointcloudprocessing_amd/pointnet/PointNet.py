@@ -522,6 +522,8 @@ class PointNet(torch.nn.Module):
         io.workspace = ws.data_ptr()
         io.workspace_bytes = ws.numel()
         io.scalars = self.scalars.data_ptr()
+        aux = getattr(self, "_aux_stream", None)       # engine.TrainStep: parameter gradients on a second stream
+        io.aux_stream = aux.cuda_stream if (aux is not None and training) else None
         keep = None
         if training and self._dropout_rate > 0:
             if fused is not None and fused.get("keep") is not None:

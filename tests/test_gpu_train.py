@@ -41,14 +41,14 @@ def test_native_train_step_learns_and_graph_matches_eager(dev):
     y_seg = torch.randint(0, 12, (B, N), generator=g, dtype=torch.int32).to(dev)
     se3 = torch.eye(3).expand(B, 3, 3).contiguous().to(dev)
     finals, w0 = [], None
-    for use_graph in (False, True):
+    for use_graph, aux in ((False, True), (True, True), (False, False), (True, False)):
         m = PointNet(23, 12, 0.0, 42, precision="bf16x3", device=dev)     # dropout 0: deterministic step
         if w0 is None:
             w0 = m.params_flat.data.clone()
         else:
             m.params_flat.data.copy_(w0)       # the classification head is unseeded (PointNet.py:186-206): share the start
         opt = KerasAdam(m.params_flat.data, 1e-3, 7000, 0.7)
-        ts = TrainStep(m, opt, B, N, (1.0, 1.0, 1.0), use_graph=use_graph)
+        ts = TrainStep(m, opt, B, N, (1.0, 1.0, 1.0), use_graph=use_graph, aux=aux)   # aux: parameter gradients on a 2nd stream
         losses = []
         for i in range(62):
             ts(pc, y_cls, y_seg, se3)
@@ -57,7 +57,8 @@ def test_native_train_step_learns_and_graph_matches_eager(dev):
         finals.append(m.params_flat.data.clone())
         assert int(opt.iterations) == 62
         assert ts.mode == ("hipgraph" if use_graph else "eager")
-    assert torch.equal(finals[0], finals[1])
+    for f in finals[1:]:
+        assert torch.equal(finals[0], f)
 
 
 def test_interleaved_models_graph_replay_is_exact(dev):
