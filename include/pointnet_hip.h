@@ -166,6 +166,28 @@ int pn_sign(const float* gamma, int C, float* sgn, pn_stream stream);
 int pn_max_finalize(const float* pmax, const int32_t* pidx, int B, int tiles_per_cloud, int C, const float* sgn,
                     const float* scale, const float* shift, float* g, float* zstar, int32_t* arg, pn_stream stream);
 
+/* --- DenseLayer (pointnet/PointNet.py:597-679: Dense [+ BatchNormalization over the batch] [+ ReLU] [+ Dropout]) and the
+ * T-Net tail X @ w + b (PointNet.py:436-442), rows = clouds.  ONE launch: split-K blocks meet in-launch and the last
+ * arriver of each 32-column block applies bias / BN / ReLU / dropout.
+ *   z (R, C) = x (R, K; row stride ldx) . W + bias,  W(k, j) = w[k*ldw + j]  (trans = 0)  or  w[j*ldw + k]  (trans = 1: the
+ *   data gradient dx = dz . W^T straight from the layer's kernel);  a = dropout(relu(BN(z))) when a_out != NULL.
+ *   bn_mode 0 none | 1 batch statistics, moving_mean/var updated in place (momentum), mean/invstd kept for the backward |
+ *   2 moving statistics (frozen layer, PointNet.py:655-662).  act 0 none | 1 relu.  keep: (R, C) uint8 mask or NULL,
+ *   survivors scaled by keep_scale = 1/(1-rate).
+ *   workspace: pn_dense_workspace_floats(R, K, C) floats + 256 uint32 arrival counters that must be ZERO on entry (the
+ *   call leaves them zero). */
+size_t pn_dense_workspace_floats(int R, int K, int C);
+int pn_dense_layer(const float* x, int ldx, const float* w, int ldw, int trans, int R, int K, int C, float* workspace,
+                   uint32_t* counters, const float* bias, const float* gamma, const float* beta, float* moving_mean,
+                   float* moving_var, float momentum, float eps, int bn_mode, int act, const uint8_t* keep, float keep_scale,
+                   float* z_out, float* a_out, float* mean_out, float* invstd_out, pn_stream stream);
+
+/* --- backward of the same layer's tail and its parameters (R <= 32): da (R, C) -> dz (R, C) through dropout, ReLU and the
+ * BatchNormalization backward (batch statistics: dgamma, dbeta; none: dbias), and dw (K, C) = x^T dz.  dw may be NULL. */
+int pn_dense_bwd(const float* da, const float* z, const float* x, int ldx, int R, int K, int C, const float* gamma,
+                 const float* beta, const float* mean, const float* invstd, int bn_mode, int act, const uint8_t* keep,
+                 float keep_scale, float* dz, float* dgamma, float* dbeta, float* dbias, float* dw, pn_stream stream);
+
 /* --- farthest point sampling (no counterpart in the reference; build-defined spec):
  * per cloud, start at `start_idx`, repeatedly take the point with the largest squared distance (fp32,
  * d = dx*dx + dy*dy + dz*dz evaluated left to right without fma contraction) to the selected set, ties ->

@@ -72,6 +72,20 @@ int pn_max_finalize(const float* pmax, const int32_t* pidx, int B, int tpc, int 
                     const float* shift, float* g, float* zstar, int32_t* arg, pn_stream stream) {
   return max_finalize(pmax, pidx, B, tpc, C, 0x7fffffff, sgn, scale, shift, g, zstar, arg, S(stream));
 }
+size_t pn_dense_workspace_floats(int R, int K, int C) { return dense_partial_floats(R, K, C); }
+int pn_dense_layer(const float* x, int ldx, const float* w, int ldw, int trans, int R, int K, int C, float* workspace, uint32_t* counters,
+                   const float* bias, const float* gamma, const float* beta, float* moving_mean, float* moving_var, float momentum,
+                   float eps, int bn_mode, int act, const uint8_t* keep, float keep_scale, float* z_out, float* a_out, float* mean_out,
+                   float* invstd_out, pn_stream stream) {
+  return dense_layer(x, ldx, w, ldw, trans != 0, R, K, C, workspace, counters, bias, gamma, beta, moving_mean, moving_var, momentum, eps,
+                     bn_mode, act, keep, keep_scale, z_out, a_out, mean_out, invstd_out, S(stream));
+}
+int pn_dense_bwd(const float* da, const float* z, const float* x, int ldx, int R, int K, int C, const float* gamma, const float* beta,
+                 const float* mean, const float* invstd, int bn_mode, int act, const uint8_t* keep, float keep_scale, float* dz,
+                 float* dgamma, float* dbeta, float* dbias, float* dw, pn_stream stream) {
+  return dense_bwd_fused(da, z, x, ldx, R, K, C, gamma, beta, mean, invstd, bn_mode, act, keep, keep_scale, dz, dgamma, dbeta, dbias, dw,
+                         S(stream));
+}
 size_t pn_fps_workspace_bytes(int B, int N) { return fps_workspace_bytes(B, N); }
 int pn_fps(const float* xyz, int B, int N, int M, int start_idx, int32_t* idx_out, float* mindist, void* ws, size_t ws_bytes,
            pn_stream stream) {

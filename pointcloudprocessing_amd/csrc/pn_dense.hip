@@ -3,145 +3,372 @@
 // bound problems (M = batch size): fp32 on the vector ALU, split over K for parallelism, reduced in a
 // fixed order so results are bitwise reproducible.
 #include "pn_common.h"
+#include "pn_internal.h"
 
 namespace pn {
 
-constexpr int DENSE_KS = 32;   // k staged per LDS step
-constexpr int DENSE_RC = 32;   // rows per register chunk
-constexpr int DENSE_MAX_SPLITS = 32;
-constexpr int DENSE_TB = 128;        // columns (threads) per block of the partial kernel
+// ---- one launch per dense layer ---------------------------------------------------------------------------------------
+// out[r][j] = sum_k x[r][k] * W(k, j)  (+ bias, BatchNormalization over the R rows, ReLU, inverted dropout).
+// Grid = (column blocks of 32) x (K splits).  A block's 256 threads are 32 columns x 8 k-slices; each thread streams its
+// weights straight from global memory into registers (a row of W is read as one 128-byte line per k) and keeps the 32
+// rows' accumulators in registers; x comes through LDS as a broadcast.  The splits of one column block meet in-launch:
+// every split writes its 32x32 partial tile, then draws a ticket; the last arriver sums the tiles in a fixed order and
+// finishes the layer for those 32 columns (statistics are per column, so column blocks are independent).  This replaces
+// the separate reduce/normalise launch (~6 us in the step's graph) by ~1-2 us of tail work in one block per 32 columns.
+// Hand-off protocol: cdna_hip_programming.md, "In-launch split-K reduction" (agent-scope release before the ticket,
+// agent-scope acquire in the last arriver, counter re-zeroed by the last arriver AND by the caller before each pass).
+//   TRANS = false: W(k, j) = w[k * ldw + j]   (forward: the layer's kernel)
+//   TRANS = true : W(k, j) = w[j * ldw + k]   (backward data: dx = dz . W^T read from the same kernel, no transpose pass)
+constexpr int DL_COLS = 32;     // columns per block
+constexpr int DL_SLICES = 8;    // k-slices per block
+constexpr int DL_KPS = 16;      // k per slice and step: 16 weight loads in flight per thread
+constexpr int DL_KSTEP = DL_SLICES * DL_KPS;   // 128 k per LDS step
+constexpr int DL_ROWS = 32;     // rows per register chunk
+constexpr int DL_MAX_SPLITS = 8;
 
-// k per split: a multiple of DENSE_KS, at most DENSE_MAX_SPLITS splits
-static inline int dense_split_len(int K) {
-  int len = cdiv(cdiv(K, DENSE_MAX_SPLITS), DENSE_KS) * DENSE_KS;
-  return len < DENSE_KS ? DENSE_KS : len;
+struct DenseArgs {
+  const float* x; int ldx;
+  const float* w; int ldw;
+  int R, K, C, split_len, nsplit;
+  float* partial;             // [nsplit][R][C]
+  unsigned* counters;         // one per column block, zero on entry, zero on exit
+  const float *bias, *gamma, *beta;
+  float *mm, *mv;
+  float momentum, eps;
+  int bn_mode, act;           // bn_mode: 0 none, 1 batch statistics (+ moving update), 2 moving statistics; act: 0 none, 1 relu
+  const unsigned char* keep; float keep_scale;
+  float *z_out, *a_out, *mean_o, *invstd_o;
+};
+
+// One 128-k step of a block costs ~4 us (LDS broadcast reads + 512 FMAs per thread), the in-launch meeting of the K splits ~5 us
+// (measured: K=1024 unsplit 35 us, split 8 ways 12.5 us; K=256, C=9 unsplit 11.6 us, split in two 10.4 us): one step per block
+// up to 8 splits, pipelined steps beyond that.
+static inline int dl_nsplit(int K) {
+  const int s = cdiv(K, DL_KSTEP);
+  return s < 1 ? 1 : (s > DL_MAX_SPLITS ? DL_MAX_SPLITS : s);
 }
+static inline int dl_split_len(int K) { return cdiv(cdiv(K, dl_nsplit(K)), DL_KSTEP) * DL_KSTEP; }
 
-// partial[ks][r][j] = sum_{k in split ks} x[r][k] * w[k][j]        x: (R, K) ld = ldx ; w: (K, C)
-__global__ __launch_bounds__(DENSE_TB) void dense_partial_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
-                                                            int R, int K, int C, int split_len, float* __restrict__ partial) {
-  __shared__ float xs[DENSE_KS][DENSE_RC];   // [k][r]: a row chunk's value for one k is read as a broadcast
-  const int j = blockIdx.x * DENSE_TB + threadIdx.x;
-  const int jc = j < C ? j : C - 1;          // clamped: weight loads are unconditional (no load under a lane-dependent branch)
+template <bool TRANS>
+__global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a) {
+  // one LDS object (a second one beside a staging array can cost a full vmcnt drain per step)
+  __shared__ __attribute__((aligned(16))) float lds[DL_SLICES * DL_ROWS * DL_COLS + DL_KSTEP * DL_ROWS + 16 * 32 + 4];
+  float* red = lds;                                        // [slice][row][col]
+  float* xs = lds + DL_SLICES * DL_ROWS * DL_COLS;         // [k][row]
+  float* fin = xs + DL_KSTEP * DL_ROWS;                    // finalize scratch [16][32]
+  unsigned* flag = reinterpret_cast<unsigned*>(fin + 16 * 32);
+  const int tid = threadIdx.x, c = tid & 31, s = tid >> 5;
+  const int j = blockIdx.x * DL_COLS + c;
+  const int jc = j < a.C ? j : a.C - 1;        // clamped: weight loads are unconditional
   const int ks = blockIdx.y;
-  const int kbeg = ks * split_len, kend = min(K, kbeg + split_len);
-  for (int rc = 0; rc < R; rc += DENSE_RC) {
-    const int nr = min(DENSE_RC, R - rc);
-    float acc[DENSE_RC];
+  const int kbeg = ks * a.split_len, kend = min(a.K, kbeg + a.split_len);
+  const bool single = a.nsplit == 1;
+  const bool small = a.R <= DL_ROWS;           // block-uniform: one row chunk, the tail keeps z in registers
+  float own[DL_ROWS / DL_SLICES];
+
+  for (int rc = 0; rc < a.R; rc += DL_ROWS) {
+    const int nr = min(DL_ROWS, a.R - rc);
+    float acc[DL_ROWS];
 #pragma unroll
-    for (int r = 0; r < DENSE_RC; ++r) acc[r] = 0.f;
-    for (int k0 = kbeg; k0 < kend; k0 += DENSE_KS) {
-      const int nk = min(DENSE_KS, kend - k0);
-      // this thread's weights for the step, all in flight together
-      float wv[DENSE_KS];
+    for (int r = 0; r < DL_ROWS; ++r) acc[r] = 0.f;
+    // software pipeline: the loads of step i+1 are in flight while step i is multiplied
+    float wn[DL_KPS], xn[DL_KPS];
+    auto issue = [&](int k0) {
 #pragma unroll
-      for (int k = 0; k < DENSE_KS; ++k) wv[k] = w[(long long)(k0 + (k < nk ? k : nk - 1)) * C + jc];
-      __syncthreads();
-      for (int t = threadIdx.x; t < DENSE_RC * DENSE_KS; t += DENSE_TB) {
-        const int r = t / DENSE_KS, k = t % DENSE_KS;
-        xs[k][r] = (r < nr && k < nk) ? x[(long long)(rc + r) * ldx + k0 + k] : 0.f;
+      for (int e = 0; e < DL_KPS; ++e) {
+        const int k = k0 + s * DL_KPS + e;
+        const long long kc = k < kend ? k : kend - 1;
+        wn[e] = TRANS ? a.w[(long long)jc * a.ldw + kc] : a.w[kc * a.ldw + jc];
+      }
+#pragma unroll
+      for (int e = 0; e < DL_KPS; ++e) {
+        const int t = tid + e * 256;
+        const int r = t / DL_KSTEP, k = t % DL_KSTEP;
+        const int kk = (k0 + k < kend) ? k0 + k : kend - 1;
+        xn[e] = a.x[(long long)(rc + (r < nr ? r : nr - 1)) * a.ldx + kk];
+      }
+    };
+    if (kbeg < kend) issue(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += DL_KSTEP) {
+      float wv[DL_KPS];
+      __syncthreads();                      // the previous step's readers are done with xs
+#pragma unroll
+      for (int e = 0; e < DL_KPS; ++e) {
+        const int t = tid + e * 256;
+        const int r = t / DL_KSTEP, k = t % DL_KSTEP;
+        xs[k * DL_ROWS + r] = (r < nr && k0 + k < kend) ? xn[e] : 0.f;
+        wv[e] = (k0 + s * DL_KPS + e < kend) ? wn[e] : 0.f;
       }
       __syncthreads();
+      if (k0 + DL_KSTEP < kend) issue(k0 + DL_KSTEP);
 #pragma unroll
-      for (int k = 0; k < DENSE_KS; ++k) {
-        const float wk = (k < nk) ? wv[k] : 0.f;
+      for (int e = 0; e < DL_KPS; ++e) {
+        const float wk = wv[e];
+        const float4* xr = reinterpret_cast<const float4*>(xs + (s * DL_KPS + e) * DL_ROWS);
 #pragma unroll
-        for (int r = 0; r < DENSE_RC; ++r) acc[r] = fmaf(xs[k][r], wk, acc[r]);
+        for (int q = 0; q < DL_ROWS / 4; ++q) {
+          const float4 v = xr[q];
+          acc[4 * q + 0] = fmaf(v.x, wk, acc[4 * q + 0]);
+          acc[4 * q + 1] = fmaf(v.y, wk, acc[4 * q + 1]);
+          acc[4 * q + 2] = fmaf(v.z, wk, acc[4 * q + 2]);
+          acc[4 * q + 3] = fmaf(v.w, wk, acc[4 * q + 3]);
+        }
       }
     }
-    if (j < C)
-      for (int r = 0; r < nr; ++r) partial[((long long)ks * R + rc + r) * C + j] = acc[r];
+    // combine the 8 k-slices in a fixed order
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < DL_ROWS; ++r) red[(s * DL_ROWS + r) * DL_COLS + c] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < DL_ROWS / DL_SLICES; ++i) {
+      const int r = s + DL_SLICES * i;
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < DL_SLICES; ++q) t += red[(q * DL_ROWS + r) * DL_COLS + c];
+      own[i] = t;      // rows s, s+8, s+16, s+24 of this chunk: exactly the rows this thread finishes below
+      if (!(single && small) && r < nr && j < a.C) a.partial[((long long)ks * a.R + rc + r) * a.C + j] = t;
+    }
   }
-}
 
-// Finish a dense layer: z = sum_ks partial + bias; optional BatchNormalization over the R rows (batch or
-// moving statistics); optional ReLU; optional inverted dropout with a given keep mask.
-// block = 32 columns x 8 row partitions; all cross-row reductions in a fixed order.
-//   bn_mode: 0 no BN, 1 batch statistics (+ moving update), 2 moving statistics;   act: 0 none, 1 relu
-__global__ __launch_bounds__(256) void dense_finalize_kernel(const float* __restrict__ partial, int nks, int R, int C,
-                                                             const float* __restrict__ bias, const float* __restrict__ gamma,
-                                                             const float* __restrict__ beta, float* __restrict__ mm,
-                                                             float* __restrict__ mv, float momentum, float eps, int bn_mode,
-                                                             int act, const unsigned char* __restrict__ keep, float keep_scale,
-                                                             float* __restrict__ z_out, float* __restrict__ a_out,
-                                                             float* __restrict__ mean_o, float* __restrict__ invstd_o) {
-  constexpr int RP = 16;   // row partitions
-  __shared__ float red[RP][16];
-  __shared__ float bc[2][16];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  const int j = blockIdx.x * 16 + tx;
-  const bool jv = j < C;
-  const float b = (jv && bias) ? bias[j] : 0.f;
-  float s1 = 0.f;
-  if (jv)
-    for (int r = ty; r < R; r += RP) {
-      float z0 = 0.f, z1 = 0.f, z2 = 0.f, z3 = 0.f;
-      int ks = 0;
-      for (; ks + 3 < nks; ks += 4) {
-        z0 += partial[((long long)ks * R + r) * C + j];
-        z1 += partial[((long long)(ks + 1) * R + r) * C + j];
-        z2 += partial[((long long)(ks + 2) * R + r) * C + j];
-        z3 += partial[((long long)(ks + 3) * R + r) * C + j];
+  // ---- the splits of this column block meet here ----
+  if (!single) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its partial-tile stores
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned t = __hip_atomic_fetch_add(a.counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned last = (t == (unsigned)a.nsplit - 1u) ? 1u : 0u;
+      if (last) {
+        __hip_atomic_store(a.counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      for (; ks < nks; ++ks) z0 += partial[((long long)ks * R + r) * C + j];
-      const float z = ((z0 + z1) + (z2 + z3)) + b;
-      z_out[(long long)r * C + j] = z;
+      *flag = last;
+    }
+    __syncthreads();
+    if (*flag == 0u) return;
+  } else {
+    __syncthreads();     // the partial tile written above is re-read by other threads of this block below
+  }
+
+  // ---- finish the layer for these 32 columns: 32 columns x 8 row partitions, fixed-order reductions ----
+  const int R = a.R, C = a.C, nks = a.nsplit;
+  const int tx = c, ty = s;
+  constexpr int RP = DL_SLICES;
+  const bool jv = j < C;
+  const float b = (jv && a.bias) ? a.bias[j] : 0.f;
+  float zr[DL_ROWS / RP];        // small: this thread's rows ty, ty+8, ty+16, ty+24 stay in registers
+  float s1 = 0.f;
+  if (small && single) {
+#pragma unroll
+    for (int i = 0; i < DL_ROWS / RP; ++i) {       // no split: the sums never left the registers
+      const int r = ty + RP * i;
+      const float z = own[i] + b;
+      zr[i] = z;
+      if (jv && r < R) {
+        a.z_out[(long long)r * C + j] = z;
+        s1 += z;
+      }
+    }
+  } else if (small) {
+    float pv[DL_ROWS / RP][DL_MAX_SPLITS];
+#pragma unroll
+    for (int i = 0; i < DL_ROWS / RP; ++i) {
+      const int r = min(ty + RP * i, R - 1);
+#pragma unroll
+      for (int q = 0; q < DL_MAX_SPLITS; ++q)          // clamped, unconditional: up to 32 loads in flight
+        pv[i][q] = a.partial[((long long)min(q, nks - 1) * R + r) * C + jc];
+    }
+#pragma unroll
+    for (int i = 0; i < DL_ROWS / RP; ++i) {
+      float z0 = 0.f, z1 = 0.f;
+#pragma unroll
+      for (int q = 0; q < DL_MAX_SPLITS; q += 2) {
+        z0 += (q < nks) ? pv[i][q] : 0.f;
+        z1 += (q + 1 < nks) ? pv[i][q + 1] : 0.f;
+      }
+      const int r = ty + RP * i;
+      const float z = (z0 + z1) + b;
+      zr[i] = z;
+      if (jv && r < R) {
+        a.z_out[(long long)r * C + j] = z;
+        s1 += z;
+      }
+    }
+  } else if (jv) {
+    for (int r = ty; r < R; r += RP) {
+      float z0 = 0.f, z1 = 0.f;
+      int q = 0;
+      for (; q + 1 < nks; q += 2) {
+        z0 += a.partial[((long long)q * R + r) * C + j];
+        z1 += a.partial[((long long)(q + 1) * R + r) * C + j];
+      }
+      if (q < nks) z0 += a.partial[((long long)q * R + r) * C + j];
+      const float z = (z0 + z1) + b;
+      a.z_out[(long long)r * C + j] = z;
       s1 += z;
     }
+  }
   float sc = 1.f, sh = 0.f;
-  if (bn_mode) {      // block-uniform
+  if (a.bn_mode) {      // block-uniform
     float mean = 0.f, var = 1.f;
-    if (bn_mode == 1) {
-      red[ty][tx] = s1;
+    if (a.bn_mode == 1) {
       __syncthreads();
-      if (ty == 0) {
-        float t = 0.f;
-        for (int q = 0; q < RP; ++q) t += red[q][tx];
-        bc[0][tx] = t / (float)R;
-      }
+      fin[ty * 32 + tx] = s1;
       __syncthreads();
-      mean = bc[0][tx];
+      float t = 0.f;
+      for (int q = 0; q < RP; ++q) t += fin[q * 32 + tx];
+      mean = t / (float)R;
       float s2 = 0.f;
-      if (jv)
+      if (small) {
+#pragma unroll
+        for (int i = 0; i < DL_ROWS / RP; ++i) {
+          const float d = zr[i] - mean;
+          s2 = (jv && ty + RP * i < R) ? fmaf(d, d, s2) : s2;
+        }
+      } else if (jv) {
         for (int r = ty; r < R; r += RP) {
-          const float d = z_out[(long long)r * C + j] - mean;   // written by this thread above
+          const float d = a.z_out[(long long)r * C + j] - mean;   // written by this thread above
           s2 = fmaf(d, d, s2);
         }
-      __syncthreads();
-      red[ty][tx] = s2;
-      __syncthreads();
-      if (ty == 0) {
-        float t = 0.f;
-        for (int q = 0; q < RP; ++q) t += red[q][tx];
-        bc[1][tx] = t / (float)R;
       }
+      fin[(8 + ty) * 32 + tx] = s2;
       __syncthreads();
-      var = bc[1][tx];
+      t = 0.f;
+      for (int q = 0; q < RP; ++q) t += fin[(8 + q) * 32 + tx];
+      var = t / (float)R;
       if (ty == 0 && jv) {
-        mm[j] = mm[j] * momentum + mean * (1.f - momentum);
-        mv[j] = mv[j] * momentum + var * (1.f - momentum);
+        a.mm[j] = a.mm[j] * a.momentum + mean * (1.f - a.momentum);
+        a.mv[j] = a.mv[j] * a.momentum + var * (1.f - a.momentum);
       }
     } else if (jv) {
-      mean = mm[j];
-      var = mv[j];
+      mean = a.mm[j];
+      var = a.mv[j];
     }
-    const float invstd = 1.0f / sqrtf(var + eps);
+    const float invstd = 1.0f / sqrtf(var + a.eps);
     if (jv) {
-      sc = gamma[j] * invstd;
-      sh = beta[j] - mean * sc;
+      sc = a.gamma[j] * invstd;
+      sh = a.beta[j] - mean * sc;
       if (ty == 0) {
-        if (mean_o) mean_o[j] = mean;
-        if (invstd_o) invstd_o[j] = invstd;
+        if (a.mean_o) a.mean_o[j] = mean;
+        if (a.invstd_o) a.invstd_o[j] = invstd;
       }
     }
   }
-  if (a_out && jv) {
-    for (int r = ty; r < R; r += RP) {
-      float y = fmaf(sc, z_out[(long long)r * C + j], sh);
-      if (act == 1) y = fmaxf(y, 0.f);
-      if (keep) y = keep[(long long)r * C + j] ? y * keep_scale : 0.f;
-      a_out[(long long)r * C + j] = y;
+  if (a.a_out && jv) {
+    if (small) {
+#pragma unroll
+      for (int i = 0; i < DL_ROWS / RP; ++i) {
+        const int r = ty + RP * i;
+        if (r < R) {
+          float y = fmaf(sc, zr[i], sh);
+          if (a.act == 1) y = fmaxf(y, 0.f);
+          if (a.keep) y = a.keep[(long long)r * C + j] ? y * a.keep_scale : 0.f;
+          a.a_out[(long long)r * C + j] = y;
+        }
+      }
+    } else {
+      for (int r = ty; r < R; r += RP) {
+        float y = fmaf(sc, a.z_out[(long long)r * C + j], sh);
+        if (a.act == 1) y = fmaxf(y, 0.f);
+        if (a.keep) y = a.keep[(long long)r * C + j] ? y * a.keep_scale : 0.f;
+        a.a_out[(long long)r * C + j] = y;
+      }
     }
+  }
+}
+
+// Backward of a dense layer's tail fused into its weight gradient (R <= 32): every thread owns one column j, rebuilds that
+// column's dz from da / z / the dropout mask (its 32 rows fit in registers, so the two column sums of the BN backward need no
+// exchange at all), and accumulates dw[k][j] for the block's 16 k.  The blocks of the first k-tile also write dz, dgamma,
+// dbeta / dbias.  One launch instead of two; dw may be NULL (frozen layer: only dz is produced, grid.y = 1).
+__global__ __launch_bounds__(256) void dense_bwd_fused_kernel(const float* __restrict__ da, const float* __restrict__ z,
+                                                              const float* __restrict__ x, int ldx, int R, int K, int C,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              int bn_mode, int act, const unsigned char* __restrict__ keep,
+                                                              float keep_scale, float* __restrict__ dz, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ dbias,
+                                                              float* __restrict__ dw) {
+  constexpr int KT = 16;
+  constexpr int WRC = 32;
+  __shared__ __attribute__((aligned(16))) float xs[KT][WRC];
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const bool jv = j < C;
+  const int jc = jv ? j : C - 1;
+  const int k0 = blockIdx.y * KT;
+  float sc = 1.f, sh = 0.f, mu = 0.f, is = 1.f;
+  if (bn_mode) {
+    mu = mean[jc]; is = invstd[jc];
+    sc = gamma[jc] * is;
+    sh = beta[jc] - mu * sc;
+  }
+  float d[WRC], zh[WRC];
+  unsigned kmask = 0xffffffffu;             // dropout keep bits of this column's rows
+#pragma unroll
+  for (int r = 0; r < WRC; ++r) {           // unconditional, clamped loads: all in flight together
+    const long long o = (long long)min(r, R - 1) * C + jc;
+    d[r] = da[o];
+    zh[r] = z[o];
+  }
+  if (keep) {
+    kmask = 0u;
+#pragma unroll
+    for (int r = 0; r < WRC; ++r) kmask |= (keep[(long long)min(r, R - 1) * C + jc] ? 1u : 0u) << r;
+  }
+  const float kscale = keep ? keep_scale : 1.f;
+  float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+  for (int r = 0; r < WRC; ++r) {
+    float v = ((kmask >> r) & 1u) ? d[r] * kscale : 0.f;
+    if (act == 1 && !(fmaf(sc, zh[r], sh) > 0.f)) v = 0.f;
+    if (r >= R) v = 0.f;
+    zh[r] = (zh[r] - mu) * is;
+    d[r] = v;
+    S1 += v;
+    S2 = fmaf(v, zh[r], S2);
+  }
+  if (bn_mode == 1) {
+    const float invR = 1.f / (float)R;
+    const float m1 = S1 * invR, m2 = S2 * invR;
+#pragma unroll
+    for (int r = 0; r < WRC; ++r) d[r] = (r < R) ? sc * (d[r] - m1 - zh[r] * m2) : 0.f;
+  } else if (bn_mode == 2) {
+#pragma unroll
+    for (int r = 0; r < WRC; ++r) d[r] *= sc;
+  }
+  if (blockIdx.y == 0 && jv) {
+#pragma unroll
+    for (int r = 0; r < WRC; ++r)
+      if (r < R) dz[(long long)r * C + j] = d[r];
+    if (bn_mode == 1) {
+      if (dgamma) dgamma[j] = S2;
+      if (dbeta) dbeta[j] = S1;
+    } else if (bn_mode == 0 && dbias) {
+      dbias[j] = S1;
+    }
+  }
+  if (!dw) return;
+  for (int t = threadIdx.x; t < KT * WRC; t += 256) {
+    const int k = t / WRC, r = t % WRC;
+    xs[k][r] = (r < R && k0 + k < K) ? x[(long long)r * ldx + k0 + k] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll 2
+  for (int k = 0; k < KT; ++k) {            // k outermost: at most two rows of the x tile live in registers at a time
+    const float4* xr = reinterpret_cast<const float4*>(&xs[k][0]);
+    float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < WRC / 4; ++q) {
+      const float4 v = xr[q];
+      a0 = fmaf(v.x, d[4 * q + 0], a0);
+      a1 = fmaf(v.y, d[4 * q + 1], a1);
+      a0 = fmaf(v.z, d[4 * q + 2], a0);
+      a1 = fmaf(v.w, d[4 * q + 3], a1);
+    }
+    if (jv && k0 + k < K) dw[(long long)(k0 + k) * C + j] = a0 + a1;
   }
 }
 
@@ -345,21 +572,37 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
 }
 
 // ---- host wrappers ---------------------------------------------------------------------------------------
-int dense_partial(const float* x, int ldx, const float* w, int R, int K, int C, float* partial, hipStream_t st) {
-  PN_CHECK_ARG(x && w && partial && R > 0 && K > 0 && C > 0, "dense_partial: bad arguments");
-  const int len = dense_split_len(K);
-  hipLaunchKernelGGL(dense_partial_kernel, dim3(cdiv(C, DENSE_TB), cdiv(K, len)), dim3(DENSE_TB), 0, st, x, ldx, w, R, K, C, len, partial);
+size_t dense_partial_floats(int R, int K, int C) { return (size_t)dl_nsplit(K) * R * C; }
+
+int dense_layer(const float* x, int ldx, const float* w, int ldw, bool trans, int R, int K, int C, float* partial, unsigned* counters,
+                const float* bias, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps, int bn_mode,
+                int act, const unsigned char* keep, float keep_scale, float* z_out, float* a_out, float* mean_o, float* invstd_o,
+                hipStream_t st) {
+  PN_CHECK_ARG(x && w && partial && counters && z_out && R > 0 && K > 0 && C > 0, "dense_layer: bad arguments");
+  PN_CHECK_ARG(cdiv(C, DL_COLS) <= DENSE_MAX_COUNTERS, "dense_layer: C=%d needs more than %d counters", C, DENSE_MAX_COUNTERS);
+  PN_CHECK_ARG(!bn_mode || (gamma && beta && mm && mv), "dense_layer: BatchNormalization needs gamma/beta/moving statistics");
+  DenseArgs a;
+  a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.R = R; a.K = K; a.C = C;
+  a.nsplit = dl_nsplit(K); a.split_len = dl_split_len(K);
+  a.partial = partial; a.counters = counters;
+  a.bias = bias; a.gamma = gamma; a.beta = beta; a.mm = mm; a.mv = mv; a.momentum = momentum; a.eps = eps;
+  a.bn_mode = bn_mode; a.act = act; a.keep = keep; a.keep_scale = keep_scale;
+  a.z_out = z_out; a.a_out = a_out; a.mean_o = mean_o; a.invstd_o = invstd_o;
+  const dim3 grid(cdiv(C, DL_COLS), a.nsplit);
+  if (trans) hipLaunchKernelGGL(dense_layer_kernel<true>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(dense_layer_kernel<false>, grid, dim3(256), 0, st, a);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
-int dense_nsplit(int K) { return cdiv(K, dense_split_len(K)); }
 
-int dense_finalize(const float* partial, int nks, int R, int C, const float* bias, const float* gamma, const float* beta, float* mm,
-                   float* mv, float momentum, float eps, int bn_mode, int act, const unsigned char* keep, float keep_scale,
-                   float* z_out, float* a_out, float* mean_o, float* invstd_o, hipStream_t st) {
-  PN_CHECK_ARG(partial && z_out, "dense_finalize: null pointer");
-  hipLaunchKernelGGL(dense_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nks, R, C, bias, gamma, beta, mm, mv,
-                     momentum, eps, bn_mode, act, keep, keep_scale, z_out, a_out, mean_o, invstd_o);
+int dense_bwd_fused(const float* da, const float* z, const float* x, int ldx, int R, int K, int C, const float* gamma, const float* beta,
+                    const float* mean, const float* invstd, int bn_mode, int act, const unsigned char* keep, float keep_scale, float* dz,
+                    float* dgamma, float* dbeta, float* dbias, float* dw, hipStream_t st) {
+  PN_CHECK_ARG(da && z && dz && R > 0 && R <= 32 && C > 0, "dense_bwd_fused: bad arguments (R must be <= 32)");
+  PN_CHECK_ARG(!dw || (x && K > 0), "dense_bwd_fused: the weight gradient needs the layer input");
+  PN_CHECK_ARG(!bn_mode || (gamma && beta && mean && invstd), "dense_bwd_fused: BatchNormalization needs gamma/beta/mean/invstd");
+  hipLaunchKernelGGL(dense_bwd_fused_kernel, dim3(cdiv(C, 256), dw ? cdiv(K, 16) : 1), dim3(256), 0, st, da, z, x, ldx, R, K, C, gamma,
+                     beta, mean, invstd, bn_mode, act, keep, keep_scale, dz, dgamma, dbeta, dbias, dw);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -36,11 +36,15 @@ int max_finalize(const float* pmax, const int* pidx, int B, int tpc, int C, int 
                  const float* shift, float* g, float* zstar, int* arg, hipStream_t st);
 
 // pn_dense.hip
-int dense_partial(const float* x, int ldx, const float* w, int R, int K, int C, float* partial, hipStream_t st);
-int dense_nsplit(int K);
-int dense_finalize(const float* partial, int nks, int R, int C, const float* bias, const float* gamma, const float* beta, float* mm,
-                   float* mv, float momentum, float eps, int bn_mode, int act, const unsigned char* keep, float keep_scale,
-                   float* z_out, float* a_out, float* mean_o, float* invstd_o, hipStream_t st);
+constexpr int DENSE_MAX_COUNTERS = 256;     // column blocks of 32 -> C <= 8192
+size_t dense_partial_floats(int R, int K, int C);
+int dense_layer(const float* x, int ldx, const float* w, int ldw, bool trans, int R, int K, int C, float* partial, unsigned* counters,
+                const float* bias, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps, int bn_mode,
+                int act, const unsigned char* keep, float keep_scale, float* z_out, float* a_out, float* mean_o, float* invstd_o,
+                hipStream_t st);
+int dense_bwd_fused(const float* da, const float* z, const float* x, int ldx, int R, int K, int C, const float* gamma, const float* beta,
+                    const float* mean, const float* invstd, int bn_mode, int act, const unsigned char* keep, float keep_scale, float* dz,
+                    float* dgamma, float* dbeta, float* dbias, float* dw, hipStream_t st);
 int dense_bwd_pre(const float* da, const float* z, int R, int C, const float* gamma, const float* beta, const float* mean,
                   const float* invstd, int bn_mode, int act, const unsigned char* keep, float keep_scale, float* dz, float* dgamma,
                   float* dbeta, float* dbias, hipStream_t st);

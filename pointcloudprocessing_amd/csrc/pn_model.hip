@@ -134,14 +134,14 @@ struct ML {   // extra state of a max-pooled layer
   int T64, tpc64;
 };
 struct DLs {  // dense layer state (rows = B)
-  float *z, *a, *mean, *invstd, *dz, *Wt, *din;
+  float *z, *a, *mean, *invstd, *dz, *din;
   int K, C;
 };
 struct TN {
   CL c1, c2, c3;
   ML m3;
   DLs d1, d2;
-  float *R, *dR, *wT, *da2;
+  float *R, *dR, *da2;
 };
 
 struct WS {
@@ -150,9 +150,10 @@ struct WS {
   CL m11, m12, m21, m22, m23, s1, s2, s3, s4;
   ML mm23;
   DLs c1, c2, c3;
-  float *Weff1, *dWeff1, *X64, *dX64, *tmpA12, *gb, *dgb, *gbWt, *dGseg, *dGcls;
+  float *Weff1, *dWeff1, *X64, *dX64, *tmpA12, *gb, *dgb, *dGseg, *dGcls;
   float *cls_logits, *cls_dlogits, *seg_dlogits, *seg_part, *dense_part, *slabs, *slabs_main, *bpart, *s5slab, *R3eye, *regpart;
   size_t slab_floats, slab_main_floats;
+  unsigned* dcount;
 };
 
 static long long wgrad_slab_rows(int B, int N, int Ci, int Cj, int* spc_out) {
@@ -229,7 +230,6 @@ static void plan_dl(Arena& A, DLs& d, const char* nm, int B, int K, int C, bool 
   d.invstd = A.get<float>((n + ".invstd").c_str(), C);
   if (training) {
     d.dz = A.get<float>((n + ".dz").c_str(), (size_t)B * C);
-    d.Wt = A.get<float>((n + ".Wt").c_str(), (size_t)K * C);
     d.din = A.get<float>((n + ".din").c_str(), (size_t)B * K);
   }
 }
@@ -244,7 +244,6 @@ static void plan_tn(Arena& A, TN& t, const char* nm, int B, int N, long long M, 
   t.R = A.get<float>((n + ".R").c_str(), (size_t)B * K * K);
   if (training) {
     t.dR = A.get<float>((n + ".dR").c_str(), (size_t)B * K * K);
-    t.wT = A.get<float>((n + ".wT").c_str(), (size_t)256 * K * K);
     t.da2 = A.get<float>((n + ".da2").c_str(), (size_t)B * 256);
   }
 }
@@ -277,7 +276,8 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
   w.gb = A.get<float>("gb", (size_t)B * 512);
   w.cls_logits = A.get<float>("cls_logits", (size_t)B * d.ccls);
   w.seg_part = A.get<float>("seg_part", (size_t)cdivll(M, 256) * seg_out_part_stride());
-  w.dense_part = A.get<float>("dense_part", (size_t)32 * B * 4096);
+  w.dense_part = A.get<float>("dense_part", (size_t)8 * B * 4096);          // split-K tiles of the dense layers (<= 8 splits)
+  w.dcount = A.get<unsigned>("dcount", DENSE_MAX_COUNTERS);                 // their in-launch arrival counters
   w.R3eye = A.get<float>("R3eye", (size_t)B * 9);
   w.regpart = A.get<float>("regpart", (size_t)2 * B);
   w.slab_floats = w.slab_main_floats = 0;
@@ -287,7 +287,6 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
     w.dX64 = A.get<float>("dX64", (size_t)M * 64);
     w.tmpA12 = A.get<float>("tmpA12", (size_t)M * 64);
     w.dgb = A.get<float>("dgb", (size_t)B * 512);
-    w.gbWt = A.get<float>("gbWt", (size_t)1024 * 512);
     w.dGseg = A.get<float>("dGseg", (size_t)B * 1024);
     w.dGcls = A.get<float>("dGcls", (size_t)B * 1024);
     w.cls_dlogits = A.get<float>("cls_dlogits", (size_t)B * d.ccls);
@@ -433,12 +432,16 @@ struct Run {
     PN_TRY(bn_fin(l, r, m.T64));
     return max_finalize(m.pmax, m.pidx, B, m.tpc64, r.cout, N, m.sgn, l.scale, l.shift, m.g, m.zstar, m.arg, st);
   }
+  // out (B, C) = x (B, K) . W (+ bias): one launch (pn_dense.hip); trans reads W^T from the same (C, K)-major... kernel
+  int dense_plain(const float* x, int ldx, const float* W, int ldw, bool trans, int K, int C, const float* bias, float* out) {
+    return dense_layer(x, ldx, W, ldw, trans, B, K, C, w.dense_part, w.dcount, bias, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0,
+                       nullptr, 1.f, out, nullptr, nullptr, nullptr, st);
+  }
   int fwd_dense(DLs& dl, const LRef& r, const float* x, int act, const unsigned char* keep) {
-    PN_TRY(dense_partial(x, r.cin, p(r.kernel), B, r.cin, r.cout, w.dense_part, st));
     const int mode = r.has_bn ? (bn_batch(r.block) ? 1 : 2) : 0;
     const float ks = 1.f / (1.f - d.dropout_rate);
-    return dense_finalize(w.dense_part, dense_nsplit(r.cin), B, r.cout, p(r.bias), p(r.gamma), p(r.beta), p(r.mm), p(r.mv),
-                          d.bn_momentum, d.bn_eps, mode, act, keep, ks, dl.z, dl.a, dl.mean, dl.invstd, st);
+    return dense_layer(x, r.cin, p(r.kernel), r.cout, false, B, r.cin, r.cout, w.dense_part, w.dcount, p(r.bias), p(r.gamma), p(r.beta),
+                       p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, mode, act, keep, ks, dl.z, dl.a, dl.mean, dl.invstd, st);
   }
   int fwd_tnet(TN& t, const TRef& r, const pn_operand* x) {
     if (r.K == 3) {
@@ -451,14 +454,13 @@ struct Run {
     PN_TRY(fwd_max(t.c3, t.m3, r.c3, lazy(t.c2), r.K == 3 ? 0 : 1));
     PN_TRY(fwd_dense(t.d1, r.d1, t.m3.g, 1, nullptr));
     PN_TRY(fwd_dense(t.d2, r.d2, t.d1.a, 1, nullptr));
-    PN_TRY(dense_partial(t.d2.a, 256, p(r.w), B, 256, r.K * r.K, w.dense_part, st));
-    return dense_finalize(w.dense_part, dense_nsplit(256), B, r.K * r.K, p(r.b), nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0,
-                          nullptr, 1.f, t.R, nullptr, nullptr, nullptr, st);
+    return dense_plain(t.d2.a, 256, p(r.w), r.K * r.K, false, 256, r.K * r.K, p(r.b), t.R);
   }
 
   pn_operand x64op() const { return d.vanilla ? lazy(w.m12) : plain(w.X64, 64); }
 
   int forward() {
+    PN_TRY(zero_fill(reinterpret_cast<float*>(w.dcount), DENSE_MAX_COUNTERS, st));   // arrival counters of the dense layers
     PN_TRY(normalize(io.pc, B, N, w.pcn, w.cent, w.scl, st));
     if (!d.vanilla) {
       PN_TRY(fwd_tnet(w.iT, L.iT, nullptr));
@@ -483,9 +485,7 @@ struct Run {
     // classification head (PointNet.py:252-263)
     PN_TRY(fwd_dense(w.c1, L.c1, Gf, 1, training ? io.keep1 : nullptr));
     PN_TRY(fwd_dense(w.c2, L.c2, w.c1.a, 1, training ? io.keep2 : nullptr));
-    PN_TRY(dense_partial(w.c2.a, 256, p(L.c3.kernel), B, 256, d.ccls, w.dense_part, st));
-    PN_TRY(dense_finalize(w.dense_part, dense_nsplit(256), B, d.ccls, p(L.c3.bias), nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0,
-                          nullptr, 1.f, w.cls_logits, nullptr, nullptr, nullptr, st));
+    PN_TRY(dense_plain(w.c2.a, 256, p(L.c3.kernel), d.ccls, false, 256, d.ccls, p(L.c3.bias), w.cls_logits));
     const bool fused = io.labels_cls != nullptr;
     PN_TRY(softmax_xent_rows(w.cls_logits, B, d.ccls, io.labels_cls, fused ? io.loss_weights[0] / (float)B : 0.f, io.out_cls,
                              (fused && training) ? w.cls_dlogits : nullptr, io.scalars ? io.scalars + 0 : nullptr,
@@ -493,9 +493,7 @@ struct Run {
 
     // segmentation head (PointNet.py:268-290)
     const float* Ws1 = p(L.s1.kernel);
-    PN_TRY(dense_partial(Gf, 1024, Ws1 + 64 * 512, B, 1024, 512, w.dense_part, st));
-    PN_TRY(dense_finalize(w.dense_part, dense_nsplit(1024), B, 512, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0, nullptr,
-                          1.f, w.gb, nullptr, nullptr, nullptr, st));
+    PN_TRY(dense_plain(Gf, 1024, Ws1 + 64 * 512, 512, false, 1024, 512, nullptr, w.gb));
     // seg_l1 always emits its forward partials: the backward needs the per-cloud sums of z
     PN_TRY(conv_fwd(&x64, Ws1, 0, B, N, 64, 512, w.gb, w.s1.Z, w.s1.part, prec, st));
     PN_TRY(bn_fin(w.s1, L.s1));
@@ -603,22 +601,25 @@ struct Run {
     const int mode = r.has_bn ? (bn_batch(r.block) ? 1 : 2) : 0;
     const bool wg = tr(r.block) && G;
     const float ks = 1.f / (1.f - d.dropout_rate);
-    PN_TRY(dense_bwd_pre(da, dl.z, B, r.cout, p(r.gamma), p(r.beta), dl.mean, dl.invstd, mode, act, keep, ks, dl.dz,
-                         (wg && mode == 1) ? gr(r.gamma) : nullptr, (wg && mode == 1) ? gr(r.beta) : nullptr,
-                         (wg && mode == 0) ? gr(r.bias) : nullptr, st));
-    if (wg) {
-      const float* dzp = dl.dz;
-      float* out = gr(r.kernel);
-      const int ci = r.cin, cj = r.cout;
-      PN_TRY(side([=] { return dense_wgrad(xin, ci, dzp, B, ci, cj, out, st); }));
-      PN_TRY(flush());
+    float* dgam = (wg && mode == 1) ? gr(r.gamma) : nullptr;
+    float* dbet = (wg && mode == 1) ? gr(r.beta) : nullptr;
+    float* dbia = (wg && mode == 0) ? gr(r.bias) : nullptr;
+    if (B <= 32) {
+      // dropout/relu/BN backward fused into the weight gradient: one launch
+      PN_TRY(dense_bwd_fused(da, dl.z, xin, r.cin, B, r.cin, r.cout, p(r.gamma), p(r.beta), dl.mean, dl.invstd, mode, act, keep, ks, dl.dz,
+                             dgam, dbet, dbia, wg ? gr(r.kernel) : nullptr, st));
+    } else {
+      PN_TRY(dense_bwd_pre(da, dl.z, B, r.cout, p(r.gamma), p(r.beta), dl.mean, dl.invstd, mode, act, keep, ks, dl.dz, dgam, dbet, dbia, st));
+      if (wg) {
+        const float* dzp = dl.dz;
+        float* out = gr(r.kernel);
+        const int ci = r.cin, cj = r.cout;
+        PN_TRY(side([=] { return dense_wgrad(xin, ci, dzp, B, ci, cj, out, st); }));
+        PN_TRY(flush());
+      }
     }
-    if (dx_out) {
-      PN_TRY(transpose(p(r.kernel), r.cin, r.cout, dl.Wt, st));
-      PN_TRY(dense_partial(dl.dz, r.cout, dl.Wt, B, r.cout, r.cin, w.dense_part, st));
-      PN_TRY(dense_finalize(w.dense_part, dense_nsplit(r.cout), B, r.cin, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0,
-                            nullptr, 1.f, dx_out, nullptr, nullptr, nullptr, st));
-    }
+    // dx = dz . W^T, read from the layer's own (K, C) kernel
+    if (dx_out) PN_TRY(dense_plain(dl.dz, r.cout, p(r.kernel), r.cout, true, r.cout, r.cin, nullptr, dx_out));
     return PN_OK;
   }
   // T-Net backward from dR (B,K*K); leaves c1's dz coefficients ready (c1.dy + c1.ca/cb/cc)
@@ -634,10 +635,7 @@ struct Run {
       }));
       PN_TRY(flush());
     }
-    PN_TRY(transpose(p(r.w), 256, KK, t.wT, st));
-    PN_TRY(dense_partial(t.dR, KK, t.wT, B, KK, 256, w.dense_part, st));
-    PN_TRY(dense_finalize(w.dense_part, dense_nsplit(KK), B, 256, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0, nullptr, 1.f,
-                          t.da2, nullptr, nullptr, nullptr, st));
+    PN_TRY(dense_plain(t.dR, KK, p(r.w), KK, true, KK, 256, nullptr, t.da2));
     PN_TRY(bwd_dense(t.d2, r.d2, t.d1.a, t.da2, 1, nullptr, t.d2.din));
     PN_TRY(bwd_dense(t.d1, r.d1, t.m3.g, t.d2.din, 1, nullptr, t.m3.dG));
     PN_TRY(bwd_max(t.c3, t.m3, r.c3, lazy(t.c2), t.c2, t.m3.dG));
@@ -667,6 +665,7 @@ struct Run {
       return PN_ERR_INVALID_ARGUMENT;
     }
     PN_TRY(zero_fill(G, L.total, st));
+    PN_TRY(zero_fill(reinterpret_cast<float*>(w.dcount), DENSE_MAX_COUNTERS, st));
     const pn_operand x64 = x64op();
     const float* Ws1 = p(L.s1.kernel);
     const bool fused = io.labels_cls != nullptr || io.labels_seg != nullptr;
@@ -701,10 +700,7 @@ struct Run {
         }));
         PN_TRY(flush());
       }
-      PN_TRY(transpose(Ws1 + 64 * 512, 1024, 512, w.gbWt, st));
-      PN_TRY(dense_partial(w.dgb, 512, w.gbWt, B, 512, 1024, w.dense_part, st));
-      PN_TRY(dense_finalize(w.dense_part, dense_nsplit(512), B, 1024, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0, nullptr,
-                            1.f, w.dGseg, nullptr, nullptr, nullptr, st));
+      PN_TRY(dense_plain(w.dgb, 512, Ws1 + 64 * 512, 512, true, 512, 1024, nullptr, w.dGseg));
       have_dGseg = true;
       PN_TRY(conv_bwd_data(&dz1, Ws1, 0, B, N, 512, 64, nullptr, nullptr, nullptr, nullptr, w.dX64, nullptr, prec, st));
       have_dx64 = true;

@@ -186,3 +186,35 @@ def voxel_downsample(xyz: torch.Tensor, leaf, origin, labels: Optional[torch.Ten
     if int(ws[:4].view(torch.int32).item()) != 0:
         raise _lib.PointNetHipError("pn_voxel_downsample: a voxel key fell outside [0, 2^21)")
     return cent[:v], cnt[:v], (maj[:v] if labels is not None else None)
+
+
+def dense_layer(x, w, trans=False, bias=None, gamma=None, beta=None, moving_mean=None, moving_var=None, bn_mode=0, act=0, keep=None,
+                rate=0.0, momentum=0.99, eps=1e-3, counters=None):
+    """DenseLayer forward in one launch: returns (z, a, mean, invstd); moving statistics are updated in place (bn_mode 1)."""
+    R, K = x.shape
+    C_ = w.shape[0] if trans else w.shape[1]
+    dev = x.device
+    ws = torch.empty(max(1, lib().pn_dense_workspace_floats(R, K, C_)), device=dev, dtype=F32)
+    if counters is None:
+        counters = torch.zeros(256, device=dev, dtype=torch.int32)
+    z = torch.empty(R, C_, device=dev, dtype=F32)
+    a = torch.empty(R, C_, device=dev, dtype=F32)
+    mean = torch.empty(C_, device=dev, dtype=F32)
+    invstd = torch.empty(C_, device=dev, dtype=F32)
+    check(lib().pn_dense_layer(ptr(x), x.stride(0), ptr(w), w.stride(0), int(trans), R, K, C_, ptr(ws), ptr(counters), ptr(bias), ptr(gamma),
+                               ptr(beta), ptr(moving_mean), ptr(moving_var), momentum, eps, bn_mode, act, ptr(keep),
+                               1.0 / (1.0 - rate), ptr(z), ptr(a), ptr(mean), ptr(invstd), current_stream()), "pn_dense_layer")
+    return z, a, mean, invstd
+
+
+def dense_bwd(da, z, x, gamma=None, beta=None, mean=None, invstd=None, bn_mode=0, act=0, keep=None, rate=0.0, want_dw=True):
+    """backward of the layer tail + parameters: returns (dz, dgamma, dbeta, dbias, dw)"""
+    R, C_ = da.shape
+    K = x.shape[1]
+    dev = da.device
+    dz = torch.empty(R, C_, device=dev, dtype=F32)
+    dg = torch.zeros(C_, device=dev, dtype=F32); db = torch.zeros(C_, device=dev, dtype=F32); dbias = torch.zeros(C_, device=dev, dtype=F32)
+    dw = torch.empty(K, C_, device=dev, dtype=F32) if want_dw else None
+    check(lib().pn_dense_bwd(ptr(da), ptr(z), ptr(x), x.stride(0), R, K, C_, ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), bn_mode, act,
+                             ptr(keep), 1.0 / (1.0 - rate), ptr(dz), ptr(dg), ptr(db), ptr(dbias), ptr(dw), current_stream()), "pn_dense_bwd")
+    return dz, dg, db, dbias, dw

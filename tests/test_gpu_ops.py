@@ -311,3 +311,98 @@ def test_invalid_arguments_raise(dev):
         ops.farthest_point_sample(torch.zeros(1, 10, 3, device=dev), 4, start_idx=10)
     with pytest.raises(L.PointNetHipError):
         ops.normalize(torch.zeros(1, 10, 3))                      # CPU tensor: no CPU fallback
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# DenseLayer in one launch (split-K blocks meeting in-launch) and its fused backward
+# ---------------------------------------------------------------------------------------------------------------------
+def _dense_ref(x, w, bias, gamma, beta, mm, mv, bn_mode, act, keep, rate, momentum=0.99, eps=1e-3):
+    """fp64 restatement of keras Dense -> BatchNormalization -> ReLU -> Dropout (pointnet/PointNet.py:597-679)"""
+    z = x.double() @ w.double()
+    if bias is not None:
+        z = z + bias.double()
+    mean = invstd = None
+    y = z
+    if bn_mode == 1:
+        mean = z.mean(0); var = z.var(0, unbiased=False)
+        invstd = 1.0 / torch.sqrt(var + eps)
+        y = (z - mean) * invstd * gamma.double() + beta.double()
+        mm_new = mm.double() * momentum + mean * (1 - momentum); mv_new = mv.double() * momentum + var * (1 - momentum)
+    elif bn_mode == 2:
+        mean = mm.double(); invstd = 1.0 / torch.sqrt(mv.double() + eps)
+        y = (z - mean) * invstd * gamma.double() + beta.double()
+        mm_new, mv_new = mm.double(), mv.double()
+    else:
+        mm_new = mv_new = None
+    if act:
+        y = torch.relu(y)
+    if keep is not None:
+        y = torch.where(keep.bool(), y / (1.0 - rate), torch.zeros_like(y))
+    return z, y, mean, invstd, mm_new, mv_new
+
+
+@pytest.mark.parametrize("R,K,C_,trans,bn_mode,act,drop", [
+    (32, 1024, 512, False, 1, 1, True), (32, 512, 256, False, 1, 1, False), (32, 256, 23, False, 0, 0, False),
+    (32, 256, 4096, False, 0, 0, False), (5, 256, 9, False, 0, 0, False), (7, 300, 70, False, 2, 1, True),
+    (32, 512, 1024, True, 0, 0, False), (32, 23, 256, True, 0, 0, False), (3, 9, 256, True, 0, 0, False),
+    (45, 1024, 96, False, 1, 1, True), (33, 130, 40, True, 0, 0, False),
+])
+def test_dense_layer_matches_fp64_reference(dev, R, K, C_, trans, bn_mode, act, drop):
+    g = torch.Generator().manual_seed(R * 7919 + K * 31 + C_)
+    x = torch.randn(R, K, generator=g).to(dev)
+    w = (torch.randn(K, C_, generator=g) * 0.05).to(dev)
+    bias = None if bn_mode else torch.randn(C_, generator=g).to(dev)
+    gamma = (torch.rand(C_, generator=g) + 0.5).to(dev); beta = torch.randn(C_, generator=g).to(dev)
+    mm = torch.randn(C_, generator=g).to(dev); mv = (torch.rand(C_, generator=g) + 0.5).to(dev)
+    keep = (torch.rand(R, C_, generator=g) > 0.3).to(torch.uint8).to(dev) if drop else None
+    zr, yr, mr, ir, mmr, mvr = _dense_ref(x, w, bias, gamma, beta, mm, mv, bn_mode, act, keep, 0.3)
+    wdev = w.t().contiguous() if trans else w
+    cnt = torch.zeros(256, device=dev, dtype=torch.int32)
+    mm_k, mv_k = mm.clone(), mv.clone()
+    for rep in range(2):           # the second call checks that the arrival counters were left at zero
+        if rep:
+            mm_k, mv_k = mm.clone(), mv.clone()
+        z, a, mean, invstd = _ops().dense_layer(x, wdev, trans=trans, bias=bias, gamma=gamma if bn_mode else None, beta=beta if bn_mode else None,
+                                             moving_mean=mm_k if bn_mode else None, moving_var=mv_k if bn_mode else None, bn_mode=bn_mode,
+                                             act=act, keep=keep, rate=0.3, counters=cnt)
+        torch.cuda.synchronize()
+        assert int(cnt.abs().sum()) == 0
+        assert torch.allclose(z.double(), zr, rtol=1e-5, atol=2e-5), float((z.double() - zr).abs().max())
+        assert torch.allclose(a.double(), yr, rtol=1e-4, atol=1e-4), float((a.double() - yr).abs().max())
+        if bn_mode:
+            assert torch.allclose(mean.double(), mr, rtol=1e-5, atol=1e-5) and torch.allclose(invstd.double(), ir, rtol=1e-4, atol=1e-5)
+            assert torch.allclose(mm_k.double(), mmr, rtol=1e-5, atol=1e-6) and torch.allclose(mv_k.double(), mvr, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("R,K,C_,bn_mode,act,drop", [(32, 1024, 512, 1, 1, True), (32, 256, 23, 0, 0, False), (6, 130, 300, 1, 1, False),
+                                                     (17, 64, 70, 2, 1, True)])
+def test_dense_bwd_matches_autograd(dev, R, K, C_, bn_mode, act, drop):
+    g = torch.Generator().manual_seed(R + K + C_)
+    x = torch.randn(R, K, generator=g, dtype=torch.float64)
+    w = (torch.randn(K, C_, generator=g, dtype=torch.float64) * 0.05).requires_grad_(True)
+    bias = torch.randn(C_, generator=g, dtype=torch.float64).requires_grad_(True)
+    gamma = (torch.rand(C_, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = torch.randn(C_, generator=g, dtype=torch.float64).requires_grad_(True)
+    mm = torch.randn(C_, generator=g, dtype=torch.float64); mv = torch.rand(C_, generator=g, dtype=torch.float64) + 0.5
+    keep = (torch.rand(R, C_, generator=g) > 0.3).to(torch.uint8) if drop else None
+    da = torch.randn(R, C_, generator=g, dtype=torch.float64)
+    z, y, mean, invstd, _, _ = _dense_ref(x, w, None if bn_mode else bias, gamma, beta, mm, mv, bn_mode, act, keep, 0.3)
+    zf = z.detach().float()
+    yf = (zf.double() - (mean if mean is not None else 0)) * (invstd * gamma if invstd is not None else 1) + (beta if bn_mode else 0)
+    if act and bool(((yf.abs() < 1e-4)).any()):
+        pytest.skip("a pre-activation sits on the ReLU boundary")
+    y.backward(da)
+    f = lambda t: None if t is None else t.detach().float().to(dev).contiguous()
+    dz, dg, db, dbias, dw = _ops().dense_bwd(f(da), f(z), f(x), gamma=f(gamma) if bn_mode else None, beta=f(beta) if bn_mode else None,
+                                          mean=f(mean), invstd=f(invstd), bn_mode=bn_mode, act=act, keep=None if keep is None else keep.to(dev), rate=0.3)
+    assert torch.allclose(dw.double().cpu(), w.grad, rtol=1e-4, atol=1e-4), float((dw.double().cpu() - w.grad).abs().max())
+    if bn_mode == 1:
+        assert torch.allclose(dg.double().cpu(), gamma.grad, rtol=1e-4, atol=1e-4) and torch.allclose(db.double().cpu(), beta.grad, rtol=1e-4, atol=1e-4)
+    if bn_mode == 0:
+        assert torch.allclose(dbias.double().cpu(), bias.grad, rtol=1e-4, atol=1e-4)
+    # dz: check through dx = dz . W^T against autograd's input gradient
+    x2 = x.clone().requires_grad_(True)
+    _, y2, _, _, _, _ = _dense_ref(x2, w.detach(), None if bn_mode else bias.detach(), gamma.detach(), beta.detach(), mm, mv, bn_mode, act, keep, 0.3)
+    y2.backward(da)
+    dx = dz.double().cpu() @ w.detach().t()
+    assert torch.allclose(dx, x2.grad, rtol=1e-4, atol=1e-4), float((dx - x2.grad).abs().max())
