@@ -287,8 +287,16 @@ int pn_model_forward(const pn_model_desc* d, const pn_model_io* io, pn_stream st
 int pn_model_backward(const pn_model_desc* d, const pn_model_io* io, const float* d_cls, const float* d_seg,
                       const float* d_R, pn_stream stream);
 
+/* --- keras.layers.Dropout masks for the two classification-head layers (PointNet.py:252-263 via DenseLayer :652-653)
+ * from a counter-based generator: keep[i] = u(seed, *step, i) >= rate, *step advanced by the call (device side, so a
+ * captured hipGraph draws fresh masks at every replay).  TF's generator stream cannot be reproduced; the parity tests
+ * feed masks in explicitly (pn_model_io.keep1/keep2). */
+int pn_dropout_masks(uint8_t* keep1, int64_t n1, uint8_t* keep2, int64_t n2, float rate, uint64_t seed, uint32_t* step,
+                     pn_stream stream);
+
 /* keras Adam + ExponentialDecay (pointnet_train.py:310-319) over a flat range; the step counter and the step size
- * stay on the device (iterations: int32; alpha_scratch: 2 floats) so the call can be replayed from a hipGraph.
+ * stay on the device (iterations: int32; alpha_scratch: 4 floats, zero-initialised once: [0] step size and [1] learning rate
+ * of the last call, [2] an internal ticket counter) so the call can be replayed from a hipGraph.
  * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce). */
 int pn_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int32_t* iterations,
                  float* alpha_scratch, float lr0, float decay_rate, float decay_steps, float beta1, float beta2,

@@ -86,6 +86,9 @@ int pn_dense_bwd(const float* da, const float* z, const float* x, int ldx, int R
   return dense_bwd_fused(da, z, x, ldx, R, K, C, gamma, beta, mean, invstd, bn_mode, act, keep, keep_scale, dz, dgamma, dbeta, dbias, dw,
                          S(stream));
 }
+int pn_dropout_masks(uint8_t* keep1, int64_t n1, uint8_t* keep2, int64_t n2, float rate, uint64_t seed, uint32_t* step, pn_stream stream) {
+  return dropout_masks(keep1, n1, keep2, n2, rate, seed, step, S(stream));
+}
 size_t pn_fps_workspace_bytes(int B, int N) { return fps_workspace_bytes(B, N); }
 int pn_fps(const float* xyz, int B, int N, int M, int start_idx, int32_t* idx_out, float* mindist, void* ws, size_t ws_bytes,
            pn_stream stream) {

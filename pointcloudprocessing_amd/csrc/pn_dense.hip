@@ -502,59 +502,82 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const float* __restrict
 }
 
 // Row softmax + keras SparseCategoricalCrossentropy (clip 1e-7, log, sparse_softmax_xent) + its gradient
-// w.r.t. the logits, one thread per row.  Used for the classification head (rows = B).
-//   loss_sum[0] += sum_r nll_r ; correct[0] += #(argmax == label)      (single block => plain stores)
+// w.r.t. the logits.  Used for the classification head (rows = B).  32 lanes per row (8 rows per pass of the single block);
+// every reduction is a fixed xor-shuffle tree, so the result does not depend on anything but the inputs.
+//   loss_sum[0] = sum_r nll_r ; correct[0] = #(argmax == label)
+__device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
+  return v;
+}
 __global__ __launch_bounds__(256) void softmax_xent_rows_kernel(const float* __restrict__ logits, int R, int C,
                                                                 const int* __restrict__ labels, float grad_scale,
                                                                 float* __restrict__ probs, float* __restrict__ dlogits,
                                                                 float* __restrict__ loss_sum, float* __restrict__ correct) {
-  __shared__ float rl[256], rc[256];
-  float myloss = 0.f, mycorr = 0.f;
-  for (int r = threadIdx.x; r < R; r += 256) {
+  __shared__ float rl[8], rc[8];
+  const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  float myloss = 0.f, mycorr = 0.f;       // lane 0 of each group accumulates its rows in row order
+  for (int r0 = 0; r0 < R; r0 += 8) {
+    const int r = r0 + grp;
+    if (r >= R) continue;                 // group-uniform (a group is half a wave; shuffles below use width 32)
     const float* l = logits + (long long)r * C;
     float mx = -INFINITY;
-    int am = 0;
-    for (int c = 0; c < C; ++c)
+    int am = 0x7fffffff;
+    for (int c = lane; c < C; c += 32)
       if (l[c] > mx) { mx = l[c]; am = c; }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) {    // max with the lowest index on ties, like the serial scan
+      const float om = __shfl_xor(mx, o, 32);
+      const int oa = __shfl_xor(am, o, 32);
+      if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
+    }
     float sum = 0.f;
-    for (int c = 0; c < C; ++c) sum += expf(l[c] - mx);
+    for (int c = lane; c < C; c += 32) sum += expf(l[c] - mx);
+    sum = grp_sum(sum);
     const float inv = 1.f / sum;
     float* p = probs + (long long)r * C;
-    for (int c = 0; c < C; ++c) p[c] = expf(l[c] - mx) * inv;
+    for (int c = lane; c < C; c += 32) p[c] = expf(l[c] - mx) * inv;
     if (labels) {
       const int y = labels[r];
       // keras: q = log(clip(p)), loss = -log_softmax(q)[y]
       float qs = 0.f;
-      for (int c = 0; c < C; ++c) qs += fminf(fmaxf(p[c], 1e-7f), 1.f - 1e-7f);
-      const float py = fminf(fmaxf(p[y], 1e-7f), 1.f - 1e-7f);
-      myloss += -(logf(py) - logf(qs));
-      mycorr += (am == y) ? 1.f : 0.f;
+      for (int c = lane; c < C; c += 32) qs += fminf(fmaxf(expf(l[c] - mx) * inv, 1e-7f), 1.f - 1e-7f);
+      qs = grp_sum(qs);
+      const float pyr = expf(l[y] - mx) * inv;
+      const float py = fminf(fmaxf(pyr, 1e-7f), 1.f - 1e-7f);
+      if (lane == 0) {
+        myloss += -(logf(py) - logf(qs));
+        mycorr += (am == y) ? 1.f : 0.f;
+      }
       if (dlogits) {
         // dL/dp_i = (s_i - [i==y]) / p_i inside the clip range, 0 outside; s = clip(p)/sum clip(p)
         float dot = 0.f;
-        for (int c = 0; c < C; ++c) {
-          const float pc = fminf(fmaxf(p[c], 1e-7f), 1.f - 1e-7f);
-          const bool inr = (p[c] > 1e-7f) && (p[c] < 1.f - 1e-7f);
-          const float dp = inr ? (pc / qs - (c == y ? 1.f : 0.f)) / p[c] : 0.f;
-          dot = fmaf(p[c], dp, dot);
+        for (int c = lane; c < C; c += 32) {
+          const float pc0 = expf(l[c] - mx) * inv;
+          const float pc = fminf(fmaxf(pc0, 1e-7f), 1.f - 1e-7f);
+          const bool inr = (pc0 > 1e-7f) && (pc0 < 1.f - 1e-7f);
+          const float dp = inr ? (pc / qs - (c == y ? 1.f : 0.f)) / pc0 : 0.f;
+          dot = fmaf(pc0, dp, dot);
         }
+        dot = grp_sum(dot);
         float* d = dlogits + (long long)r * C;
-        for (int c = 0; c < C; ++c) {
-          const float pc = fminf(fmaxf(p[c], 1e-7f), 1.f - 1e-7f);
-          const bool inr = (p[c] > 1e-7f) && (p[c] < 1.f - 1e-7f);
-          const float dp = inr ? (pc / qs - (c == y ? 1.f : 0.f)) / p[c] : 0.f;
-          d[c] = grad_scale * p[c] * (dp - dot);
+        for (int c = lane; c < C; c += 32) {
+          const float pc0 = expf(l[c] - mx) * inv;
+          const float pc = fminf(fmaxf(pc0, 1e-7f), 1.f - 1e-7f);
+          const bool inr = (pc0 > 1e-7f) && (pc0 < 1.f - 1e-7f);
+          const float dp = inr ? (pc / qs - (c == y ? 1.f : 0.f)) / pc0 : 0.f;
+          d[c] = grad_scale * pc0 * (dp - dot);
         }
       }
     }
   }
-  rl[threadIdx.x] = myloss; rc[threadIdx.x] = mycorr;
+  if (lane == 0) { rl[grp] = myloss; rc[grp] = mycorr; }
   __syncthreads();
   if (threadIdx.x == 0 && labels) {
-    float a = 0.f, b = 0.f;
-    for (int i = 0; i < 256; ++i) { a += rl[i]; b += rc[i]; }
-    if (loss_sum) loss_sum[0] = a;
-    if (correct) correct[0] = b;
+    float x = 0.f, y = 0.f;
+    for (int i = 0; i < 8; ++i) { x += rl[i]; y += rc[i]; }
+    if (loss_sum) loss_sum[0] = x;
+    if (correct) correct[0] = y;
   }
 }
 

@@ -50,6 +50,8 @@ int dense_bwd_pre(const float* da, const float* z, int R, int C, const float* ga
                   float* dbeta, float* dbias, hipStream_t st);
 int dense_wgrad(const float* x, int ldx, const float* dz, int R, int K, int C, float* dw, hipStream_t st);
 int transpose(const float* in, int R, int C, float* out, hipStream_t st);
+int weights_prep3(const float* const* w, const int* K, const int* C, void* const* hi, void* const* lo, unsigned* zero_p, int zero_n,
+                  hipStream_t st);
 int transpose2(const float* in, int R, int C, const float* rowscale, float* out, float* out2, hipStream_t st);
 int softmax_xent_rows(const float* logits, int R, int C, const int* labels, float grad_scale, float* probs, float* dlogits,
                       float* loss_sum, float* correct, hipStream_t st);
@@ -66,7 +68,7 @@ int sum_partials(const float* part, int n, int stride, int elems, float* out, hi
 // pn_maxbwd.hip
 int maxbwd_prep(const float* dg, const float* g, const float* zstar, int B, int C, const float* mean, const float* invstd,
                 const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege, float* f, float* dgamma,
-                float* dbeta, hipStream_t st);
+                float* dbeta, const float* W, int K, float* Wt, float* We, hipStream_t st);
 int colsum_lazy(const pn_operand* x, int B, int N, int C, float* part, hipStream_t st);
 int maxbwd_dw(const pn_operand* x, const int* arg, const float* hs, int B, int N, int K, int C, const float* a1, const float* f,
               const float* e, const float* GW, float* dW, hipStream_t st);
@@ -94,6 +96,12 @@ int fold3_bwd(const float* dWeff, const float* R, const float* W, int B, int C, 
 int fill_eye3(float* out, int B, hipStream_t st);
 int axpy(const float* x, float a, float* y, long long n, hipStream_t st);
 int zero_fill(float* p, long long n, hipStream_t st);
+int zero_fill2(float* p, long long n, float* p2, int n2, hipStream_t st);   // + a second, small region
+int add2(const float* a, const float* b, float* out, long long n, hipStream_t st);
+int adam_fused(float* p, const float* g, float* m, float* v, long long n, int* iterations, float lr0, float decay_rate, float decay_steps,
+               float beta1, float beta2, float eps, float grad_scale, float* scratch, hipStream_t st);
+int dropout_masks(unsigned char* k1, long long n1, unsigned char* k2, long long n2, float rate, unsigned long long seed, unsigned* step,
+                  hipStream_t st);
 int cloud_bias_grad(const float* bwd_part, const float* fwd_part, int B, int tpc, int N, int C, const float* ca, const float* cb,
                     const float* cc, float* dgb, hipStream_t st);
 

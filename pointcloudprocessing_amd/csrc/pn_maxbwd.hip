@@ -23,8 +23,11 @@ __global__ __launch_bounds__(256) void maxbwd_prep_kernel(const float* __restric
                                                           const float* __restrict__ scale, int batch_stats, double inv_count,
                                                           float* __restrict__ hs, float* __restrict__ e, float* __restrict__ nege,
                                                           float* __restrict__ f, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta) {
+                                                          float* __restrict__ dbeta, const float* __restrict__ W, int K,
+                                                          float* __restrict__ Wt, float* __restrict__ We) {
   __shared__ double red[8][2][32];
+  __shared__ float neg_s[32];
+  __shared__ float tt[32][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + tx;
   float sc = 0.f, mu = 0.f, is = 0.f;
@@ -42,18 +45,39 @@ __global__ __launch_bounds__(256) void maxbwd_prep_kernel(const float* __restric
   red[ty][0][tx] = S1;
   red[ty][1][tx] = S2;
   __syncthreads();
-  if (ty != 0 || c >= C) return;
-  S1 = 0.0; S2 = 0.0;
-  for (int q = 0; q < 8; ++q) { S1 += red[q][0][tx]; S2 += red[q][1][tx]; }
-  if (batch_stats) {
-    if (dgamma) dgamma[c] = (float)S2;
-    if (dbeta) dbeta[c] = (float)S1;
-    const double ee = (double)sc * (double)is * S2 * inv_count;
-    e[c] = (float)ee;
-    nege[c] = (float)(-ee);
-    f[c] = (float)(-(double)sc * S1 * inv_count + ee * (double)mu);
-  } else {
-    e[c] = 0.f; nege[c] = 0.f; f[c] = 0.f;
+  if (ty == 0) {
+    float ng = 0.f;
+    if (c < C) {
+      S1 = 0.0; S2 = 0.0;
+      for (int q = 0; q < 8; ++q) { S1 += red[q][0][tx]; S2 += red[q][1][tx]; }
+      if (batch_stats) {
+        if (dgamma) dgamma[c] = (float)S2;
+        if (dbeta) dbeta[c] = (float)S1;
+        const double ee = (double)sc * (double)is * S2 * inv_count;
+        e[c] = (float)ee;
+        ng = (float)(-ee);
+        nege[c] = ng;
+        f[c] = (float)(-(double)sc * S1 * inv_count + ee * (double)mu);
+      } else {
+        e[c] = 0.f; nege[c] = 0.f; f[c] = 0.f;
+      }
+    }
+    neg_s[tx] = ng;
+  }
+  if (!W) return;
+  // channel-major copies of this block's 32 kernel columns: Wt[c][k] = W[k][c], We[c][k] = -e[c] W[k][c]
+  const int c0 = blockIdx.x * 32;
+  for (int k0 = 0; k0 < K; k0 += 32) {
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+      if (k0 + i < K && c0 + tx < C) tt[i][tx] = W[(long long)(k0 + i) * C + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+      if (c0 + i < C && k0 + tx < K) {
+        const float v = tt[tx][i];
+        Wt[(long long)(c0 + i) * K + k0 + tx] = v;
+        We[(long long)(c0 + i) * K + k0 + tx] = neg_s[i] * v;
+      }
   }
 }
 
@@ -205,10 +229,11 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restri
 
 int maxbwd_prep(const float* dg, const float* g, const float* zstar, int B, int C, const float* mean, const float* invstd,
                 const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege, float* f, float* dgamma,
-                float* dbeta, hipStream_t st) {
+                float* dbeta, const float* W, int K, float* Wt, float* We, hipStream_t st) {
   PN_CHECK_ARG(dg && g && zstar && mean && invstd && scale && hs && e && nege && f, "maxbwd_prep: null pointer");
+  PN_CHECK_ARG(!W || (Wt && We && K > 0), "maxbwd_prep: the transposed copies need Wt and We");
   hipLaunchKernelGGL(maxbwd_prep_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, dg, g, zstar, B, C, mean, invstd, scale, batch_stats,
-                     1.0 / (double)count, hs, e, nege, f, dgamma, dbeta);
+                     1.0 / (double)count, hs, e, nege, f, dgamma, dbeta, W, K, Wt, We);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -423,7 +423,6 @@ struct Run {
   }
   int fwd_max(CL& l, ML& m, const LRef& r, const pn_operand& x, int prof_slot) {
     m.sgn = p(r.gamma);   // only the sign is used (sgn(gamma) = sgn(BN scale))
-    PN_TRY(weights_prep(p(r.kernel), r.cin, r.cout, m.wb_hi, prec == PN_PREC_BF16X3 ? m.wb_lo : nullptr, st));
     void** ev = io.prof_events;
     if (ev && ev[2 * prof_slot]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot]), st);
     PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.sgn, m.pmax, m.pidx, bn_batch(r.block) ? l.part : nullptr,
@@ -460,7 +459,14 @@ struct Run {
   pn_operand x64op() const { return d.vanilla ? lazy(w.m12) : plain(w.X64, 64); }
 
   int forward() {
-    PN_TRY(zero_fill(reinterpret_cast<float*>(w.dcount), DENSE_MAX_COUNTERS, st));   // arrival counters of the dense layers
+    {   // bf16 channel-major copies of the three 128->1024 kernels (they only change in the optimizer) + the dense layers' arrival counters
+      const bool x3 = prec == PN_PREC_BF16X3;
+      const float* ws[3] = {d.vanilla ? nullptr : p(L.iT.c3.kernel), d.vanilla ? nullptr : p(L.fT.c3.kernel), p(L.m23.kernel)};
+      const int Ks[3] = {128, 128, 128}, Cs[3] = {1024, 1024, 1024};
+      void* his[3] = {d.vanilla ? nullptr : w.iT.m3.wb_hi, d.vanilla ? nullptr : w.fT.m3.wb_hi, w.mm23.wb_hi};
+      void* los[3] = {(x3 && !d.vanilla) ? w.iT.m3.wb_lo : nullptr, (x3 && !d.vanilla) ? w.fT.m3.wb_lo : nullptr, x3 ? w.mm23.wb_lo : nullptr};
+      PN_TRY(weights_prep3(ws, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS, st));
+    }
     PN_TRY(normalize(io.pc, B, N, w.pcn, w.cent, w.scl, st));
     if (!d.vanilla) {
       PN_TRY(fwd_tnet(w.iT, L.iT, nullptr));
@@ -572,8 +578,9 @@ struct Run {
     const int K = r.cin, C = r.cout;
     const int bs = bn_batch(r.block) ? 1 : 0;
     const bool wg = tr(r.block) && G;
+    // + the channel-major copies Wt, We = -e (.) Wt used below, written by the same launch
     PN_TRY(maxbwd_prep(dG, m.g, m.zstar, B, C, l.mean, l.invstd, l.scale, bs, M, m.hs, m.e, m.nege, m.f, wg ? gr(r.gamma) : nullptr,
-                       wg ? gr(r.beta) : nullptr, st));
+                       wg ? gr(r.beta) : nullptr, p(r.kernel), K, m.Wt, m.We, st));
     if (wg) {
       const ML mm = m;
       float* dw = gr(r.kernel);
@@ -590,7 +597,6 @@ struct Run {
     }
     // Pm[k'][k] = sum_c (-e_c) W[k'][c] W[k][c]: the contraction runs over the 1024 channels, so it is laid out as a
     // weight-gradient problem over "rows" c (16 slabs of 64 channels -> 16 workgroups) instead of one 128x128 tile
-    PN_TRY(transpose2(p(r.kernel), K, C, m.nege, m.Wt, m.We, st));
     PN_TRY(wgrad_general(plain(m.We, K), plain(m.Wt, K), 1, C, K, K, m.Pm, false, PN_PREC_BF16X3));
     PN_TRY(maxbwd_q(p(r.kernel), m.f, K, C, m.q, st));
     PN_TRY(maxbwd_scatter(m.arg, m.hs, m.Wt, m.q, B, N, K, C, m.D, st));
@@ -664,8 +670,7 @@ struct Run {
       set_error("pn_model_backward: grads buffer is NULL");
       return PN_ERR_INVALID_ARGUMENT;
     }
-    PN_TRY(zero_fill(G, L.total, st));
-    PN_TRY(zero_fill(reinterpret_cast<float*>(w.dcount), DENSE_MAX_COUNTERS, st));
+    PN_TRY(zero_fill2(G, L.total, reinterpret_cast<float*>(w.dcount), DENSE_MAX_COUNTERS, st));
     const pn_operand x64 = x64op();
     const float* Ws1 = p(L.s1.kernel);
     const bool fused = io.labels_cls != nullptr || io.labels_seg != nullptr;
@@ -716,9 +721,7 @@ struct Run {
       have_dGcls = true;
     }
     float* dG = w.mm23.dG;
-    PN_TRY(zero_fill(dG, (long long)B * 1024, st));
-    if (have_dGcls) PN_TRY(axpy(w.dGcls, 1.f, dG, (long long)B * 1024, st));
-    if (have_dGseg) PN_TRY(axpy(w.dGseg, 1.f, dG, (long long)B * 1024, st));
+    PN_TRY(add2(have_dGcls ? w.dGcls : nullptr, have_dGseg ? w.dGseg : nullptr, dG, (long long)B * 1024, st));
 
     const bool have_R_grad = !d.vanilla && (d_R != nullptr || (io.se3 != nullptr && io.loss_weights[2] != 0.f) || d.reg_in);
     const bool trunk = has_seg || has_cls || (!d.vanilla && d.reg_feat);
@@ -904,8 +907,7 @@ int pn_adam_step(float* params, const float* grads, float* m, float* v, int64_t 
                  float decay_rate, float decay_steps, float beta1, float beta2, float eps, float grad_scale, pn_stream stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   PN_CHECK_ARG(iterations && alpha_scratch, "pn_adam_step: null pointer");
-  PN_TRY(adam_schedule(iterations, lr0, decay_rate, decay_steps, beta1, beta2, alpha_scratch, alpha_scratch + 1, st));
-  return adam(params, grads, m, v, n, alpha_scratch, beta1, beta2, eps, grad_scale, st);
+  return adam_fused(params, grads, m, v, n, iterations, lr0, decay_rate, decay_steps, beta1, beta2, eps, grad_scale, alpha_scratch, st);
 }
 
 }  // extern "C"

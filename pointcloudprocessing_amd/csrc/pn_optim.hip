@@ -19,6 +19,43 @@ __global__ void adam_schedule_kernel(int* __restrict__ iterations, float lr0, fl
   *iterations = it + 1;
 }
 
+// Schedule + update in one launch: every block derives the step size from optimizer.iterations itself (the same fp64
+// expression in every block, so all agree); the block that draws the last ticket advances the counter and publishes
+// [step size, learning rate] for the host.  scratch: [0] step size, [1] learning rate, [2] ticket counter (uint32, zero).
+__global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, long long n, int* __restrict__ iterations, float lr0,
+                                                         float decay_rate, float decay_steps, float beta1, float beta2, float eps,
+                                                         float grad_scale, float* __restrict__ scratch) {
+  __shared__ float sh[2];
+  if (threadIdx.x == 0) {
+    const int it = *iterations;           // optimizer.iterations before this update
+    const double lr = (double)lr0 * pow((double)decay_rate, (double)it / (double)decay_steps);
+    const double t = (double)(it + 1);
+    sh[0] = (float)(lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+    sh[1] = (float)lr;
+  }
+  __syncthreads();
+  const float alpha = sh[0];
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float gi = g[i] * grad_scale;
+    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
+    const float vi = v[i] + (gi * gi - v[i]) * (1.f - beta2);
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= mi * alpha / (sqrtf(vi) + eps);
+  }
+  if (threadIdx.x == 0) {
+    unsigned* ticket = reinterpret_cast<unsigned*>(scratch + 2);
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == gridDim.x - 1) {             // every block has read *iterations by now: only now may it move
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *iterations = *iterations + 1;
+      scratch[0] = sh[0];
+      scratch[1] = sh[1];
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, const float* __restrict__ alpha_p, float beta1,
                                                    float beta2, float eps, float grad_scale) {
@@ -168,6 +205,58 @@ int adam(float* p, const float* g, float* m, float* v, long long n, const float*
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
+int adam_fused(float* p, const float* g, float* m, float* v, long long n, int* iterations, float lr0, float decay_rate, float decay_steps,
+               float beta1, float beta2, float eps, float grad_scale, float* scratch, hipStream_t st) {
+  PN_CHECK_ARG(p && g && m && v && iterations && scratch && n > 0, "pn_adam_step: bad arguments");
+  const long long blocks = cdivll(n, 1024);
+  hipLaunchKernelGGL(adam_fused_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, p, g, m, v, n, iterations, lr0,
+                     decay_rate, decay_steps, beta1, beta2, eps, grad_scale, scratch);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// Inverted-dropout keep masks for the two classification-head layers from a counter-based generator (no state but a step
+// counter on the device, so a captured graph draws fresh masks at every replay): keep = u(seed, step, index) >= rate.
+// One block; the counter moves once everyone has read it.  (keras draws from TF's stateful generator; there is no stream
+// to be bit-compatible with, so masks are an INPUT of the parity tests.)
+__device__ __forceinline__ unsigned mix32(unsigned x) {      // murmur3 finaliser
+  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
+  return x;
+}
+__global__ __launch_bounds__(1024) void dropout_masks_kernel(unsigned char* __restrict__ k1, long long n1, unsigned char* __restrict__ k2,
+                                                             long long n2, float rate, unsigned seed_lo, unsigned seed_hi,
+                                                             unsigned* __restrict__ step) {
+  const unsigned st = *step;
+  __syncthreads();
+  const unsigned thr = (unsigned)fminf(rate * 16777216.f, 16777216.f);     // compare on 24 bits
+  const unsigned base = mix32(seed_lo ^ mix32(seed_hi + 0x9e3779b9u * (st + 1u)));
+  for (long long i = threadIdx.x; i < n1 + n2; i += 1024) {
+    const unsigned h = mix32(base + 0x9e3779b9u * (unsigned)i) ^ mix32(seed_hi ^ (unsigned)(i >> 32) ^ (unsigned)i * 0x7feb352du);
+    const unsigned char keep = ((h >> 8) >= thr) ? 1 : 0;
+    if (i < n1) k1[i] = keep; else k2[i - n1] = keep;
+  }
+  if (threadIdx.x == 0) *step = st + 1u;
+}
+int dropout_masks(unsigned char* k1, long long n1, unsigned char* k2, long long n2, float rate, unsigned long long seed, unsigned* step,
+                  hipStream_t st) {
+  PN_CHECK_ARG(step && n1 >= 0 && n2 >= 0 && (n1 == 0 || k1) && (n2 == 0 || k2) && rate >= 0.f && rate < 1.f, "pn_dropout_masks: bad arguments");
+  hipLaunchKernelGGL(dropout_masks_kernel, dim3(1), dim3(1024), 0, st, k1, n1, k2, n2, rate, (unsigned)seed, (unsigned)(seed >> 32), step);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// out = a + b (either may be NULL = zeros)
+__global__ __launch_bounds__(256) void add2_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, long long n) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (a ? a[i] : 0.f) + (b ? b[i] : 0.f);
+}
+int add2(const float* a, const float* b, float* out, long long n, hipStream_t st) {
+  PN_CHECK_ARG(out && n > 0, "add2: bad arguments");
+  hipLaunchKernelGGL(add2_kernel, dim3((unsigned)cdivll(n, 256)), dim3(256), 0, st, a, b, out, n);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
 int mse(const float* R, const float* T, int n, float gscale, float* dR, float* loss_sum, hipStream_t st) {
   hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, st, R, T, n, gscale, dR, loss_sum);
   PN_CHECK_LAUNCH();
@@ -198,7 +287,9 @@ int fold3_bwd(const float* dWeff, const float* R, const float* W, int B, int C, 
 // Zero fill as an ordinary kernel.  hipMemsetAsync is avoided on purpose: captured into a hipGraph (ROCm 7.2) the
 // 16 MiB memset node of the gradient buffer replayed with a garbage fill pattern once another model had launched
 // work between two replays (tools/graph_hunt.py); a kernel node has no such state.
-__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, long long n) {
+__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, long long n, float* __restrict__ p2, int n2) {
+  if (blockIdx.x == 0 && p2)
+    for (int i = threadIdx.x; i < n2; i += 256) p2[i] = 0.f;
   const long long n4 = n >> 2;
   float4* p4 = reinterpret_cast<float4*>(p);
   const long long stride = (long long)gridDim.x * 256;
@@ -206,11 +297,13 @@ __global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, l
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = 0.f;
 }
 
-int zero_fill(float* p, long long n, hipStream_t st) {
+int zero_fill2(float* p, long long n, float* p2, int n2, hipStream_t st);
+int zero_fill(float* p, long long n, hipStream_t st) { return zero_fill2(p, n, nullptr, 0, st); }
+int zero_fill2(float* p, long long n, float* p2, int n2, hipStream_t st) {
   PN_CHECK_ARG(p && n >= 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0, "zero_fill: null or unaligned buffer");
-  if (n == 0) return PN_OK;
+  if (n == 0 && !p2) return PN_OK;
   const long long blocks = cdivll(cdivll(n, 4), 256);
-  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, p, n);
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks < 2048 ? blocks : 2048))), dim3(256), 0, st, p, n, p2, n2);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

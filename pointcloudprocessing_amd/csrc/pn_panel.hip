@@ -38,6 +38,55 @@ __global__ __launch_bounds__(256) void weights_prep_kernel(const float* __restri
     }
 }
 
+// the three max-pooled layers' kernels in one launch (blockIdx.z picks the matrix); block (0,0,0) also clears `zero_n` words
+struct Prep3Args {
+  const float* w[3];
+  __bf16* hi[3];
+  __bf16* lo[3];
+  int K[3], C[3];
+  unsigned* zero_p;
+  int zero_n;
+};
+__global__ __launch_bounds__(256) void weights_prep3_kernel(const Prep3Args a) {
+  __shared__ float t[32][33];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && a.zero_p)
+    for (int i = threadIdx.x; i < a.zero_n; i += 256) a.zero_p[i] = 0u;
+  const int z = blockIdx.z;
+  const float* w = a.w[z];
+  if (!w) return;
+  const int K = a.K[z], C = a.C[z];
+  __bf16* hi = a.hi[z];
+  __bf16* lo = a.lo[z];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;      // bx over C, by over K
+  if (bx >= C || by >= K) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8)
+    if (by + i < K && bx + tx < C) t[i][tx] = w[(long long)(by + i) * C + bx + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (bx + i < C && by + tx < K) {
+      const float v = t[tx][i];
+      const __bf16 h = (__bf16)v;
+      hi[(long long)(bx + i) * K + by + tx] = h;
+      if (lo) lo[(long long)(bx + i) * K + by + tx] = (__bf16)(v - (float)h);
+    }
+}
+int weights_prep3(const float* const* w, const int* K, const int* C, void* const* hi, void* const* lo, unsigned* zero_p, int zero_n,
+                  hipStream_t st) {
+  Prep3Args a;
+  int mk = 1, mc = 1;
+  for (int i = 0; i < 3; ++i) {
+    a.w[i] = w[i]; a.K[i] = K[i]; a.C[i] = C[i];
+    a.hi[i] = reinterpret_cast<__bf16*>(hi[i]); a.lo[i] = reinterpret_cast<__bf16*>(lo[i]);
+    PN_CHECK_ARG(!w[i] || (hi[i] && K[i] > 0 && C[i] > 0), "weights_prep3: bad arguments");
+    if (w[i]) { mk = K[i] > mk ? K[i] : mk; mc = C[i] > mc ? C[i] : mc; }
+  }
+  a.zero_p = zero_p; a.zero_n = zero_n;
+  hipLaunchKernelGGL(weights_prep3_kernel, dim3(cdiv(mc, 32), cdiv(mk, 32), 3), dim3(256), 0, st, a);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
 int weights_prep(const float* w, int K, int C, void* hi, void* lo, hipStream_t st) {
   PN_CHECK_ARG(w && hi && K > 0 && C > 0, "pn_weights_prep: bad arguments");
   hipLaunchKernelGGL(weights_prep_kernel, dim3(cdiv(C, 32), cdiv(K, 32)), dim3(256), 0, st, w, K, C, reinterpret_cast<__bf16*>(hi),

@@ -20,7 +20,13 @@ from typing import Optional, Sequence
 
 import torch
 
+from ._lib import check, current_stream, lib, ptr
 from .optim import KerasAdam
+
+
+def rank_salt() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() + 1 if dist.is_available() and dist.is_initialized() else 1
 
 
 class TrainStep:
@@ -40,6 +46,8 @@ class TrainStep:
         self.y_seg = torch.zeros(batch, points, dtype=torch.int32, device=dev)
         self.se3 = torch.zeros(batch, 3, 3, device=dev)
         self.keep = (torch.ones(batch, 512, dtype=torch.uint8, device=dev), torch.ones(batch, 256, dtype=torch.uint8, device=dev))
+        self._mask_seed = int(torch.randint(0, 2**62, (1,)).item()) ^ (rank_salt() << 20)   # per process / rank
+        self._mask_step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.mode = "eager"
         self._g1 = self._g2 = None
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
@@ -55,9 +63,9 @@ class TrainStep:
     # -- pieces ---------------------------------------------------------------------------------------------
     def _fwd_bwd(self):
         rate = self.model._dropout_rate
-        if rate > 0:
-            self.keep[0].copy_(torch.rand(self.B, 512, device=self.dev) >= rate)
-            self.keep[1].copy_(torch.rand(self.B, 256, device=self.dev) >= rate)
+        if rate > 0:        # one native launch; the step counter lives on the device, so graph replays draw fresh masks
+            check(lib().pn_dropout_masks(ptr(self.keep[0]), self.keep[0].numel(), ptr(self.keep[1]), self.keep[1].numel(), rate,
+                                         self._mask_seed, ptr(self._mask_step), current_stream()), "pn_dropout_masks")
         self.model._aux_stream = self.aux_stream
         try:
             self.model.fused_loss_step(self.pc, self.y_cls, self.y_seg, self.se3, self.lw, keep=self.keep if rate > 0 else None)

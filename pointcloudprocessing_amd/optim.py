@@ -1,6 +1,6 @@
 """keras.optimizers.Adam + ExponentialDecay (reference pointnet_train.py:310-319) on the model's flat buffers.
 
-One native launch pair per step (schedule + update, pn_adam_step); the step counter and step size live on the
+One native launch per step (schedule + update fused, pn_adam_step); the step counter and step size live on the
 device, so a training step captured in a hipGraph replays with the right learning rate.
 """
 from __future__ import annotations
@@ -20,7 +20,7 @@ class KerasAdam:
         self.m = torch.zeros_like(params_flat)
         self.v = torch.zeros_like(params_flat)
         self.iterations = torch.zeros(1, dtype=torch.int32, device=params_flat.device)
-        self._alpha = torch.zeros(2, dtype=torch.float32, device=params_flat.device)   # [step size, learning rate]
+        self._alpha = torch.zeros(4, dtype=torch.float32, device=params_flat.device)   # [step size, learning rate, ticket, -]
         self.lr0, self.decay_steps, self.decay_rate = float(learning_rate), float(decay_steps), float(decay_rate)
         self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
 

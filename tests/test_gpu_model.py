@@ -382,7 +382,7 @@ def test_boundary_buffers_are_never_overrun(dev, vanilla):
     t_params = carve("params", m.params_flat.data)
     t_grads = carve("grads", nbytes=P * 4)
     t_m, t_v = carve("adam_m", torch.zeros(P)), carve("adam_v", torch.zeros(P))
-    t_it, t_al = carve("iterations", torch.zeros(1, dtype=torch.int32)), carve("alpha", torch.zeros(2))
+    t_it, t_al = carve("iterations", torch.zeros(1, dtype=torch.int32)), carve("alpha", torch.zeros(4))
     t_sc = carve("scalars", torch.zeros(16))
     t_cls, t_seg, t_R = carve("out_cls", nbytes=B * 23 * 4), carve("out_seg", nbytes=B * N * 12 * 4), carve("out_R", nbytes=B * 9 * 4)
     snap = {k: tin[k].clone() for k in tin}

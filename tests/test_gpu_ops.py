@@ -406,3 +406,29 @@ def test_dense_bwd_matches_autograd(dev, R, K, C_, bn_mode, act, drop):
     y2.backward(da)
     dx = dz.double().cpu() @ w.detach().t()
     assert torch.allclose(dx, x2.grad, rtol=1e-4, atol=1e-4), float((dx - x2.grad).abs().max())
+
+
+def test_dropout_masks_counter_based(dev):
+    """keep-probability, independence of the two layers, fresh masks per call, reproducible from (seed, step)"""
+    import ctypes as C
+    L = _lib()
+    B = 64
+    k1 = torch.zeros(B, 512, dtype=torch.uint8, device=dev); k2 = torch.zeros(B, 256, dtype=torch.uint8, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def draw(seed):
+        L.check(L.lib().pn_dropout_masks(L.ptr(k1), k1.numel(), L.ptr(k2), k2.numel(), 0.3, seed, L.ptr(step), L.current_stream()), "pn_dropout_masks")
+        torch.cuda.synchronize()
+        return k1.clone(), k2.clone()
+    a1, a2 = draw(1234)
+    b1, b2 = draw(1234)
+    assert int(step) == 2 and set(a1.unique().tolist()) <= {0, 1}
+    assert abs(float(a1.float().mean()) - 0.7) < 0.02 and abs(float(a2.float().mean()) - 0.7) < 0.03
+    assert 0.35 < float((a1 != b1).float().mean()) < 0.49          # 2 * 0.3 * 0.7 = 0.42 when independent
+    assert 0.35 < float((a1[:, :256] != a2).float().mean()) < 0.49
+    step.zero_()
+    c1, c2 = draw(1234)
+    assert torch.equal(a1, c1) and torch.equal(a2, c2)
+    step.zero_()
+    d1, _ = draw(99)
+    assert not torch.equal(a1, d1)
