@@ -295,9 +295,13 @@ int pn_dropout_masks(uint8_t* keep1, int64_t n1, uint8_t* keep2, int64_t n2, flo
                      pn_stream stream);
 
 /* keras Adam + ExponentialDecay (pointnet_train.py:310-319) over a flat range; the step counter and the step size
- * stay on the device (iterations: int32; alpha_scratch: 4 floats, zero-initialised once: [0] step size and [1] learning rate
- * of the last call, [2] an internal ticket counter) so the call can be replayed from a hipGraph.
+ * stay on the device (iterations: int32; alpha_scratch: 4 floats, initialised by pn_adam_prepare: [0] step size and [1] learning rate
+ * for the current *iterations, kept current by every pn_adam_step, [2] an internal ticket counter) so the call can be replayed from a hipGraph.
  * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce). */
+/* evaluate the schedule for the CURRENT *iterations into alpha_scratch and clear the ticket: once after allocating the
+ * state, and again whenever *iterations is set from outside (checkpoint restore) */
+int pn_adam_prepare(const int32_t* iterations, float* alpha_scratch, float lr0, float decay_rate, float decay_steps, float beta1,
+                    float beta2, pn_stream stream);
 int pn_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int32_t* iterations,
                  float* alpha_scratch, float lr0, float decay_rate, float decay_steps, float beta1, float beta2,
                  float eps, float grad_scale, pn_stream stream);

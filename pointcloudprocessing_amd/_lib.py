@@ -95,6 +95,7 @@ SIGNATURES = {
     "pn_model_ws_entry": (_I, [_DESC, _I, _I, _I, _I, C.c_char_p, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pn_model_forward": (_I, [_DESC, _IO, _P]),
     "pn_model_backward": (_I, [_DESC, _IO, _P, _P, _P, _P]),
+    "pn_adam_prepare": (_I, [_P, _P, _F, _F, _F, _F, _F, _P]),
     "pn_adam_step": (_I, [_P, _P, _P, _P, _I64, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P]),
 }
 

@@ -98,6 +98,8 @@ int axpy(const float* x, float a, float* y, long long n, hipStream_t st);
 int zero_fill(float* p, long long n, hipStream_t st);
 int zero_fill2(float* p, long long n, float* p2, int n2, hipStream_t st);   // + a second, small region
 int add2(const float* a, const float* b, float* out, long long n, hipStream_t st);
+int adam_prepare(const int* iterations, float lr0, float decay_rate, float decay_steps, float beta1, float beta2, float* scratch,
+                 hipStream_t st);
 int adam_fused(float* p, const float* g, float* m, float* v, long long n, int* iterations, float lr0, float decay_rate, float decay_steps,
                float beta1, float beta2, float eps, float grad_scale, float* scratch, hipStream_t st);
 int dropout_masks(unsigned char* k1, long long n1, unsigned char* k2, long long n2, float rate, unsigned long long seed, unsigned* step,

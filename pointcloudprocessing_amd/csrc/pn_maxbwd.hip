@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void maxbwd_prep_kernel(const float* __restric
                                                           float* __restrict__ Wt, float* __restrict__ We) {
   __shared__ double red[8][2][32];
   __shared__ float neg_s[32];
-  __shared__ float tt[32][33];
+  __shared__ float tt[128][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + tx;
   float sc = 0.f, mu = 0.f, is = 0.f;
@@ -67,17 +67,31 @@ __global__ __launch_bounds__(256) void maxbwd_prep_kernel(const float* __restric
   if (!W) return;
   // channel-major copies of this block's 32 kernel columns: Wt[c][k] = W[k][c], We[c][k] = -e[c] W[k][c]
   const int c0 = blockIdx.x * 32;
-  for (int k0 = 0; k0 < K; k0 += 32) {
+  for (int k0 = 0; k0 < K; k0 += 128) {           // 128 kernel rows per pass: 16 loads in flight per thread, one barrier pair
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = k0 + ty + 8 * i;
+      v[i] = W[(long long)min(k, K - 1) * C + min(c0 + tx, C - 1)];
+    }
     __syncthreads();
-    for (int i = ty; i < 32; i += 8)
-      if (k0 + i < K && c0 + tx < C) tt[i][tx] = W[(long long)(k0 + i) * C + c0 + tx];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) tt[ty + 8 * i][tx] = v[i];
     __syncthreads();
-    for (int i = ty; i < 32; i += 8)
-      if (c0 + i < C && k0 + tx < K) {
-        const float v = tt[tx][i];
-        Wt[(long long)(c0 + i) * K + k0 + tx] = v;
-        We[(long long)(c0 + i) * K + k0 + tx] = neg_s[i] * v;
+    // thread -> (channel i = tid / 8, 16 consecutive k starting at (tid % 8) * 16): 64-byte runs along k
+    const int ci = threadIdx.x >> 3, kk0 = (threadIdx.x & 7) * 16;
+    if (c0 + ci < C) {
+      const float ng = neg_s[ci];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int k = k0 + kk0 + q;
+        if (k < K) {
+          const float t = tt[kk0 + q][ci];
+          Wt[(long long)(c0 + ci) * K + k] = t;
+          We[(long long)(c0 + ci) * K + k] = ng * t;
+        }
       }
+    }
   }
 }
 

@@ -19,23 +19,27 @@ __global__ void adam_schedule_kernel(int* __restrict__ iterations, float lr0, fl
   *iterations = it + 1;
 }
 
-// Schedule + update in one launch: every block derives the step size from optimizer.iterations itself (the same fp64
-// expression in every block, so all agree); the block that draws the last ticket advances the counter and publishes
-// [step size, learning rate] for the host.  scratch: [0] step size, [1] learning rate, [2] ticket counter (uint32, zero).
+// Schedule + update in one launch.  scratch: [0] step size and [1] learning rate for the CURRENT optimizer.iterations (written by
+// adam_prepare at construction / after a restore, then kept current by this kernel), [2] ticket counter (uint32, zero).
+// The block that draws the last ticket -- every block has used scratch[0] by then -- advances the counter and evaluates the
+// schedule for the next step, so the fp64 pow()s are paid by one thread per step, off everyone else's path.
+__device__ __forceinline__ void adam_schedule_eval(int it, float lr0, float decay_rate, float decay_steps, float beta1, float beta2,
+                                                   float* __restrict__ scratch) {
+  const double lr = (double)lr0 * pow((double)decay_rate, (double)it / (double)decay_steps);
+  const double t = (double)(it + 1);
+  scratch[0] = (float)(lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+  scratch[1] = (float)lr;
+}
+__global__ void adam_prepare_kernel(const int* __restrict__ iterations, float lr0, float decay_rate, float decay_steps, float beta1,
+                                    float beta2, float* __restrict__ scratch) {
+  adam_schedule_eval(*iterations, lr0, decay_rate, decay_steps, beta1, beta2, scratch);
+  reinterpret_cast<unsigned*>(scratch)[2] = 0u;
+}
 __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, long long n, int* __restrict__ iterations, float lr0,
                                                          float decay_rate, float decay_steps, float beta1, float beta2, float eps,
                                                          float grad_scale, float* __restrict__ scratch) {
-  __shared__ float sh[2];
-  if (threadIdx.x == 0) {
-    const int it = *iterations;           // optimizer.iterations before this update
-    const double lr = (double)lr0 * pow((double)decay_rate, (double)it / (double)decay_steps);
-    const double t = (double)(it + 1);
-    sh[0] = (float)(lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
-    sh[1] = (float)lr;
-  }
-  __syncthreads();
-  const float alpha = sh[0];
+  const float alpha = scratch[0];
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
     const float gi = g[i] * grad_scale;
     const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
@@ -44,14 +48,15 @@ __global__ __launch_bounds__(256) void adam_fused_kernel(float* __restrict__ p, 
     v[i] = vi;
     p[i] -= mi * alpha / (sqrtf(vi) + eps);
   }
+  __syncthreads();                        // every thread of this block has read scratch[0]
   if (threadIdx.x == 0) {
     unsigned* ticket = reinterpret_cast<unsigned*>(scratch + 2);
     const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (t == gridDim.x - 1) {             // every block has read *iterations by now: only now may it move
+    if (t == gridDim.x - 1) {
       __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *iterations = *iterations + 1;
-      scratch[0] = sh[0];
-      scratch[1] = sh[1];
+      const int it = *iterations + 1;
+      *iterations = it;
+      adam_schedule_eval(it, lr0, decay_rate, decay_steps, beta1, beta2, scratch);
     }
   }
 }
@@ -205,11 +210,18 @@ int adam(float* p, const float* g, float* m, float* v, long long n, const float*
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
+int adam_prepare(const int* iterations, float lr0, float decay_rate, float decay_steps, float beta1, float beta2, float* scratch,
+                 hipStream_t st) {
+  PN_CHECK_ARG(iterations && scratch, "pn_adam_prepare: null pointer");
+  hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, iterations, lr0, decay_rate, decay_steps, beta1, beta2, scratch);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
 int adam_fused(float* p, const float* g, float* m, float* v, long long n, int* iterations, float lr0, float decay_rate, float decay_steps,
                float beta1, float beta2, float eps, float grad_scale, float* scratch, hipStream_t st) {
   PN_CHECK_ARG(p && g && m && v && iterations && scratch && n > 0, "pn_adam_step: bad arguments");
-  const long long blocks = cdivll(n, 1024);
-  hipLaunchKernelGGL(adam_fused_kernel, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, p, g, m, v, n, iterations, lr0,
+  const long long blocks = cdivll(n, 256);
+  hipLaunchKernelGGL(adam_fused_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, p, g, m, v, n, iterations, lr0,
                      decay_rate, decay_steps, beta1, beta2, eps, grad_scale, scratch);
   PN_CHECK_LAUNCH();
   return PN_OK;

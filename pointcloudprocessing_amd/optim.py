@@ -20,9 +20,19 @@ class KerasAdam:
         self.m = torch.zeros_like(params_flat)
         self.v = torch.zeros_like(params_flat)
         self.iterations = torch.zeros(1, dtype=torch.int32, device=params_flat.device)
-        self._alpha = torch.zeros(4, dtype=torch.float32, device=params_flat.device)   # [step size, learning rate, ticket, -]
+        self._alpha = torch.zeros(4, dtype=torch.float32, device=params_flat.device)   # [step size, learning rate (current), ticket, -]
         self.lr0, self.decay_steps, self.decay_rate = float(learning_rate), float(decay_steps), float(decay_rate)
         self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
+        self.prepare()
+
+    def prepare(self):
+        """(re)evaluate the schedule for the current ``iterations``: at construction and after restoring a checkpoint"""
+        check(lib().pn_adam_prepare(ptr(self.iterations), ptr(self._alpha), self.lr0, self.decay_rate, self.decay_steps, self.beta_1,
+                                    self.beta_2, current_stream()), "pn_adam_prepare")
+
+    def load_state_dict(self, state):
+        self.m.copy_(state["m"]); self.v.copy_(state["v"]); self.iterations.copy_(state["iterations"])
+        self.prepare()
 
     def step(self, grads_flat: torch.Tensor, grad_scale: float = 1.0):
         check(lib().pn_adam_step(ptr(self.params), ptr(grads_flat), ptr(self.m), ptr(self.v), self.params.numel(),

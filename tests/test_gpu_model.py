@@ -391,6 +391,7 @@ def test_boundary_buffers_are_never_overrun(dev, vanilla):
     io, _ = m._io(tin["pc"].view(torch.float32).view(B, N, 3), True, fused)
     io.params, io.grads, io.scalars = t_params.data_ptr(), t_grads.data_ptr(), t_sc.data_ptr()
     io.out_cls, io.out_seg, io.out_R = t_cls.data_ptr(), t_seg.data_ptr(), t_R.data_ptr()
+    check(lib().pn_adam_prepare(t_it.data_ptr(), t_al.data_ptr(), 1e-3, 0.7, 7000.0, 0.9, 0.999, current_stream()), "pn_adam_prepare")
     for _ in range(2):
         check(lib().pn_model_forward(C.byref(m._desc), C.byref(io), current_stream()), "pn_model_forward")
         check(lib().pn_model_backward(C.byref(m._desc), C.byref(io), None, None, None, current_stream()), "pn_model_backward")
