@@ -159,7 +159,13 @@ def main():
     torch.cuda.synchronize()
     model._io = orig_io
     kt = [evs[i][2 * j].elapsed_time(evs[i][2 * j + 1]) * 1e-3 for i in range(n_prof) for j in range(3)]
-    k_mean = sum(kt) / len(kt)
+    # an event pair with nothing between it on the same stream measures the timing overhead of the bracket itself
+    cal = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(50)]
+    for e0, e1 in cal:
+        e0.record(); e1.record()
+    torch.cuda.synchronize()
+    ev_overhead = sorted(e0.elapsed_time(e1) * 1e-3 for e0, e1 in cal)[len(cal) // 2]
+    k_mean = sum(kt) / len(kt) - ev_overhead
     flop_per_launch = 2.0 * 128 * 1024 * B * N
     # algorithmic bytes: pre-BN input rows read once (fp32) + the bf16 kernel copy + per-(cloud, channel) max/argmax/2 sums
     bytes_per_launch = 128 * 4 * B * N + 128 * 1024 * 2 * (2 if args.precision == "bf16x3" else 1) + B * 1024 * 16
@@ -189,7 +195,7 @@ def main():
         "roofline": {"bound": "mfma", "kernel": "panel_max_kernel<NS,128> (ConvLayer 128->1024 + BN sums + reduce_max, 3 launches per step)",
                      "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12 / (3 if args.precision == "bf16x3" else 1),
                      "unit": "TFLOP/s", "frac": achieved / (MFMA_BF16_PEAK / (3 if args.precision == "bf16x3" else 1)),
-                     "traffic": traffic, "launch_us": k_mean * 1e6, "launches_timed": len(kt),
+                     "traffic": traffic, "launch_us": k_mean * 1e6, "launches_timed": len(kt), "event_pair_overhead_us": ev_overhead * 1e6,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "hbm_frac_if_bandwidth_bound": bytes_per_launch / k_mean / HBM_PEAK},
     }
