@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--aux", action="store_true", help="A/B: parameter-gradient kernels on a second stream")
+    ap.add_argument("--rehearse-ddp", action="store_true",
+                    help="one process: initialise RCCL with world_size 1 and run the data-parallel step layout (graph, all-reduce, graph)")
     ap.add_argument("--caller-stream", action="store_true", help="A/B: run the step on torch's current (null) stream instead of its own")
     args = ap.parse_args()
 
@@ -93,6 +95,9 @@ def main():
     dev = torch.device("cuda", local)
     if world > 1:
         dist.init_process_group(backend="nccl", device_id=dev)
+    elif args.rehearse_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
     if args.gpus != world and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -110,7 +115,8 @@ def main():
     pc, y_cls, y_seg, se3 = synth_batch(B, N, 20260001 + rank, dev)
     from pointcloudprocessing_amd.engine import TrainStep
     ts = TrainStep(model, opt, B, N, lw, use_graph=not args.no_graph,
-                   stream=torch.cuda.current_stream() if args.caller_stream else None, aux=args.aux)      # hipGraph replay of the whole step
+                   stream=torch.cuda.current_stream() if args.caller_stream else None, aux=args.aux,
+                   split_optimizer=True if args.rehearse_ddp else None)      # hipGraph replay of the whole step
     ts.load(pc, y_cls, y_seg, se3)
     step, step_eager = ts.run, ts.run_eager
     torch.cuda.set_stream(ts.stream)     # the loop lives on the step's stream: no cross-stream fences (engine.TrainStep)
@@ -203,7 +209,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B, N)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -31,13 +31,18 @@ def rank_salt() -> int:
 
 class TrainStep:
     def __init__(self, model, optimizer: KerasAdam, batch: int, points: int, loss_weights: Sequence[float], use_graph: bool = True,
-                 stream: Optional["torch.cuda.Stream"] = None, aux: bool = False):
+                 stream: Optional["torch.cuda.Stream"] = None, aux: bool = False,
+                 split_optimizer: Optional[bool] = None):
         import torch.distributed as dist
         self.model, self.opt = model, optimizer
         self.B, self.N = batch, points
         self.lw = tuple(float(w) for w in loss_weights)
         self.dist = dist
         self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        # data-parallel layout of a step: [graph 1: forward+backward] -> all-reduce -> [graph 2: Adam]; a single process fuses
+        # both graphs unless split_optimizer asks for the data-parallel layout anyway (rehearsal of the N > 1 path on one GPU)
+        self.split = (self.world > 1) if split_optimizer is None else bool(split_optimizer)
+        self.reduce = self.split and dist.is_available() and dist.is_initialized()
         dev = model.params_flat.device
         self.dev = dev
         # static inputs: a graph replays fixed addresses
@@ -74,7 +79,7 @@ class TrainStep:
 
     def _eager(self):
         self._fwd_bwd()
-        if self.world > 1:
+        if self.reduce:
             self.dist.all_reduce(self.model.grads_flat)        # RCCL sum over xGMI
         self.opt.step(self.model.grads_flat, 1.0 / self.world)
 
@@ -84,10 +89,10 @@ class TrainStep:
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, stream=self._capture_stream):
                 self._fwd_bwd()
-                if self.world == 1:
+                if not self.split:
                     self.opt.step(self.model.grads_flat, 1.0)
             g2 = None
-            if self.world > 1:
+            if self.split:
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, stream=self._capture_stream):
                     self.opt.step(self.model.grads_flat, 1.0 / self.world)
@@ -136,8 +141,9 @@ class TrainStep:
                 self._eager()
             else:
                 self._g1.replay()
-                if self.world > 1:
-                    self.dist.all_reduce(self.model.grads_flat)
+                if self.split:
+                    if self.reduce:
+                        self.dist.all_reduce(self.model.grads_flat)
                     self._g2.replay()
         self._exit()
 
