@@ -15,8 +15,10 @@ namespace pn {
 // every split writes its 32x32 partial tile, then draws a ticket; the last arriver sums the tiles in a fixed order and
 // finishes the layer for those 32 columns (statistics are per column, so column blocks are independent).  This replaces
 // the separate reduce/normalise launch (~6 us in the step's graph) by ~1-2 us of tail work in one block per 32 columns.
-// Hand-off protocol: cdna_hip_programming.md, "In-launch split-K reduction" (agent-scope release before the ticket,
-// agent-scope acquire in the last arriver, counter re-zeroed by the last arriver AND by the caller before each pass).
+// Hand-off protocol: cdna_hip_programming.md, "In-launch split-K reduction", write-through form: the partial tiles are stored
+// sc1 (relaxed agent-scope atomic stores), every wave drains them, barrier, one lane draws a relaxed ticket; the last arriver
+// reads every tile with sc1 loads (relaxed agent-scope atomic loads) -- no release or acquire fence.  The counter is re-zeroed
+// by the last arriver AND by the caller before each pass.
 //   TRANS = false: W(k, j) = w[k * ldw + j]   (forward: the layer's kernel)
 //   TRANS = true : W(k, j) = w[j * ldw + k]   (backward data: dx = dz . W^T read from the same kernel, no transpose pass)
 constexpr int DL_COLS = 32;     // columns per block
@@ -127,7 +129,9 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a) {
 #pragma unroll
       for (int q = 0; q < DL_SLICES; ++q) t += red[(q * DL_ROWS + r) * DL_COLS + c];
       own[i] = t;      // rows s, s+8, s+16, s+24 of this chunk: exactly the rows this thread finishes below
-      if (!(single && small) && r < nr && j < a.C) a.partial[((long long)ks * a.R + rc + r) * a.C + j] = t;
+      // write-through (sc1) store: visible to every XCD once drained, so the meeting below needs no release fence
+      if (!(single && small) && r < nr && j < a.C)
+        __hip_atomic_store(&a.partial[((long long)ks * a.R + rc + r) * a.C + j], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
@@ -136,15 +140,9 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains its partial-tile stores
     __syncthreads();
     if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned t = __hip_atomic_fetch_add(a.counters + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const unsigned last = (t == (unsigned)a.nsplit - 1u) ? 1u : 0u;
-      if (last) {
-        __hip_atomic_store(a.counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      if (last) __hip_atomic_store(a.counters + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
       *flag = last;
     }
     __syncthreads();
@@ -179,7 +177,7 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a) {
       const int r = min(ty + RP * i, R - 1);
 #pragma unroll
       for (int q = 0; q < DL_MAX_SPLITS; ++q)          // clamped, unconditional: up to 32 loads in flight
-        pv[i][q] = a.partial[((long long)min(q, nks - 1) * R + r) * C + jc];
+        pv[i][q] = __hip_atomic_load(&a.partial[((long long)min(q, nks - 1) * R + r) * C + jc], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #pragma unroll
     for (int i = 0; i < DL_ROWS / RP; ++i) {
@@ -202,10 +200,10 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a) {
       float z0 = 0.f, z1 = 0.f;
       int q = 0;
       for (; q + 1 < nks; q += 2) {
-        z0 += a.partial[((long long)q * R + r) * C + j];
-        z1 += a.partial[((long long)(q + 1) * R + r) * C + j];
+        z0 += __hip_atomic_load(&a.partial[((long long)q * R + r) * C + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        z1 += __hip_atomic_load(&a.partial[((long long)(q + 1) * R + r) * C + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      if (q < nks) z0 += a.partial[((long long)q * R + r) * C + j];
+      if (q < nks) z0 += __hip_atomic_load(&a.partial[((long long)q * R + r) * C + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const float z = (z0 + z1) + b;
       a.z_out[(long long)r * C + j] = z;
       s1 += z;
