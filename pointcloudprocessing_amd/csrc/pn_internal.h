@@ -18,7 +18,7 @@ int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, i
 // pn_panel.hip
 int weights_prep(const float* w, int K, int C, void* hi, void* lo, hipStream_t st);
 int conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C, const float* sgn,
-                       float* pmax, int* pidx, float* stat_partials, int prec, hipStream_t st);
+                       float* pmax, int* pidx, float* stat_partials, int prec, hipStream_t st, int presigned = 0);
 
 // pn_pointwise.hip
 int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st);
@@ -50,8 +50,8 @@ int dense_bwd_pre(const float* da, const float* z, int R, int C, const float* ga
                   float* dbeta, float* dbias, hipStream_t st);
 int dense_wgrad(const float* x, int ldx, const float* dz, int R, int K, int C, float* dw, hipStream_t st);
 int transpose(const float* in, int R, int C, float* out, hipStream_t st);
-int weights_prep3(const float* const* w, const int* K, const int* C, void* const* hi, void* const* lo, unsigned* zero_p, int zero_n,
-                  hipStream_t st);
+int weights_prep3(const float* const* w, const float* const* sgn, const int* K, const int* C, void* const* hi, void* const* lo,
+                  unsigned* zero_p, int zero_n, hipStream_t st);
 int transpose2(const float* in, int R, int C, const float* rowscale, float* out, float* out2, hipStream_t st);
 int softmax_xent_rows(const float* logits, int R, int C, const int* labels, float grad_scale, float* probs, float* dlogits,
                       float* loss_sum, float* correct, hipStream_t st);

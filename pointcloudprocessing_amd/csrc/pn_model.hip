@@ -426,7 +426,7 @@ struct Run {
     void** ev = io.prof_events;
     if (ev && ev[2 * prof_slot]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot]), st);
     PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.sgn, m.pmax, m.pidx, bn_batch(r.block) ? l.part : nullptr,
-                              prec, st));
+                              prec, st, 1));
     if (ev && ev[2 * prof_slot + 1]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot + 1]), st);
     PN_TRY(bn_fin(l, r, m.T64));
     return max_finalize(m.pmax, m.pidx, B, m.tpc64, r.cout, N, m.sgn, l.scale, l.shift, m.g, m.zstar, m.arg, st);
@@ -465,7 +465,8 @@ struct Run {
       const int Ks[3] = {128, 128, 128}, Cs[3] = {1024, 1024, 1024};
       void* his[3] = {d.vanilla ? nullptr : w.iT.m3.wb_hi, d.vanilla ? nullptr : w.fT.m3.wb_hi, w.mm23.wb_hi};
       void* los[3] = {(x3 && !d.vanilla) ? w.iT.m3.wb_lo : nullptr, (x3 && !d.vanilla) ? w.fT.m3.wb_lo : nullptr, x3 ? w.mm23.wb_lo : nullptr};
-      PN_TRY(weights_prep3(ws, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS, st));
+      const float* sgs[3] = {d.vanilla ? nullptr : p(L.iT.c3.gamma), d.vanilla ? nullptr : p(L.fT.c3.gamma), p(L.m23.gamma)};
+      PN_TRY(weights_prep3(ws, sgs, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS, st));   // copies carry sign(gamma): max(sgn*z) needs no multiply
     }
     PN_TRY(normalize(io.pc, B, N, w.pcn, w.cent, w.scl, st));
     if (!d.vanilla) {

@@ -18,6 +18,7 @@ namespace pn {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in registers (HIP's uint4 struct does not)
 
 // ---- weight preparation: Wb_hi[c][k] = bf16(W[k][c]),  Wb_lo[c][k] = bf16(W[k][c] - hi) --------------------------
@@ -40,6 +41,7 @@ __global__ __launch_bounds__(256) void weights_prep_kernel(const float* __restri
 
 // the three max-pooled layers' kernels in one launch (blockIdx.z picks the matrix); block (0,0,0) also clears `zero_n` words
 struct Prep3Args {
+  const float* sgn[3];          // optional per-channel sign source (gamma): the copy holds sign(gamma_c) * W[:, c]
   const float* w[3];
   __bf16* hi[3];
   __bf16* lo[3];
@@ -65,18 +67,19 @@ __global__ __launch_bounds__(256) void weights_prep3_kernel(const Prep3Args a) {
   __syncthreads();
   for (int i = ty; i < 32; i += 8)
     if (bx + i < C && by + tx < K) {
-      const float v = t[tx][i];
+      const float sg = (a.sgn[z] && a.sgn[z][bx + i] < 0.f) ? -1.f : 1.f;      // exact: a sign flip commutes with the rounding
+      const float v = sg * t[tx][i];
       const __bf16 h = (__bf16)v;
       hi[(long long)(bx + i) * K + by + tx] = h;
       if (lo) lo[(long long)(bx + i) * K + by + tx] = (__bf16)(v - (float)h);
     }
 }
-int weights_prep3(const float* const* w, const int* K, const int* C, void* const* hi, void* const* lo, unsigned* zero_p, int zero_n,
-                  hipStream_t st) {
+int weights_prep3(const float* const* w, const float* const* sgn, const int* K, const int* C, void* const* hi, void* const* lo,
+                  unsigned* zero_p, int zero_n, hipStream_t st) {
   Prep3Args a;
   int mk = 1, mc = 1;
   for (int i = 0; i < 3; ++i) {
-    a.w[i] = w[i]; a.K[i] = K[i]; a.C[i] = C[i];
+    a.w[i] = w[i]; a.sgn[i] = sgn ? sgn[i] : nullptr; a.K[i] = K[i]; a.C[i] = C[i];
     a.hi[i] = reinterpret_cast<__bf16*>(hi[i]); a.lo[i] = reinterpret_cast<__bf16*>(lo[i]);
     PN_CHECK_ARG(!w[i] || (hi[i] && K[i] > 0 && C[i] > 0), "weights_prep3: bad arguments");
     if (w[i]) { mk = K[i] > mk ? K[i] : mk; mc = C[i] > mc ? C[i] : mc; }
@@ -102,6 +105,7 @@ struct PanelArgs {
   int B, N, K, C;
   int tiles_per_cloud;          // ceil(N / 64)
   const float* sgn;             // per channel; only the sign is used (may be gamma)
+  int presigned;                // the weight copy already carries sign(gamma_c): the accumulators hold sgn*z
   float* pmax;                  // [tiles][C]
   int* pidx;                    // [tiles][C]
   float* stat_partials;         // [tiles][2][C] or NULL
@@ -244,19 +248,36 @@ __global__ __launch_bounds__(256) void panel_max_kernel(const PanelArgs g) {
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
       const int jl = wn * 64 + n * 32 + r;
-      const float sg = sgn_s[(ct * BN + jl) & 1023];
+      const float sgc = sgn_s[(ct * BN + jl) & 1023];
+      const float sg = g.presigned ? 1.f : sgc;          // presigned copies: acc = sgn*z already, no per-element multiply
       float a1 = 0.f, a2 = 0.f, best = -INFINITY;
       int besti = 0x7fffffff;
       if (full) {
+        f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};         // packed pairs: v_pk_add_f32 / v_pk_fma_f32
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const float v = acc[n][e];
-          a1 += v;
-          a2 = fmaf(v, v, a2);
-          const float t = sg * v;
-          const bool better = t > best;                 // rows ascend with e: first maximum wins
-          best = better ? t : best;
-          besti = better ? (rbase_lane + (e & 3) + 8 * (e >> 2)) : besti;
+        for (int e = 0; e < 16; e += 2) {
+          const f32x2 v2 = {acc[n][e], acc[n][e + 1]};
+          s1 += v2;
+          s2 = __builtin_elementwise_fma(v2, v2, s2);
+        }
+        a1 = s1.x + s1.y;
+        a2 = s2.x + s2.y;
+        if (g.presigned) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float t = acc[n][e];
+            const bool better = t > best;                 // rows ascend with e: first maximum wins
+            best = better ? t : best;
+            besti = better ? (rbase_lane + (e & 3) + 8 * (e >> 2)) : besti;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float t = sg * acc[n][e];
+            const bool better = t > best;
+            best = better ? t : best;
+            besti = better ? (rbase_lane + (e & 3) + 8 * (e >> 2)) : besti;
+          }
         }
       } else {
 #pragma unroll
@@ -272,6 +293,7 @@ __global__ __launch_bounds__(256) void panel_max_kernel(const PanelArgs g) {
           besti = better ? (row_in_cloud0 + il) : besti;
         }
       }
+      if (g.presigned) a1 *= sgc;                         // the column sum of z itself
       a1 += __shfl_xor(a1, 32, 64);
       a2 += __shfl_xor(a2, 32, 64);
       const float ob = __shfl_xor(best, 32, 64);
@@ -306,7 +328,7 @@ __global__ __launch_bounds__(256) void panel_max_kernel(const PanelArgs g) {
 }
 
 int conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C, const float* sgn,
-                       float* pmax, int* pidx, float* stat_partials, int prec, hipStream_t st) {
+                       float* pmax, int* pidx, float* stat_partials, int prec, hipStream_t st, int presigned) {
   PN_CHECK_ARG(x && x->s1 && !x->s2, "pn_conv_fwd_max_panel: bad operand");
   PN_CHECK_ARG((reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && x->ld % 4 == 0 && x->ld >= K, "pn_conv_fwd_max_panel: operand alignment");
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_fwd_max_panel: B and N must be positive");
@@ -319,7 +341,7 @@ int conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo
   g.a = *x; g.wb_hi = reinterpret_cast<const __bf16*>(wb_hi); g.wb_lo = reinterpret_cast<const __bf16*>(wb_lo);
   g.B = B; g.N = N; g.K = K; g.C = C;
   g.tiles_per_cloud = cdiv(N, 64);
-  g.sgn = sgn; g.pmax = pmax; g.pidx = pidx; g.stat_partials = stat_partials;
+  g.sgn = sgn; g.pmax = pmax; g.pidx = pidx; g.stat_partials = stat_partials; g.presigned = presigned;
   const dim3 grid(B * g.tiles_per_cloud);
   if (prec == PN_PREC_BF16X3) {
     if (K == 128) hipLaunchKernelGGL((panel_max_kernel<3, 128>), grid, dim3(256), 0, st, g);
