@@ -205,6 +205,14 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "hbm_frac_if_bandwidth_bound": bytes_per_launch / k_mean / HBM_PEAK},
     }
+    # whole-step roofline: cls trunk fwd+bwd 2.61 MFLOP and 18.4 KB of compulsory layer-boundary traffic per point
+    # (7.04 MFLOP with the segmentation head trained); the slower of the two roofs bounds the step
+    f_alg = (7.04e6 if lw[1] != 0.0 else 2.61e6) * B * N
+    b_alg = 18.4e3 * B * N + 16.8e6
+    t_roof = max(f_alg / MFMA_BF16_PEAK, b_alg / HBM_PEAK)
+    out["step_roofline"] = {"algorithmic_flop": f_alg, "algorithmic_bytes": b_alg, "t_mfma_us": f_alg / MFMA_BF16_PEAK * 1e6,
+                            "t_hbm_us": b_alg / HBM_PEAK * 1e6, "bound": "hbm" if b_alg / HBM_PEAK > f_alg / MFMA_BF16_PEAK else "mfma",
+                            "frac": t_roof / (dt / args.steps)}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B, N)

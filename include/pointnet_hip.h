@@ -188,6 +188,23 @@ int pn_dense_bwd(const float* da, const float* z, const float* x, int ldx, int R
                  const float* beta, const float* mean, const float* invstd, int bn_mode, int act, const uint8_t* keep,
                  float keep_scale, float* dz, float* dgamma, float* dbeta, float* dbias, float* dw, pn_stream stream);
 
+/* --- tf.nn.softmax (PointNet.py:134) + keras SparseCategoricalCrossentropy(from_logits=False) + sparse accuracy for rows = B
+ * (pointnet_train.py:334-345): probs (R, C); with labels: loss_sum[0] = sum_r nll_r, correct[0] = #(argmax == label), and, if
+ * dlogits != NULL, dlogits = grad_scale * d(sum nll)/d(logits) including keras' clip to [1e-7, 1-1e-7] (zero gradient outside). */
+int pn_softmax_xent(const float* logits, int R, int C, const int32_t* labels, float grad_scale, float* probs, float* dlogits,
+                    float* loss_sum, float* correct, pn_stream stream);
+
+/* --- seg_l5_output (ConvLayer K -> Cseg <= 16 with bias, no BN; PointNet.py:141,288-290) fused with its softmax and the
+ * per-point loss: probs (M, C) = softmax(x . w + bias) over M = B*N rows of a lazy operand; with labels: part[] receives
+ * per-256-row partial (sum nll, #correct) pairs at stride pn_seg_out_part_stride() floats, dlogits (M, C) the scaled gradient. */
+int pn_seg_out_part_stride(void);
+int pn_seg_out_fwd(const pn_operand* x, const float* w, const float* bias, int64_t M, int K, int C, const int32_t* labels,
+                   float grad_scale, float* probs, float* dlogits, float* part, pn_stream stream);
+
+/* --- tf.matmul(X, R) with one K x K matrix per cloud (PointNet.py:207 K = 3, :228 K = 64): out (B*N, K) = x (B*N, K) . R[b].
+ * K = 64 runs on the MFMA engine (pn_conv_fwd with a per-cloud weight stride); K = 3 is a three-FMA-per-output kernel. */
+int pn_bmm(const float* x, const float* R, int B, int N, int K, float* out, int prec, pn_stream stream);
+
 /* --- farthest point sampling (no counterpart in the reference; build-defined spec):
  * per cloud, start at `start_idx`, repeatedly take the point with the largest squared distance (fp32,
  * d = dx*dx + dy*dy + dz*dz evaluated left to right without fma contraction) to the selected set, ties ->

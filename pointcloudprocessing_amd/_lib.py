@@ -81,6 +81,10 @@ SIGNATURES = {
     "pn_dense_workspace_floats": (C.c_size_t, [_I, _I, _I]),
     "pn_dense_layer": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
     "pn_dense_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _F, _P, _P, _P, _P, _P, _P]),
+    "pn_softmax_xent": (_I, [_P, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
+    "pn_seg_out_part_stride": (_I, []),
+    "pn_seg_out_fwd": (_I, [_OP, _P, _P, _I64, _I, _I, _P, _F, _P, _P, _P, _P]),
+    "pn_bmm": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
     "pn_dropout_masks": (_I, [_P, _I64, _P, _I64, _F, C.c_uint64, _P, _P]),
     "pn_fps_workspace_bytes": (C.c_size_t, [_I, _I]),
     "pn_fps": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),

@@ -86,6 +86,25 @@ int pn_dense_bwd(const float* da, const float* z, const float* x, int ldx, int R
   return dense_bwd_fused(da, z, x, ldx, R, K, C, gamma, beta, mean, invstd, bn_mode, act, keep, keep_scale, dz, dgamma, dbeta, dbias, dw,
                          S(stream));
 }
+int pn_softmax_xent(const float* logits, int R, int C, const int32_t* labels, float grad_scale, float* probs, float* dlogits,
+                    float* loss_sum, float* correct, pn_stream stream) {
+  return softmax_xent_rows(logits, R, C, labels, grad_scale, probs, dlogits, loss_sum, correct, S(stream));
+}
+int pn_seg_out_part_stride(void) { return seg_out_part_stride(); }
+int pn_seg_out_fwd(const pn_operand* x, const float* w, const float* bias, int64_t M, int K, int C, const int32_t* labels, float grad_scale,
+                   float* probs, float* dlogits, float* part, pn_stream stream) {
+  PN_CHECK_ARG(x && x->s1 && w && probs && M > 0, "pn_seg_out_fwd: null pointer");
+  return seg_out_fwd(x, w, bias, M, K, C, labels, grad_scale, probs, dlogits, part, S(stream));
+}
+int pn_bmm(const float* x, const float* R, int B, int N, int K, float* out, int prec, pn_stream stream) {
+  PN_CHECK_ARG(x && R && out && B > 0 && N > 0, "pn_bmm: bad arguments");
+  PN_CHECK_ARG(K == 3 || K == 64, "pn_bmm: K must be 3 or 64 (K=%d)", K);
+  if (K == 3) return bmm3(x, R, B, N, out, S(stream));
+  pn_operand o;
+  memset(&o, 0, sizeof(o));
+  o.s1 = x; o.ld = 64; o.lo = -INFINITY;
+  return conv_fwd(&o, R, 4096, B, N, 64, 64, nullptr, out, nullptr, prec, S(stream));
+}
 int pn_dropout_masks(uint8_t* keep1, int64_t n1, uint8_t* keep2, int64_t n2, float rate, uint64_t seed, uint32_t* step, pn_stream stream) {
   return dropout_masks(keep1, n1, keep2, n2, rate, seed, step, S(stream));
 }

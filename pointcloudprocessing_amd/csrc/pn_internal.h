@@ -57,6 +57,8 @@ int softmax_xent_rows(const float* logits, int R, int C, const int* labels, floa
                       float* loss_sum, float* correct, hipStream_t st);
 int softmax_bwd_rows(const float* probs, const float* dprobs, long long R, int C, float* dlogits, hipStream_t st);
 
+int bmm3(const float* x, const float* R, int B, int N, float* out, hipStream_t st);
+
 // pn_segout.hip
 int seg_out_fwd(const pn_operand* x, const float* w, const float* bias, long long M, int K, int C, const int* labels,
                 float grad_scale, float* probs, float* dlogits, float* part, hipStream_t st);

@@ -360,4 +360,23 @@ int max_finalize(const float* pmax, const int* pidx, int B, int tpc, int C, int 
   return PN_OK;
 }
 
+// tf.matmul(pc, R) for K = 3 (PointNet.py:207): out[b, n, :] = pc[b, n, :] . R[b]   (the model folds this into mlp_1_1's weights;
+// the stand-alone op exists for the module API and the parity tests)
+__global__ __launch_bounds__(256) void bmm3_kernel(const float* __restrict__ x, const float* __restrict__ R, int N, long long M,
+                                                   float* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M) return;
+  const float* r = R + (i / N) * 9;
+  const float a = x[3 * i], b = x[3 * i + 1], c = x[3 * i + 2];
+  out[3 * i + 0] = fmaf(c, r[6], fmaf(b, r[3], a * r[0]));
+  out[3 * i + 1] = fmaf(c, r[7], fmaf(b, r[4], a * r[1]));
+  out[3 * i + 2] = fmaf(c, r[8], fmaf(b, r[5], a * r[2]));
+}
+int bmm3(const float* x, const float* R, int B, int N, float* out, hipStream_t st) {
+  const long long M = (long long)B * N;
+  hipLaunchKernelGGL(bmm3_kernel, dim3((unsigned)cdivll(M, 256)), dim3(256), 0, st, x, R, N, M, out);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
 }  // namespace pn

@@ -270,3 +270,18 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib().pn_model_workspace_bytes(C.byref(d), 4, 1024, 1) > _lib.lib().pn_model_workspace_bytes(C.byref(d), 4, 1024, 0) > 0
     bad = _lib.pn_model_desc(ccls=23, cseg=99, prec=3, dropout_rate=0.3, bn_momentum=0.99, bn_eps=1e-3)
     assert _lib.lib().pn_model_num_slots(C.byref(bad)) == -1 and b"segmentation width" in _lib.lib().pn_last_error()
+
+
+def test_oracle_reproduces_committed_golden_vectors():
+    """tests/golden/oracle_b2_n64.npz (made by tests/golden/make_oracle_vectors.py) pins the oracle against drift: inference
+    outputs, training-mode outputs, the three keras losses and a digest of every parameter gradient, all fp64."""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_oracle_vectors", os.path.join(here, "golden", "make_oracle_vectors.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    want = np.load(os.path.join(here, "golden", "oracle_b2_n64.npz"))
+    got = mod.build()
+    assert set(want.files) == set(got.keys())
+    for k in want.files:
+        assert np.allclose(np.asarray(got[k], dtype=np.float64), want[k].astype(np.float64), rtol=1e-9, atol=1e-12), k
+    assert np.array_equal(got["inf_cls"].argmax(-1), want["inf_cls"].argmax(-1))

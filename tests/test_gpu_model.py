@@ -10,6 +10,8 @@ same bf16 operand rounding (tight) and with the fp32 oracle (loose, 3e-2).
 """
 import os
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -405,3 +407,21 @@ def test_boundary_buffers_are_never_overrun(dev, vanilla):
     for k in tin:
         assert torch.equal(tin[k], snap[k]), f"read-only input {k} was modified"
     assert bool(torch.isfinite(t_grads.view(torch.float32)).all()) and int(t_it.view(torch.int32)[0]) == 2
+
+
+def test_inference_against_committed_golden_vectors(dev):
+    """the HIP path on the inputs of tests/golden/oracle_b2_n64.npz against the outputs stored there (fp64 oracle, made by
+    tests/golden/make_oracle_vectors.py): probabilities within 1e-5 (bf16x3 operands), arg-max class and per-point part bit-exact
+    wherever the stored top-2 margin exceeds that tolerance."""
+    gv = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_b2_n64.npz"))
+    params = O.init_params(23, 12, seed=7, vanilla=False, dtype=torch.float64, randomize_bn=True)     # as in the generator
+    m = build_model(dev, params, precision="bf16x3")
+    pc = torch.from_numpy(gv["pc"]).float().to(dev)
+    cls, seg, R = m(pc, training=False)
+    cls, seg, R = cls.double().cpu().numpy(), seg.double().cpu().numpy(), R.double().cpu().numpy()
+    assert np.abs(cls - gv["inf_cls"]).max() < 1e-5 and np.abs(seg - gv["inf_seg"]).max() < 1e-5 and np.abs(R - gv["inf_R"]).max() < 1e-4
+    top2 = np.sort(gv["inf_seg"], -1)
+    safe = (top2[..., -1] - top2[..., -2]) > 1e-4
+    assert safe.mean() > 0.9
+    assert np.array_equal(seg.argmax(-1)[safe], gv["inf_seg"].argmax(-1)[safe])
+    assert np.array_equal(cls.argmax(-1), gv["inf_cls"].argmax(-1))

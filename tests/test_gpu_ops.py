@@ -4,6 +4,7 @@ Every test calls libpointnet_hip.so through pointcloudprocessing_amd.ops (ctypes
 CPU computation of the same formula.  Integer-valued inputs make the bf16 MFMA path EXACT, so layout bugs
 (row/column swaps, k permutations) show up as hard mismatches, not tolerance noise.
 """
+import ctypes as C
 import math
 
 import numpy as np
@@ -432,3 +433,73 @@ def test_dropout_masks_counter_based(dev):
     step.zero_()
     d1, _ = draw(99)
     assert not torch.equal(a1, d1)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# classification loss, segmentation output layer, per-cloud matmul: the remaining SURVEY 8(b) exports
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("R,C_", [(32, 23), (5, 2), (70, 40), (32, 300)])
+def test_softmax_xent_matches_keras_restatement(dev, R, C_):
+    L = _lib()
+    g = torch.Generator().manual_seed(R * 100 + C_)
+    logits = (torch.randn(R, C_, generator=g) * 3).double()
+    logits[0, 0] = 60.0                                    # one saturated row: exercises the clip to [1e-7, 1-1e-7]
+    labels = torch.randint(0, C_, (R,), generator=g)
+    lg = logits.clone().requires_grad_(True)
+    probs = torch.softmax(lg, -1)
+    loss = O.keras_sparse_cce(probs, labels) * R           # sum over rows
+    loss.backward()
+    ld = logits.float().to(dev)
+    lab_d = labels.int().to(dev)                           # named: a temporary would be freed before the kernel runs
+    p = torch.empty(R, C_, device=dev); d = torch.empty(R, C_, device=dev); ls = torch.zeros(1, device=dev); cr = torch.zeros(1, device=dev)
+    L.check(L.lib().pn_softmax_xent(L.ptr(ld), R, C_, L.ptr(lab_d), 0.5, L.ptr(p), L.ptr(d), L.ptr(ls), L.ptr(cr),
+                                    L.current_stream()), "pn_softmax_xent")
+    torch.cuda.synchronize()
+    assert torch.allclose(p.double().cpu(), probs.detach(), rtol=1e-5, atol=1e-7)
+    assert torch.equal(p.argmax(-1).cpu(), probs.argmax(-1))
+    assert abs(float(ls) - float(loss)) <= 1e-5 * max(1.0, abs(float(loss)))
+    assert float(cr) == float((probs.argmax(-1) == labels).sum())
+    assert torch.allclose(d.double().cpu(), 0.5 * lg.grad, rtol=2e-4, atol=2e-6), float((d.double().cpu() - 0.5 * lg.grad).abs().max())
+
+
+@pytest.mark.parametrize("B,N,C_", [(2, 300, 12), (3, 257, 5)])
+def test_seg_out_fwd_matches_restatement(dev, B, N, C_):
+    L = _lib()
+    K, M = 128, B * N
+    g = torch.Generator().manual_seed(B * N + C_)
+    z = torch.randn(M, K, generator=g); ca = torch.rand(K, generator=g) + 0.5; cc = torch.randn(K, generator=g) * 0.3
+    w = torch.randn(K, C_, generator=g) * 0.2; bias = torch.randn(C_, generator=g)
+    labels = torch.randint(0, C_, (M,), generator=g)
+    x = torch.relu(z.double() * ca.double() + cc.double())
+    lg = (x @ w.double() + bias.double()).requires_grad_(True)
+    probs = torch.softmax(lg, -1)
+    nll_sum = O.keras_sparse_cce(probs, labels) * M
+    nll_sum.backward()
+    zd, cad, ccd = z.to(dev), ca.to(dev), cc.to(dev)
+    wd, bd, lab_d = w.to(dev), bias.to(dev), labels.int().to(dev)
+    op = L.operand(zd, ca=cad, cc=ccd, ld=K, relu=True)
+    stride = L.lib().pn_seg_out_part_stride()
+    nparts = (M + 255) // 256
+    p = torch.empty(M, C_, device=dev); d = torch.empty(M, C_, device=dev); part = torch.zeros(nparts * stride, device=dev)
+    L.check(L.lib().pn_seg_out_fwd(C.byref(op), L.ptr(wd), L.ptr(bd), M, K, C_, L.ptr(lab_d), 1.0 / M,
+                                   L.ptr(p), L.ptr(d), L.ptr(part), L.current_stream()), "pn_seg_out_fwd")
+    torch.cuda.synchronize()
+    assert torch.allclose(p.double().cpu(), probs.detach(), rtol=1e-4, atol=1e-6)
+    pr = part.view(nparts, stride).double().cpu()
+    assert abs(float(pr[:, 0].sum()) - float(nll_sum)) <= 1e-4 * float(nll_sum)
+    safe = (probs.detach().topk(2, -1).values.diff(dim=-1).abs().squeeze(-1) > 1e-5)
+    assert abs(float(pr[:, 1].sum()) - float((probs.argmax(-1) == labels).sum())) <= float((~safe).sum())
+    assert torch.allclose(d.double().cpu(), lg.grad / M, rtol=1e-3, atol=1e-7)
+
+
+@pytest.mark.parametrize("K", [3, 64])
+def test_bmm_per_cloud_matrices(dev, K):
+    L = _lib()
+    B, N = 3, 200
+    g = torch.Generator().manual_seed(K)
+    x = ints(g, (B, N, K)); R = ints(g, (B, K, K), -2, 3)       # integer-valued: exact in bf16 and in fp32
+    out = torch.empty(B * N, K, device=dev)
+    xd, Rd = x.to(dev), R.to(dev)
+    L.check(L.lib().pn_bmm(L.ptr(xd), L.ptr(Rd), B, N, K, L.ptr(out), 1, L.current_stream()), "pn_bmm")
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu().view(B, N, K), torch.bmm(x, R))
