@@ -17,25 +17,29 @@ int zero_fill(float* p, long long n, hipStream_t st);   // pn_optim.hip
 // atomics (a single naturally aligned 8-byte sc1 store/load needs no other ordering:
 // MI355X_MICROARCH.md, "R2's granule").  Every spin is bounded.
 // ------------------------------------------------------------------------------------------------------
-constexpr int FPS_T = 1024;
-constexpr int FPS_PPT = 16;
-constexpr int FPS_PER_BLOCK = FPS_T * FPS_PPT;
+constexpr int FPS_T_MULTI = 1024;
+constexpr int FPS_PPT_MULTI = 16;     // points per thread when a cloud is split over blocks (and for clouds <= 16384 points)
+constexpr int FPS_PPT_WIDE = 28;      // single block of 768 threads (12 waves -> 170 VGPRs each) x 28 points = 21504 points, no spill
+constexpr int FPS_T_WIDE = 768;
+constexpr int FPS_PER_BLOCK = FPS_T_MULTI * FPS_PPT_MULTI;
 
 __device__ __forceinline__ void fps_better(float& best, int& bi, float ob, int oi) {
   if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
 }
 
+template <int FPS_PPT, int FPS_T>
 __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xyz, int N, int M, int start_idx, int bpc,
                                                     int* __restrict__ idx_out, float* __restrict__ mindist,
                                                     unsigned long long* __restrict__ xchg, int* __restrict__ err) {
 #pragma clang fp contract(off)   // the distance is specified without fused multiply-add (bit-exact vs the oracle)
   __shared__ float s_best[2][16];
   __shared__ int s_idx[2][16];
+  __shared__ float s_xyz[2][16][3];   // coordinates of each wave's candidate: the next round starts without a global load
   __shared__ int s_cur;
   const int cloud = blockIdx.x / bpc, blk = blockIdx.x - cloud * bpc;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* p = xyz + (long long)cloud * N * 3;
-  const int base = blk * FPS_PER_BLOCK;
+  const int base = blk * (FPS_T * FPS_PPT);
   float px[FPS_PPT], py[FPS_PPT], pz[FPS_PPT], md[FPS_PPT];
 #pragma unroll
   for (int j = 0; j < FPS_PPT; ++j) {
@@ -49,11 +53,11 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
     }
   }
   int cur = start_idx;
+  float cx = p[3 * cur], cy = p[3 * cur + 1], cz = p[3 * cur + 2];
   unsigned long long* xc = xchg + (long long)cloud * 2 * bpc;
   for (int it = 0; it < M; ++it) {
     if (blk == 0 && tid == 0) idx_out[(long long)cloud * M + it] = cur;
     if (it == M - 1) break;
-    const float cx = p[3 * cur], cy = p[3 * cur + 1], cz = p[3 * cur + 2];
     float best = -1.f;
     int bi = 0x7fffffff;
 #pragma unroll
@@ -65,6 +69,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
         if (md[j] > best) { best = md[j]; bi = base + j * FPS_T + tid; }
       }
     }
+    const int mine = bi;                 // this lane's own candidate
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
       const float ob = __shfl_xor(best, o, 64);
@@ -73,10 +78,28 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
     }
     const int par = it & 1;
     if (lane == 0) { s_best[par][wave] = best; s_idx[par][wave] = bi; }
+    constexpr bool LDS_XYZ = (FPS_PPT <= 16);      // a 32-way register select chain ends up in scratch: the wide variant re-loads instead
+    if (LDS_XYZ && mine == bi && bi != 0x7fffffff) {          // exactly one lane per wave: publish the candidate's coordinates
+      const int jw = (bi - base - tid) / FPS_T;
+      float bx = px[0], by = py[0], bz = pz[0];
+#pragma unroll
+      for (int j = 1; j < FPS_PPT; ++j)
+        if (j == jw) { bx = px[j]; by = py[j]; bz = pz[j]; }
+      s_xyz[par][wave][0] = bx; s_xyz[par][wave][1] = by; s_xyz[par][wave][2] = bz;
+    }
     __syncthreads();
     best = s_best[par][0]; bi = s_idx[par][0];
+    int bw = 0;
 #pragma unroll
-    for (int w = 1; w < 16; ++w) fps_better(best, bi, s_best[par][w], s_idx[par][w]);
+    for (int w = 1; w < FPS_T / 64; ++w) {
+      const float ob = s_best[par][w];
+      const int oi = s_idx[par][w];
+      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; bw = w; }
+    }
+    if (bpc == 1) {
+      if (LDS_XYZ) { cx = s_xyz[par][bw][0]; cy = s_xyz[par][bw][1]; cz = s_xyz[par][bw][2]; }
+      else { cx = p[3 * bi]; cy = p[3 * bi + 1]; cz = p[3 * bi + 2]; }
+    }
     if (bpc > 1) {
       const unsigned tag = (unsigned)(it + 1) & 0xfffu;
       if (tid == 0) {
@@ -115,6 +138,7 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
       __syncthreads();
       bi = s_cur;
       if (bi < 0) break;   // block-uniform: a peer never published (error flag set)
+      cx = p[3 * bi]; cy = p[3 * bi + 1]; cz = p[3 * bi + 2];   // the winner may live in another block
     }
     cur = bi;
   }
@@ -127,8 +151,10 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
   }
 }
 
+static inline int fps_blocks_per_cloud(int N) { return N <= FPS_T_WIDE * FPS_PPT_WIDE ? 1 : cdiv(N, FPS_PER_BLOCK); }
+
 size_t fps_workspace_bytes(int B, int N) {
-  const int bpc = cdiv(N, FPS_PER_BLOCK);
+  const int bpc = fps_blocks_per_cloud(N);
   return 16 + (size_t)B * 2 * bpc * sizeof(unsigned long long);
 }
 
@@ -137,7 +163,8 @@ int fps(const float* xyz, int B, int N, int M, int start_idx, int* idx_out, floa
   PN_CHECK_ARG(xyz && idx_out, "pn_fps: null pointer");
   PN_CHECK_ARG(B > 0 && N > 0 && M > 0, "pn_fps: B, N, M must be positive (B=%d N=%d M=%d)", B, N, M);
   PN_CHECK_ARG(start_idx >= 0 && start_idx < N, "pn_fps: start_idx %d outside [0,%d)", start_idx, N);
-  const int bpc = cdiv(N, FPS_PER_BLOCK);
+  const int bpc = fps_blocks_per_cloud(N);
+  const bool wide = bpc == 1 && N > FPS_PER_BLOCK;
   PN_CHECK_ARG(bpc <= 64, "pn_fps: N=%d exceeds %d points per cloud", N, 64 * FPS_PER_BLOCK);
   PN_CHECK_ARG(ws && ws_bytes >= fps_workspace_bytes(B, N), "pn_fps: workspace too small");
   int* err = reinterpret_cast<int*>(ws);
@@ -147,9 +174,14 @@ int fps(const float* xyz, int B, int N, int M, int start_idx, int* idx_out, floa
   const int clouds_per_launch = bpc > 1 ? (128 / bpc > 0 ? 128 / bpc : 1) : B;
   for (int b0 = 0; b0 < B; b0 += clouds_per_launch) {
     const int nb = (B - b0) < clouds_per_launch ? (B - b0) : clouds_per_launch;
-    hipLaunchKernelGGL(fps_kernel, dim3(nb * bpc), dim3(FPS_T), 0, st, xyz + (long long)b0 * N * 3, N, M, start_idx, bpc,
-                       idx_out + (long long)b0 * M, mindist ? mindist + (long long)b0 * N : nullptr,
-                       xchg + (long long)b0 * 2 * bpc, err);
+    if (wide)
+      hipLaunchKernelGGL((fps_kernel<FPS_PPT_WIDE, FPS_T_WIDE>), dim3(nb * bpc), dim3(FPS_T_WIDE), 0, st, xyz + (long long)b0 * N * 3, N, M, start_idx, bpc,
+                         idx_out + (long long)b0 * M, mindist ? mindist + (long long)b0 * N : nullptr,
+                         xchg + (long long)b0 * 2 * bpc, err);
+    else
+      hipLaunchKernelGGL((fps_kernel<FPS_PPT_MULTI, FPS_T_MULTI>), dim3(nb * bpc), dim3(FPS_T_MULTI), 0, st, xyz + (long long)b0 * N * 3, N, M, start_idx, bpc,
+                         idx_out + (long long)b0 * M, mindist ? mindist + (long long)b0 * N : nullptr,
+                         xchg + (long long)b0 * 2 * bpc, err);
     PN_CHECK_LAUNCH();
   }
   return PN_OK;

@@ -267,7 +267,7 @@ def test_bn_finalize_and_backward_coefficients(dev):
     assert torch.allclose(dbeta.cpu().double(), bt.grad, atol=1e-3, rtol=1e-4)
 
 
-@pytest.mark.parametrize("B,N,M", [(2, 1000, 64), (1, 5000, 512), (3, 17, 17), (1, 40000, 256), (2, 20000, 100)])
+@pytest.mark.parametrize("B,N,M", [(2, 1000, 64), (1, 5000, 512), (3, 17, 17), (1, 40000, 256), (2, 20000, 100), (1, 21504, 40), (1, 21505, 40), (1, 16384, 40), (1, 16385, 40)])
 def test_fps_bit_exact_indices(dev, B, N, M):
     ops = _ops()
     rng = np.random.default_rng(9)
