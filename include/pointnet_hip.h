@@ -196,8 +196,10 @@ int pn_softmax_xent(const float* logits, int R, int C, const int32_t* labels, fl
 
 /* --- seg_l5_output (ConvLayer K -> Cseg <= 16 with bias, no BN; PointNet.py:141,288-290) fused with its softmax and the
  * per-point loss: probs (M, C) = softmax(x . w + bias) over M = B*N rows of a lazy operand; with labels: part[] receives
- * per-256-row partial (sum nll, #correct) pairs at stride pn_seg_out_part_stride() floats, dlogits (M, C) the scaled gradient. */
+ * per-block partial (sum nll, #correct) pairs -- one block per pn_seg_out_part_rows() rows -- at stride pn_seg_out_part_stride()
+ * floats; dlogits (M, C) the scaled gradient. */
 int pn_seg_out_part_stride(void);
+int pn_seg_out_part_rows(void);
 int pn_seg_out_fwd(const pn_operand* x, const float* w, const float* bias, int64_t M, int K, int C, const int32_t* labels,
                    float grad_scale, float* probs, float* dlogits, float* part, pn_stream stream);
 

@@ -83,6 +83,7 @@ SIGNATURES = {
     "pn_dense_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _F, _P, _P, _P, _P, _P, _P]),
     "pn_softmax_xent": (_I, [_P, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
     "pn_seg_out_part_stride": (_I, []),
+    "pn_seg_out_part_rows": (_I, []),
     "pn_seg_out_fwd": (_I, [_OP, _P, _P, _I64, _I, _I, _P, _F, _P, _P, _P, _P]),
     "pn_bmm": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
     "pn_dropout_masks": (_I, [_P, _I64, _P, _I64, _F, C.c_uint64, _P, _P]),

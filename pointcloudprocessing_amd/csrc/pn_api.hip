@@ -91,6 +91,7 @@ int pn_softmax_xent(const float* logits, int R, int C, const int32_t* labels, fl
   return softmax_xent_rows(logits, R, C, labels, grad_scale, probs, dlogits, loss_sum, correct, S(stream));
 }
 int pn_seg_out_part_stride(void) { return seg_out_part_stride(); }
+int pn_seg_out_part_rows(void) { return seg_out_part_rows(); }
 int pn_seg_out_fwd(const pn_operand* x, const float* w, const float* bias, int64_t M, int K, int C, const int32_t* labels, float grad_scale,
                    float* probs, float* dlogits, float* part, pn_stream stream) {
   PN_CHECK_ARG(x && x->s1 && w && probs && M > 0, "pn_seg_out_fwd: null pointer");

@@ -63,6 +63,7 @@ int bmm3(const float* x, const float* R, int B, int N, float* out, hipStream_t s
 int seg_out_fwd(const pn_operand* x, const float* w, const float* bias, long long M, int K, int C, const int* labels,
                 float grad_scale, float* probs, float* dlogits, float* part, hipStream_t st);
 int seg_out_part_stride();
+int seg_out_part_rows();
 int seg_out_bwd(const pn_operand* x, const float* w, const float* dlogits, int B, int N, int K, int C, float* dyhat, float* stat_part,
                 float* wslab, hipStream_t st);
 int sum_partials(const float* part, int n, int stride, int elems, float* out, hipStream_t st);

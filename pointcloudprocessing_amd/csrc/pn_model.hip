@@ -275,7 +275,7 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
   w.X64 = d.vanilla ? nullptr : A.get<float>("X64", (size_t)M * 64);
   w.gb = A.get<float>("gb", (size_t)B * 512);
   w.cls_logits = A.get<float>("cls_logits", (size_t)B * d.ccls);
-  w.seg_part = A.get<float>("seg_part", (size_t)cdivll(M, 256) * seg_out_part_stride());
+  w.seg_part = A.get<float>("seg_part", (size_t)cdivll(M, seg_out_part_rows()) * seg_out_part_stride());
   w.dense_part = A.get<float>("dense_part", (size_t)8 * B * 4096);          // split-K tiles of the dense layers (<= 8 splits)
   w.dcount = A.get<unsigned>("dcount", DENSE_MAX_COUNTERS);                 // their in-launch arrival counters
   w.R3eye = A.get<float>("R3eye", (size_t)B * 9);
@@ -428,6 +428,7 @@ struct Run {
     PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.sgn, m.pmax, m.pidx, bn_batch(r.block) ? l.part : nullptr,
                               prec, st, 1));
     if (ev && ev[2 * prof_slot + 1]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot + 1]), st);
+    // (a fused statistics + reduce_max finaliser was measured slower than the pair: 17.5 vs 5.0 + 7.6 us)
     PN_TRY(bn_fin(l, r, m.T64));
     return max_finalize(m.pmax, m.pidx, B, m.tpc64, r.cout, N, m.sgn, l.scale, l.shift, m.g, m.zstar, m.arg, st);
   }
@@ -512,7 +513,7 @@ struct Run {
     PN_TRY(seg_out_fwd(&a4, p(L.s5.kernel), p(L.s5.bias), M, 128, d.cseg, io.labels_seg, fseg ? io.loss_weights[1] / (float)M : 0.f,
                        io.out_seg, (fseg && training) ? w.seg_dlogits : nullptr, fseg ? w.seg_part : nullptr, st));
     if (fseg && io.scalars)
-      PN_TRY(sum_partials(w.seg_part, (int)cdivll(M, 256), seg_out_part_stride(), 2, io.scalars + 2, st));
+      PN_TRY(sum_partials(w.seg_part, (int)cdivll(M, seg_out_part_rows()), seg_out_part_stride(), 2, io.scalars + 2, st));
 
     // third output: the input transform (PointNet.py:292); identity for vanilla (:211)
     if (io.out_R) {

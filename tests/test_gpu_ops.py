@@ -479,7 +479,8 @@ def test_seg_out_fwd_matches_restatement(dev, B, N, C_):
     wd, bd, lab_d = w.to(dev), bias.to(dev), labels.int().to(dev)
     op = L.operand(zd, ca=cad, cc=ccd, ld=K, relu=True)
     stride = L.lib().pn_seg_out_part_stride()
-    nparts = (M + 255) // 256
+    rpb = L.lib().pn_seg_out_part_rows()
+    nparts = (M + rpb - 1) // rpb
     p = torch.empty(M, C_, device=dev); d = torch.empty(M, C_, device=dev); part = torch.zeros(nparts * stride, device=dev)
     L.check(L.lib().pn_seg_out_fwd(C.byref(op), L.ptr(wd), L.ptr(bd), M, K, C_, L.ptr(lab_d), 1.0 / M,
                                    L.ptr(p), L.ptr(d), L.ptr(part), L.current_stream()), "pn_seg_out_fwd")
