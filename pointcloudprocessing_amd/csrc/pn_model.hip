@@ -159,7 +159,10 @@ struct WS {
 static long long wgrad_slab_rows(int B, int N, int Ci, int Cj, int* spc_out) {
   const int bm = (Ci % 128 == 0 && Cj % 128 == 0) ? 128 : 64, bn = (Cj % 128 == 0) ? 128 : 64;
   const int n_out = (Ci / bm) * (Cj / bn);
-  int target = 512 / n_out;
+  // about one workgroup per CU: 512 slabs of 64 rows made the weight-gradient kernels write (and slab_reduce re-read) twice the
+  // bytes for no extra parallelism -- 1.40 -> 1.34 ms/step at B=32, N=1024 (sweep: 64: 1.47, 128: 1.38, 192: 1.36, 256-384: 1.34)
+  static const int target_blocks = getenv("PN_WGRAD_TARGET") ? atoi(getenv("PN_WGRAD_TARGET")) : 256;
+  int target = target_blocks / n_out;
   if (target < 1) target = 1;
   int spc = cdiv(target, B);
   const int max_spc = cdiv(N, 64);
