@@ -7,11 +7,13 @@
 
 namespace pn {
 
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
 // ---- one launch per dense layer ---------------------------------------------------------------------------------------
 // out[r][j] = sum_k x[r][k] * W(k, j)  (+ bias, BatchNormalization over the R rows, ReLU, inverted dropout).
-// Grid = (column blocks of 32) x (K splits).  A block's 256 threads are 32 columns x 8 k-slices; each thread streams its
-// weights straight from global memory into registers (a row of W is read as one 128-byte line per k) and keeps the 32
-// rows' accumulators in registers; x comes through LDS as a broadcast.  The splits of one column block meet in-launch:
+// Grid = (column blocks of 32) x (K splits).  The products run on the matrix cores in bf16 hi/lo split form (see the kernel);
+// operands are read straight from global memory in the MFMA register layout.  The splits of one column block meet in-launch:
 // every split writes its 32x32 partial tile, then draws a ticket; the last arriver sums the tiles in a fixed order and
 // finishes the layer for those 32 columns (statistics are per column, so column blocks are independent).  This replaces
 // the separate reduce/normalise launch (~6 us in the step's graph) by ~1-2 us of tail work in one block per 32 columns.
@@ -54,10 +56,9 @@ static inline int dl_split_len(int K) { return cdiv(cdiv(K, dl_nsplit(K)), DL_KS
 template <bool TRANS>
 __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a) {
   // one LDS object (a second one beside a staging array can cost a full vmcnt drain per step)
-  __shared__ __attribute__((aligned(16))) float lds[DL_SLICES * DL_ROWS * DL_COLS + DL_KSTEP * DL_ROWS + 16 * 32 + 4];
-  float* red = lds;                                        // [slice][row][col]
-  float* xs = lds + DL_SLICES * DL_ROWS * DL_COLS;         // [k][row]
-  float* fin = xs + DL_KSTEP * DL_ROWS;                    // finalize scratch [16][32]
+  __shared__ __attribute__((aligned(16))) float lds[4 * DL_ROWS * DL_COLS + 16 * 32 + 4];
+  float* red = lds;                                        // [wave][row][col]
+  float* fin = lds + 4 * DL_ROWS * DL_COLS;                // finalize scratch [16][32]
   unsigned* flag = reinterpret_cast<unsigned*>(fin + 16 * 32);
   const int tid = threadIdx.x, c = tid & 31, s = tid >> 5;
   const int j = blockIdx.x * DL_COLS + c;
@@ -68,66 +69,62 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a) {
   const bool small = a.R <= DL_ROWS;           // block-uniform: one row chunk, the tail keeps z in registers
   float own[DL_ROWS / DL_SLICES];
 
+  // ---- products on the matrix cores -----------------------------------------------------------------------------------------
+  // z tile (32 rows x 32 columns) = x (32 x k) . W (k x 32), one v_mfma_f32_32x32x16_bf16 triple per 16 k: both operands are split
+  // into bf16 hi + lo on the fly and the three significant products (lo*hi, hi*lo, hi*hi) accumulate in fp32 -- fp32-grade results
+  // (the dropped lo*lo term is 2^-16 of a product) without the LDS broadcast of x that bounded the vector-ALU form (~4 us per 128 k).
+  // Operands go straight from global memory to the MFMA layout: lane (r = lane % 32, g = lane / 32) supplies row r / column r and
+  // the 8 consecutive k at 8g.  Wave w owns the k16-steps w, w+4, ... of the block's k range; the four waves' accumulators are
+  // combined through LDS in a fixed order.
+  const int lane = tid & 63, wv = tid >> 6;
+  const int lr = lane & 31, lg = lane >> 5;
+  const int jw = blockIdx.x * DL_COLS + lr;                 // this lane's column as the B operand
+  const int jwc = jw < a.C ? jw : a.C - 1;
   for (int rc = 0; rc < a.R; rc += DL_ROWS) {
     const int nr = min(DL_ROWS, a.R - rc);
-    float acc[DL_ROWS];
+    f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < DL_ROWS; ++r) acc[r] = 0.f;
-    // software pipeline: the loads of step i+1 are in flight while step i is multiplied
-    float wn[DL_KPS], xn[DL_KPS];
-    auto issue = [&](int k0) {
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    const int xr = rc + (lr < nr ? lr : nr - 1);
+    float xa[8], wb[8];
+    auto issue = [&](int k0) {                              // k0: first k of this wave's step
 #pragma unroll
-      for (int e = 0; e < DL_KPS; ++e) {
-        const int k = k0 + s * DL_KPS + e;
+      for (int e = 0; e < 8; ++e) {
+        const int k = k0 + 8 * lg + e;
         const long long kc = k < kend ? k : kend - 1;
-        wn[e] = TRANS ? a.w[(long long)jc * a.ldw + kc] : a.w[kc * a.ldw + jc];
-      }
-#pragma unroll
-      for (int e = 0; e < DL_KPS; ++e) {
-        const int t = tid + e * 256;
-        const int r = t / DL_KSTEP, k = t % DL_KSTEP;
-        const int kk = (k0 + k < kend) ? k0 + k : kend - 1;
-        xn[e] = a.x[(long long)(rc + (r < nr ? r : nr - 1)) * a.ldx + kk];
+        xa[e] = a.x[(long long)xr * a.ldx + kc];
+        wb[e] = TRANS ? a.w[(long long)jwc * a.ldw + kc] : a.w[kc * a.ldw + jwc];
       }
     };
-    if (kbeg < kend) issue(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += DL_KSTEP) {
-      float wv[DL_KPS];
-      __syncthreads();                      // the previous step's readers are done with xs
+    int k0 = kbeg + 16 * wv;
+    if (k0 < kend) issue(k0);
+    for (; k0 < kend; k0 += 64) {
+      bf16x8 ah, al, bh, bl;
 #pragma unroll
-      for (int e = 0; e < DL_KPS; ++e) {
-        const int t = tid + e * 256;
-        const int r = t / DL_KSTEP, k = t % DL_KSTEP;
-        xs[k * DL_ROWS + r] = (r < nr && k0 + k < kend) ? xn[e] : 0.f;
-        wv[e] = (k0 + s * DL_KPS + e < kend) ? wn[e] : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        const bool kv = k0 + 8 * lg + e < kend;
+        const float xv = (kv && lr < nr) ? xa[e] : 0.f;
+        const float wvv = (kv && jw < a.C) ? wb[e] : 0.f;
+        ah[e] = (__bf16)xv;
+        al[e] = (__bf16)(xv - (float)ah[e]);
+        bh[e] = (__bf16)wvv;
+        bl[e] = (__bf16)(wvv - (float)bh[e]);
       }
-      __syncthreads();
-      if (k0 + DL_KSTEP < kend) issue(k0 + DL_KSTEP);
-#pragma unroll
-      for (int e = 0; e < DL_KPS; ++e) {
-        const float wk = wv[e];
-        const float4* xr = reinterpret_cast<const float4*>(xs + (s * DL_KPS + e) * DL_ROWS);
-#pragma unroll
-        for (int q = 0; q < DL_ROWS / 4; ++q) {
-          const float4 v = xr[q];
-          acc[4 * q + 0] = fmaf(v.x, wk, acc[4 * q + 0]);
-          acc[4 * q + 1] = fmaf(v.y, wk, acc[4 * q + 1]);
-          acc[4 * q + 2] = fmaf(v.z, wk, acc[4 * q + 2]);
-          acc[4 * q + 3] = fmaf(v.w, wk, acc[4 * q + 3]);
-        }
-      }
+      if (k0 + 64 < kend) issue(k0 + 64);                  // next step's loads fly under the MFMAs
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
     }
-    // combine the 8 k-slices in a fixed order
+    // combine the four waves in a fixed order: acc[e] is row (e & 3) + 8 (e >> 2) + 4 g, column r
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < DL_ROWS; ++r) red[(s * DL_ROWS + r) * DL_COLS + c] = acc[r];
+    for (int e = 0; e < 16; ++e) red[(wv * DL_ROWS + (e & 3) + 8 * (e >> 2) + 4 * lg) * DL_COLS + lr] = acc[e];
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < DL_ROWS / DL_SLICES; ++i) {
       const int r = s + DL_SLICES * i;
-      float t = 0.f;
-#pragma unroll
-      for (int q = 0; q < DL_SLICES; ++q) t += red[(q * DL_ROWS + r) * DL_COLS + c];
+      const float t = (red[(0 * DL_ROWS + r) * DL_COLS + c] + red[(1 * DL_ROWS + r) * DL_COLS + c]) +
+                      (red[(2 * DL_ROWS + r) * DL_COLS + c] + red[(3 * DL_ROWS + r) * DL_COLS + c]);
       own[i] = t;      // rows s, s+8, s+16, s+24 of this chunk: exactly the rows this thread finishes below
       // write-through (sc1) store: visible to every XCD once drained, so the meeting below needs no release fence
       if (!(single && small) && r < nr && j < a.C)

@@ -368,10 +368,11 @@ def test_dense_layer_matches_fp64_reference(dev, R, K, C_, trans, bn_mode, act, 
                                              act=act, keep=keep, rate=0.3, counters=cnt)
         torch.cuda.synchronize()
         assert int(cnt.abs().sum()) == 0
-        assert torch.allclose(z.double(), zr, rtol=1e-5, atol=2e-5), float((z.double() - zr).abs().max())
-        assert torch.allclose(a.double(), yr, rtol=1e-4, atol=1e-4), float((a.double() - yr).abs().max())
+        # products run as bf16 hi/lo splits on the matrix cores (3 of the 4 cross terms): ~2^-16 relative per product
+        assert torch.allclose(z.double(), zr, rtol=1e-4, atol=1e-4), float((z.double() - zr).abs().max())
+        assert torch.allclose(a.double(), yr, rtol=3e-4, atol=3e-4), float((a.double() - yr).abs().max())
         if bn_mode:
-            assert torch.allclose(mean.double(), mr, rtol=1e-5, atol=1e-5) and torch.allclose(invstd.double(), ir, rtol=1e-4, atol=1e-5)
+            assert torch.allclose(mean.double(), mr, rtol=1e-4, atol=1e-5) and torch.allclose(invstd.double(), ir, rtol=1e-4, atol=1e-5)
             assert torch.allclose(mm_k.double(), mmr, rtol=1e-5, atol=1e-6) and torch.allclose(mv_k.double(), mvr, rtol=1e-5, atol=1e-6)
 
 
