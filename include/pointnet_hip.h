@@ -287,6 +287,11 @@ typedef struct pn_model_io {
    * data-gradient chain reads them) on it, forked from and joined back into `stream` with events -- graph edges when
    * the call is being captured.  NULL (or == stream) = everything on `stream`.  Results are bit-identical either way. */
   void* aux_stream;
+  /* pn_model_backward only: 0 = the whole pass; 1 = everything down to and including the feature transform -- afterwards every
+   * gradient slot from "feature_transform.conv1.kernel" (pn_model_slot_info) to the end of the buffer is final; 2 = the rest (mlp_1,
+   * input transform).  Lets a data-parallel caller all-reduce the large first bucket while phase 2 runs.  1 must precede 2. */
+  int32_t bwd_phase;
+  int32_t pad3_;
 } pn_model_io;
 
 int pn_model_num_slots(const pn_model_desc* d);

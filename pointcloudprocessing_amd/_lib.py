@@ -50,7 +50,8 @@ class pn_model_io(C.Structure):
                 ("labels_seg", C.c_void_p), ("se3", C.c_void_p), ("loss_weights", C.c_float * 3),
                 ("pad2_", C.c_float), ("out_cls", C.c_void_p), ("out_seg", C.c_void_p), ("out_R", C.c_void_p),
                 ("scalars", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
-                ("prof_events", C.POINTER(C.c_void_p)), ("aux_stream", C.c_void_p)]
+                ("prof_events", C.POINTER(C.c_void_p)), ("aux_stream", C.c_void_p),
+                ("bwd_phase", C.c_int32), ("pad3_", C.c_int32)]
 
 
 # every symbol include/pointnet_hip.h declares: name -> (restype, argtypes)

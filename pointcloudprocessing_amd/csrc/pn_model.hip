@@ -675,13 +675,20 @@ struct Run {
       set_error("pn_model_backward: grads buffer is NULL");
       return PN_ERR_INVALID_ARGUMENT;
     }
-    PN_TRY(zero_fill2(G, L.total, reinterpret_cast<float*>(w.dcount), DENSE_MAX_COUNTERS, st));
     const pn_operand x64 = x64op();
     const float* Ws1 = p(L.s1.kernel);
     const bool fused = io.labels_cls != nullptr || io.labels_seg != nullptr;
     bool has_seg = d_seg != nullptr || (io.labels_seg != nullptr && io.loss_weights[1] != 0.f);
     bool has_cls = d_cls != nullptr || (io.labels_cls != nullptr && io.loss_weights[0] != 0.f);
     (void)fused;
+    const bool have_R_grad = !d.vanilla && (d_R != nullptr || (io.se3 != nullptr && io.loss_weights[2] != 0.f) || d.reg_in);
+    const bool trunk = has_seg || has_cls || (!d.vanilla && d.reg_feat);
+    // pn_model_io.bwd_phase: 0 = the whole backward pass; 1 = heads, mlp_2 and the feature transform (every gradient slot from
+    // feature_transform.* to the end of the flat buffer is final afterwards); 2 = mlp_1 and the input transform (the slots before
+    // feature_transform.*).  A data-parallel caller all-reduces the first bucket while phase 2 runs (engine.TrainStep).
+    const int phase = io.bwd_phase;
+    if (phase != 2) {
+    PN_TRY(zero_fill2(G, L.total, reinterpret_cast<float*>(w.dcount), DENSE_MAX_COUNTERS, st));
 
     // ---- segmentation head ----
     bool have_dx64 = false;     // w.dX64 holds the seg head's contribution to d(X_64)
@@ -728,8 +735,6 @@ struct Run {
     float* dG = w.mm23.dG;
     PN_TRY(add2(have_dGcls ? w.dGcls : nullptr, have_dGseg ? w.dGseg : nullptr, dG, (long long)B * 1024, st));
 
-    const bool have_R_grad = !d.vanilla && (d_R != nullptr || (io.se3 != nullptr && io.loss_weights[2] != 0.f) || d.reg_in);
-    const bool trunk = has_seg || has_cls || (!d.vanilla && d.reg_feat);
     if (!trunk && !have_R_grad) return PN_OK;
 
     // ---- mlp_2 ----
@@ -766,6 +771,9 @@ struct Run {
       PN_TRY(conv_bwd_data(&dzf1, p(L.fT.c1.kernel), 0, B, N, 64, 64, have_dx ? w.tmpA12 : nullptr, w.m12.Z, w.m12.scale, w.m12.shift,
                            w.m12.dy, w.bpart, prec, st));
     }
+    }   // phase != 2
+    if (phase == 1) return PN_OK;
+    if (!trunk && !have_R_grad) return PN_OK;
     // ---- mlp_1 ----
     PN_TRY(bwd_step(w.m12, L.m12, w.m11, lazy(w.m11)));
     PN_TRY(bn_bwd_fin(w.m11, L.m11, w.bpart));

@@ -2,8 +2,10 @@
 
 A PointNet training step is ~200 short kernels; launched eagerly the host (ctypes + hipLaunchKernel, ~7 us each) is
 the bottleneck.  The native plan never allocates or synchronises, so the whole step is captured once per input shape
-and replayed: graph 1 = dropout masks + forward + losses + backward, then the gradient all-reduce (eager, on the same
-stream), then graph 2 = Adam.  With one GPU both graphs are fused into one.
+and replayed.  One GPU: a single graph (dropout masks, forward, losses, backward, Adam).  Data parallel: graph 1 = dropout masks,
+forward, losses and the backward pass down to the feature transform; then the RCCL all-reduce of that gradient bucket (13.5 of
+16.8 MB) is issued asynchronously and graph 1b = the rest of the backward pass (mlp_1, input transform) runs under it; then the
+small second bucket is reduced and graph 2 = Adam.
 
 Everything a TrainStep launches goes to ITS OWN HIP stream (created here), fenced against the caller's stream with
 events on entry and exit: the step stays off the legacy null stream's implicit synchronisation, and several
@@ -17,6 +19,8 @@ tests/test_gpu_train.py::test_interleaved_models_graph_replay_is_exact keeps tha
 from __future__ import annotations
 
 from typing import Optional, Sequence
+
+import os
 
 import torch
 
@@ -43,6 +47,8 @@ class TrainStep:
         # both graphs unless split_optimizer asks for the data-parallel layout anyway (rehearsal of the N > 1 path on one GPU)
         self.split = (self.world > 1) if split_optimizer is None else bool(split_optimizer)
         self.reduce = self.split and dist.is_available() and dist.is_initialized()
+        # PN_DDP_OVERLAP=0: one all-reduce of the whole buffer after the backward pass instead of the two overlapped buckets
+        self.overlap = os.environ.get("PN_DDP_OVERLAP", "1") != "0"
         dev = model.params_flat.device
         self.dev = dev
         # static inputs: a graph replays fixed addresses
@@ -54,7 +60,7 @@ class TrainStep:
         self._mask_seed = int(torch.randint(0, 2**62, (1,)).item()) ^ (rank_salt() << 20)   # per process / rank
         self._mask_step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.mode = "eager"
-        self._g1 = self._g2 = None
+        self._g1 = self._g1b = self._g2 = None
         self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         # capture needs a created stream; a caller-supplied null stream only replays
         self._capture_stream = self.stream if self.stream.cuda_stream != 0 else torch.cuda.Stream(device=dev)
@@ -66,21 +72,48 @@ class TrainStep:
         self._calls = 0           # the first two steps run eagerly (they warm up allocator / lazy init), then the step is captured
 
     # -- pieces ---------------------------------------------------------------------------------------------
-    def _fwd_bwd(self):
+    def _fwd_bwd(self, phase: int = 0):
         rate = self.model._dropout_rate
         if rate > 0:        # one native launch; the step counter lives on the device, so graph replays draw fresh masks
             check(lib().pn_dropout_masks(ptr(self.keep[0]), self.keep[0].numel(), ptr(self.keep[1]), self.keep[1].numel(), rate,
                                          self._mask_seed, ptr(self._mask_step), current_stream()), "pn_dropout_masks")
         self.model._aux_stream = self.aux_stream
         try:
-            self.model.fused_loss_step(self.pc, self.y_cls, self.y_seg, self.se3, self.lw, keep=self.keep if rate > 0 else None)
+            self.model.fused_loss_step(self.pc, self.y_cls, self.y_seg, self.se3, self.lw, keep=self.keep if rate > 0 else None,
+                                       backward_phase=phase)
         finally:
             self.model._aux_stream = None
 
+    def _bwd2(self):
+        self.model._aux_stream = self.aux_stream
+        try:
+            self.model._run_backward(None, None, None, 2)
+        finally:
+            self.model._aux_stream = None
+
+    def _reduce_async(self, lo, hi):
+        """RCCL sum over xGMI of one gradient bucket; runs on RCCL's stream behind everything enqueued so far"""
+        if not self.reduce or hi <= lo:
+            return None
+        if not self.overlap:
+            if lo != 0:
+                return None                                   # single collective: issued with the second bucket
+            hi = self.model.grads_flat.numel()
+        return self.dist.all_reduce(self.model.grads_flat[lo:hi], async_op=True)
+
     def _eager(self):
-        self._fwd_bwd()
-        if self.reduce:
-            self.dist.all_reduce(self.model.grads_flat)        # RCCL sum over xGMI
+        if not self.split:
+            self._fwd_bwd()
+        else:
+            # bucket 1 (feature transform .. heads, ~80 % of the bytes) is reduced while mlp_1 / the input transform run backward
+            cut, end = self.model.grad_bucket_boundary(), self.model.grads_flat.numel()
+            self._fwd_bwd(1)
+            h1 = self._reduce_async(cut, end)
+            self._bwd2()
+            h2 = self._reduce_async(0, cut)
+            for h in (h1, h2):
+                if h is not None:
+                    h.wait()
         self.opt.step(self.model.grads_flat, 1.0 / self.world)
 
     def _capture(self):
@@ -88,20 +121,23 @@ class TrainStep:
             torch.cuda.synchronize()
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, stream=self._capture_stream):
-                self._fwd_bwd()
+                self._fwd_bwd(1 if self.split else 0)
                 if not self.split:
                     self.opt.step(self.model.grads_flat, 1.0)
-            g2 = None
+            g1b = g2 = None
             if self.split:
+                g1b = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1b, stream=self._capture_stream):
+                    self._bwd2()
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, stream=self._capture_stream):
                     self.opt.step(self.model.grads_flat, 1.0 / self.world)
             torch.cuda.synchronize()
-            self._g1, self._g2, self.mode = g1, g2, "hipgraph"
+            self._g1, self._g1b, self._g2, self.mode = g1, g1b, g2, "hipgraph"
         except Exception as e:                                  # capture unsupported: stay eager (a speed matter only)
             import sys
             print(f"# hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly", file=sys.stderr)
-            self._g1 = self._g2 = None
+            self._g1 = self._g1b = self._g2 = None
             self.mode = "eager"
 
     # -- API ------------------------------------------------------------------------------------------------
@@ -142,8 +178,13 @@ class TrainStep:
             else:
                 self._g1.replay()
                 if self.split:
-                    if self.reduce:
-                        self.dist.all_reduce(self.model.grads_flat)
+                    cut, end = self.model.grad_bucket_boundary(), self.model.grads_flat.numel()
+                    h1 = self._reduce_async(cut, end)           # overlaps graph 1b
+                    self._g1b.replay()
+                    h2 = self._reduce_async(0, cut)
+                    for h in (h1, h2):
+                        if h is not None:
+                            h.wait()
                     self._g2.replay()
         self._exit()
 

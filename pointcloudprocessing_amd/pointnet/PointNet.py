@@ -565,9 +565,11 @@ class PointNet(torch.nn.Module):
             self.input_transform._last_predicted = R
         return cls, seg, R
 
-    def _run_backward(self, d_cls, d_seg, d_R):
+    def _run_backward(self, d_cls, d_seg, d_R, phase: int = 0):
+        """phase 0: the whole backward pass; 1 / 2: its two halves (pn_model_io.bwd_phase) for gradient-bucket overlap"""
         lc = self._last_call
         io = lc["io"]
+        io.bwd_phase = int(phase)
         def c(t):
             return None if t is None else t.contiguous()
         d_cls, d_seg, d_R = c(d_cls), c(d_seg), c(d_R)
@@ -585,10 +587,17 @@ class PointNet(torch.nn.Module):
 
     call = forward
 
-    def fused_loss_step(self, pc, labels_cls, labels_seg, se3, loss_weights, keep=None):
+    def grad_bucket_boundary(self) -> int:
+        """offset (floats) in ``grads_flat`` from which every slot is final after backward phase 1"""
+        for n, s in self._weights.slots.items():
+            if n.startswith("feature_transform." if not self._vanilla else "mlp_2_1."):
+                return int(s["offset"])
+        raise PointNetHipError("parameter layout has no feature_transform / mlp_2_1 slot")
+
+    def fused_loss_step(self, pc, labels_cls, labels_seg, se3, loss_weights, keep=None, backward_phase: int = 0):
         """forward + the three keras losses of pointnet_train.py:334-345 + backward, all native.  Leaves the
         gradients in ``grads_flat`` and the loss / metric sums in ``self.scalars`` (see pn_model_io)."""
         fused = dict(labels_cls=labels_cls, labels_seg=labels_seg.reshape(-1), se3=se3, loss_weights=loss_weights, keep=keep)
         outs = self._run_forward(pc, True, fused)
-        self._run_backward(None, None, None)
+        self._run_backward(None, None, None, backward_phase)
         return outs

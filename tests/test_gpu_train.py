@@ -41,14 +41,16 @@ def test_native_train_step_learns_and_graph_matches_eager(dev):
     y_seg = torch.randint(0, 12, (B, N), generator=g, dtype=torch.int32).to(dev)
     se3 = torch.eye(3).expand(B, 3, 3).contiguous().to(dev)
     finals, w0 = [], None
-    for use_graph, aux in ((False, True), (True, True), (False, False), (True, False)):
+    # split: the data-parallel step layout (backward in two phases around the bucketed all-reduce, Adam in its own graph)
+    for use_graph, aux, split in ((False, True, False), (True, True, False), (False, False, False), (True, False, False),
+                                  (False, False, True), (True, False, True)):
         m = PointNet(23, 12, 0.0, 42, precision="bf16x3", device=dev)     # dropout 0: deterministic step
         if w0 is None:
             w0 = m.params_flat.data.clone()
         else:
             m.params_flat.data.copy_(w0)       # the classification head is unseeded (PointNet.py:186-206): share the start
         opt = KerasAdam(m.params_flat.data, 1e-3, 7000, 0.7)
-        ts = TrainStep(m, opt, B, N, (1.0, 1.0, 1.0), use_graph=use_graph, aux=aux)   # aux: parameter gradients on a 2nd stream
+        ts = TrainStep(m, opt, B, N, (1.0, 1.0, 1.0), use_graph=use_graph, aux=aux, split_optimizer=split)   # aux: parameter gradients on a 2nd stream
         losses = []
         for i in range(62):
             ts(pc, y_cls, y_seg, se3)
