@@ -275,10 +275,15 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a) {
   }
 }
 
-// Backward of a dense layer's tail fused into its weight gradient (R <= 32): every thread owns one column j, rebuilds that
-// column's dz from da / z / the dropout mask (its 32 rows fit in registers, so the two column sums of the BN backward need no
-// exchange at all), and accumulates dw[k][j] for the block's 16 k.  The blocks of the first k-tile also write dz, dgamma,
-// dbeta / dbias.  One launch instead of two; dw may be NULL (frozen layer: only dz is produced, grid.y = 1).
+// Backward of a dense layer's tail fused into its weight gradient (R <= 32), on the matrix cores.
+// Grid = (32-column tiles of C) x (groups of 256 k); a wave owns two 32 x 32 tiles of dw = x^T . dz.  Lane (j = lane % 32,
+// g = lane / 32) rebuilds dz for column j and the 16 rows {8g..8g+7, 16+8g..16+8g+7} from da / z / the dropout mask -- exactly
+// the B operand of its two MFMA k-steps; the two halves of a column meet with one xor-32 shuffle for the BN-backward sums.
+// The first k-group's wave 0 also writes dz, dgamma, dbeta / dbias.  Operands are split bf16 hi + lo (3 products, fp32-grade).
+// dw may be NULL (frozen layer: only dz is produced).
+constexpr int DB_TPW = 2;                 // 32-k tiles per wave
+constexpr int DB_KG = 4 * DB_TPW * 32;    // k per block
+
 __global__ __launch_bounds__(256) void dense_bwd_fused_kernel(const float* __restrict__ da, const float* __restrict__ z,
                                                               const float* __restrict__ x, int ldx, int R, int K, int C,
                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -287,83 +292,132 @@ __global__ __launch_bounds__(256) void dense_bwd_fused_kernel(const float* __res
                                                               float keep_scale, float* __restrict__ dz, float* __restrict__ dgamma,
                                                               float* __restrict__ dbeta, float* __restrict__ dbias,
                                                               float* __restrict__ dw) {
-  constexpr int KT = 16;
-  constexpr int WRC = 32;
-  __shared__ __attribute__((aligned(16))) float xs[KT][WRC];
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lg = lane >> 5;
+  const int j = blockIdx.x * 32 + lr;
   const bool jv = j < C;
   const int jc = jv ? j : C - 1;
-  const int k0 = blockIdx.y * KT;
   float sc = 1.f, sh = 0.f, mu = 0.f, is = 1.f;
   if (bn_mode) {
     mu = mean[jc]; is = invstd[jc];
     sc = gamma[jc] * is;
     sh = beta[jc] - mu * sc;
   }
-  float d[WRC], zh[WRC];
-  unsigned kmask = 0xffffffffu;             // dropout keep bits of this column's rows
+  // this lane's 16 rows of column j
+  float d[16], zh[16];
+  unsigned kmask = 0xffffu;
 #pragma unroll
-  for (int r = 0; r < WRC; ++r) {           // unconditional, clamped loads: all in flight together
+  for (int q = 0; q < 16; ++q) {            // unconditional, clamped loads: all in flight together
+    const int r = (q >> 3) * 16 + 8 * lg + (q & 7);
     const long long o = (long long)min(r, R - 1) * C + jc;
-    d[r] = da[o];
-    zh[r] = z[o];
+    d[q] = da[o];
+    zh[q] = z[o];
   }
   if (keep) {
     kmask = 0u;
 #pragma unroll
-    for (int r = 0; r < WRC; ++r) kmask |= (keep[(long long)min(r, R - 1) * C + jc] ? 1u : 0u) << r;
+    for (int q = 0; q < 16; ++q) {
+      const int r = (q >> 3) * 16 + 8 * lg + (q & 7);
+      kmask |= (keep[(long long)min(r, R - 1) * C + jc] ? 1u : 0u) << q;
+    }
   }
+  // first x tile of this wave in flight while dz is rebuilt
+  const int kbase = blockIdx.y * DB_KG + wave * (DB_TPW * 32);
+  float xa[16];
+  auto issue_x = [&](int k0) {
+    const int kk = min(k0 + lr, K - 1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int r = (q >> 3) * 16 + 8 * lg + (q & 7);
+      xa[q] = x[(long long)min(r, R - 1) * ldx + kk];
+    }
+  };
+  if (dw && kbase < K) issue_x(kbase);
   const float kscale = keep ? keep_scale : 1.f;
   float S1 = 0.f, S2 = 0.f;
 #pragma unroll
-  for (int r = 0; r < WRC; ++r) {
-    float v = ((kmask >> r) & 1u) ? d[r] * kscale : 0.f;
-    if (act == 1 && !(fmaf(sc, zh[r], sh) > 0.f)) v = 0.f;
-    if (r >= R) v = 0.f;
-    zh[r] = (zh[r] - mu) * is;
-    d[r] = v;
+  for (int q = 0; q < 16; ++q) {
+    const int r = (q >> 3) * 16 + 8 * lg + (q & 7);
+    float v = ((kmask >> q) & 1u) ? d[q] * kscale : 0.f;
+    if (act == 1 && !(fmaf(sc, zh[q], sh) > 0.f)) v = 0.f;
+    if (r >= R || !jv) v = 0.f;
+    zh[q] = (zh[q] - mu) * is;
+    d[q] = v;
     S1 += v;
-    S2 = fmaf(v, zh[r], S2);
+    S2 = fmaf(v, zh[q], S2);
   }
+  S1 += __shfl_xor(S1, 32, 64);             // the other 16 rows of the column live in lane ^ 32
+  S2 += __shfl_xor(S2, 32, 64);
   if (bn_mode == 1) {
     const float invR = 1.f / (float)R;
     const float m1 = S1 * invR, m2 = S2 * invR;
 #pragma unroll
-    for (int r = 0; r < WRC; ++r) d[r] = (r < R) ? sc * (d[r] - m1 - zh[r] * m2) : 0.f;
+    for (int q = 0; q < 16; ++q) {
+      const int r = (q >> 3) * 16 + 8 * lg + (q & 7);
+      d[q] = (r < R && jv) ? sc * (d[q] - m1 - zh[q] * m2) : 0.f;
+    }
   } else if (bn_mode == 2) {
 #pragma unroll
-    for (int r = 0; r < WRC; ++r) d[r] *= sc;
+    for (int q = 0; q < 16; ++q) d[q] *= sc;
   }
-  if (blockIdx.y == 0 && jv) {
+  if (blockIdx.y == 0 && wave == 0 && jv) {
 #pragma unroll
-    for (int r = 0; r < WRC; ++r)
-      if (r < R) dz[(long long)r * C + j] = d[r];
-    if (bn_mode == 1) {
-      if (dgamma) dgamma[j] = S2;
-      if (dbeta) dbeta[j] = S1;
-    } else if (bn_mode == 0 && dbias) {
-      dbias[j] = S1;
+    for (int q = 0; q < 16; ++q) {
+      const int r = (q >> 3) * 16 + 8 * lg + (q & 7);
+      if (r < R) dz[(long long)r * C + j] = d[q];
+    }
+    if (lg == 0) {
+      if (bn_mode == 1) {
+        if (dgamma) dgamma[j] = S2;
+        if (dbeta) dbeta[j] = S1;
+      } else if (bn_mode == 0 && dbias) {
+        dbias[j] = S1;
+      }
     }
   }
   if (!dw) return;
-  for (int t = threadIdx.x; t < KT * WRC; t += 256) {
-    const int k = t / WRC, r = t % WRC;
-    xs[k][r] = (r < R && k0 + k < K) ? x[(long long)r * ldx + k0 + k] : 0.f;
-  }
-  __syncthreads();
-#pragma unroll 2
-  for (int k = 0; k < KT; ++k) {            // k outermost: at most two rows of the x tile live in registers at a time
-    const float4* xr = reinterpret_cast<const float4*>(&xs[k][0]);
-    float a0 = 0.f, a1 = 0.f;
+  // B operand (dz) of the two k16-steps, bf16 hi + lo
+  bf16x8 bh[2], bl[2];
 #pragma unroll
-    for (int q = 0; q < WRC / 4; ++q) {
-      const float4 v = xr[q];
-      a0 = fmaf(v.x, d[4 * q + 0], a0);
-      a1 = fmaf(v.y, d[4 * q + 1], a1);
-      a0 = fmaf(v.z, d[4 * q + 2], a0);
-      a1 = fmaf(v.w, d[4 * q + 3], a1);
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = d[8 * t + e];
+      bh[t][e] = (__bf16)v;
+      bl[t][e] = (__bf16)(v - (float)bh[t][e]);
     }
-    if (jv && k0 + k < K) dw[(long long)(k0 + k) * C + j] = a0 + a1;
+#pragma unroll
+  for (int tile = 0; tile < DB_TPW; ++tile) {
+    const int k0 = kbase + tile * 32;
+    if (k0 >= K) break;                      // wave-uniform
+    bf16x8 ah[2], al[2];
+    const bool kv = k0 + lr < K;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int r = 16 * t + 8 * lg + e;
+        const float v = (kv && r < R) ? xa[8 * t + e] : 0.f;
+        ah[t][e] = (__bf16)v;
+        al[t][e] = (__bf16)(v - (float)ah[t][e]);
+      }
+    if (tile + 1 < DB_TPW && k0 + 32 < K) issue_x(k0 + 32);
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh[t], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl[t], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh[t], acc, 0, 0, 0);
+    }
+    if (jv) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int k = k0 + (e & 3) + 8 * (e >> 2) + 4 * lg;
+        if (k < K) dw[(long long)k * C + j] = acc[e];
+      }
+    }
   }
 }
 
@@ -619,7 +673,7 @@ int dense_bwd_fused(const float* da, const float* z, const float* x, int ldx, in
   PN_CHECK_ARG(da && z && dz && R > 0 && R <= 32 && C > 0, "dense_bwd_fused: bad arguments (R must be <= 32)");
   PN_CHECK_ARG(!dw || (x && K > 0), "dense_bwd_fused: the weight gradient needs the layer input");
   PN_CHECK_ARG(!bn_mode || (gamma && beta && mean && invstd), "dense_bwd_fused: BatchNormalization needs gamma/beta/mean/invstd");
-  hipLaunchKernelGGL(dense_bwd_fused_kernel, dim3(cdiv(C, 256), dw ? cdiv(K, 16) : 1), dim3(256), 0, st, da, z, x, ldx, R, K, C, gamma,
+  hipLaunchKernelGGL(dense_bwd_fused_kernel, dim3(cdiv(C, 32), dw ? cdiv(K, DB_KG) : 1), dim3(256), 0, st, da, z, x, ldx, R, K, C, gamma,
                      beta, mean, invstd, bn_mode, act, keep, keep_scale, dz, dgamma, dbeta, dbias, dw);
   PN_CHECK_LAUNCH();
   return PN_OK;
