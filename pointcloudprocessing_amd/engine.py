@@ -101,6 +101,14 @@ class TrainStep:
             hi = self.model.grads_flat.numel()
         return self.dist.all_reduce(self.model.grads_flat[lo:hi], async_op=True)
 
+    @staticmethod
+    def _wait_last(*handles):
+        """the collectives of one process group run in order on one RCCL stream: waiting for the last issued one is enough, and
+        every cross-stream wait costs ~50-100 us on this stack"""
+        live = [h for h in handles if h is not None]
+        if live:
+            live[-1].wait()
+
     def _eager(self):
         if not self.split:
             self._fwd_bwd()
@@ -111,9 +119,7 @@ class TrainStep:
             h1 = self._reduce_async(cut, end)
             self._bwd2()
             h2 = self._reduce_async(0, cut)
-            for h in (h1, h2):
-                if h is not None:
-                    h.wait()
+            self._wait_last(h1, h2)
         self.opt.step(self.model.grads_flat, 1.0 / self.world)
 
     def _capture(self):
@@ -182,9 +188,7 @@ class TrainStep:
                     h1 = self._reduce_async(cut, end)           # overlaps graph 1b
                     self._g1b.replay()
                     h2 = self._reduce_async(0, cut)
-                    for h in (h1, h2):
-                        if h is not None:
-                            h.wait()
+                    self._wait_last(h1, h2)
                     self._g2.replay()
         self._exit()
 
