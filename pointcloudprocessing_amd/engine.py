@@ -123,20 +123,23 @@ class TrainStep:
         self.opt.step(self.model.grads_flat, 1.0 / self.world)
 
     def _capture(self):
+        # capture_error_mode="thread_local": RCCL's watchdog thread polls its work events with hipEventQuery all the time; under the
+        # default "global" mode that query is illegal while THIS thread captures and the watchdog aborts the process
+        # (c10::DistBackendError "operation not permitted when stream is capturing" -- seen 2 times in 14 data-parallel rehearsals).
         try:
             torch.cuda.synchronize()
             g1 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1, stream=self._capture_stream):
+            with torch.cuda.graph(g1, stream=self._capture_stream, capture_error_mode="thread_local"):
                 self._fwd_bwd(1 if self.split else 0)
                 if not self.split:
                     self.opt.step(self.model.grads_flat, 1.0)
             g1b = g2 = None
             if self.split:
                 g1b = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1b, stream=self._capture_stream):
+                with torch.cuda.graph(g1b, stream=self._capture_stream, capture_error_mode="thread_local"):
                     self._bwd2()
                 g2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g2, stream=self._capture_stream):
+                with torch.cuda.graph(g2, stream=self._capture_stream, capture_error_mode="thread_local"):
                     self.opt.step(self.model.grads_flat, 1.0 / self.world)
             torch.cuda.synchronize()
             self._g1, self._g1b, self._g2, self.mode = g1, g1b, g2, "hipgraph"
