@@ -51,6 +51,7 @@ struct GemmArgs {
   const float* sgn;         // MAX
   float* pmax;              // MAX [tiles][C]
   int* pidx;                // MAX [tiles][C]
+  int colsum;               // WGRAD: also emit sum_rows a[row][i] as an extra row after each slab (slab stride Ci*C + Ci)
   int dbg;                  // PN_GEMM_DBG ablations (tools/gemm_probe.py): 1 no output stores, 2 no statistics, 4 no A loads, 8 no W loads
 };
 
@@ -192,10 +193,12 @@ struct TrnStage {
         if (HAS2) asm volatile("" : "+v"(y[p][e]));
       }
   }
+  // returns (when want_sum, block-uniform) the sum of the values this lane staged: its channel, the rows it gathered
   template <int NS>
-  __device__ __forceinline__ void finish(__bf16* __restrict__ Thi, __bf16* __restrict__ Tlo, const pn_operand& op,
-                                         int nvalid_k, int nvalid_r, int coef0, int tid) {
+  __device__ __forceinline__ float finish(__bf16* __restrict__ Thi, __bf16* __restrict__ Tlo, const pn_operand& op,
+                                          int nvalid_k, int nvalid_r, int coef0, int tid, bool want_sum = false) {
     constexpr int PITCH = Geo<BK>::PITCH;
+    float csum = 0.f;
     const int r = tid % TR, kgin = tid / TR;
     const bool rv = r < nvalid_r;
     const int rc = rv ? r : (nvalid_r - 1);
@@ -215,8 +218,10 @@ struct TrnStage {
         if (HAS2) t = fmaf(cb, y[p][e], t);
         v[e] = (rv && k < nvalid_k) ? fmaxf(t, lo) : 0.f;
       }
+      if (want_sum) csum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
       cvt_store8(Thi + r * PITCH + kg * 8, Tlo + r * PITCH + kg * 8, v, NS == 3);
     }
+    return csum;
   }
 };
 
@@ -332,6 +337,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
 
   if (MODE == MODE_WGRAD) {
     const int i0 = blockIdx.y * BM, j0 = blockIdx.z * BN;
+    const bool want_cs = g.colsum != 0 && blockIdx.z == 0;     // block-uniform
+    float cs = 0.f;
     const int rbeg = tin * g.K;
     const int rend = min(g.N, rbeg + g.K);
     for (int r0 = rbeg; r0 < rend; r0 += BK) {
@@ -342,7 +349,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
       sa.issue(g.a, rowbase * g.a.ld + i0, nk, g.Ci - i0, tid);
       sb.issue(g.b, rowbase * g.b.ld + j0, nk, g.C - j0, tid);
       sa.pin();
-      sa.template finish<NS>(Ahi, Alo, g.a, nk, g.Ci - i0, i0, tid);
+      cs += sa.template finish<NS>(Ahi, Alo, g.a, nk, g.Ci - i0, i0, tid, want_cs);
       sb.pin();
       sb.template finish<NS>(Bhi, Blo, g.b, nk, g.C - j0, j0, tid);
       __syncthreads();
@@ -350,7 +357,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
       __syncthreads();
     }
     // slab store
-    float* slab = g.out + (long long)bx * g.Ci * g.C;
+    const long long slab_stride = (long long)g.Ci * g.C + (g.colsum ? g.Ci : 0);
+    float* slab = g.out + (long long)bx * slab_stride;
+    if (want_cs) {
+      // the 256 / BM threads that share a channel combine through LDS (the tiles are dead after the last barrier), fixed order
+      constexpr int TPGA = 256 / BM;
+      float* red = reinterpret_cast<float*>(lds_raw);
+      red[(tid / BM) * BM + (tid % BM)] = cs;
+      __syncthreads();
+      if (tid < BM && i0 + tid < g.Ci) {
+        float t = red[tid];
+#pragma unroll
+        for (int q = 1; q < TPGA; ++q) t += red[q * BM + tid];
+        slab[(long long)g.Ci * g.C + i0 + tid] = t;
+      }
+    }
     const int r = lane & 31, h = lane >> 5;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -618,7 +639,7 @@ static int dispatch_wgrad(const GemmArgs& g, bool b2, int prec, dim3 grid, hipSt
 }
 
 int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, int Cj, int slab_rows, float* slabs, int prec,
-               hipStream_t st) {
+               hipStream_t st, int colsum) {
   PN_TRY(check_operand(a, "pn_conv_wgrad.a"));
   PN_TRY(check_operand(b, "pn_conv_wgrad.b"));
   PN_CHECK_ARG(!a->s2, "pn_conv_wgrad: operand a has no second source");
@@ -633,7 +654,7 @@ int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, i
   memset(&g, 0, sizeof(g));
   g.a = *a; g.b = *b; g.B = B; g.N = N; g.K = slab_rows; g.C = Cj; g.Ci = Ci;
   g.tiles_per_cloud = cdiv(N, slab_rows);
-  g.out = slabs;
+  g.out = slabs; g.colsum = colsum;
   const bool b2 = b->s2 != nullptr;
   const int nslab = B * g.tiles_per_cloud;
   if (Ci % 128 == 0 && Cj % 128 == 0) return dispatch_wgrad<128, 128>(g, b2, prec, dim3(nslab, Ci / 128, Cj / 128), st);

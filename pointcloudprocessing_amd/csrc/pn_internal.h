@@ -13,7 +13,7 @@ int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, in
                   const float* zmask, const float* msc, const float* msh, float* out, float* stat_partials, int prec,
                   hipStream_t st);
 int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, int Cj, int slab_rows, float* slabs, int prec,
-               hipStream_t st);
+               hipStream_t st, int colsum = 0);   // colsum: every slab is followed by Ci floats = sum over its rows of operand a
 
 // pn_panel.hip
 int weights_prep(const float* w, int K, int C, void* hi, void* lo, hipStream_t st);

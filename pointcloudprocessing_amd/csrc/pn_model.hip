@@ -212,9 +212,9 @@ static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, 
     m.e = A.get<float>((n + ".e").c_str(), C);
     m.nege = A.get<float>((n + ".nege").c_str(), C);
     m.f = A.get<float>((n + ".f").c_str(), C);
-    m.a1part = A.get<float>((n + ".a1part").c_str(), (size_t)T * K);
-    m.a1 = A.get<float>((n + ".a1").c_str(), K);
-    m.gram = A.get<float>((n + ".gram").c_str(), (size_t)K * K);
+    m.gram = A.get<float>((n + ".gram").c_str(), (size_t)K * K + K);   // A^T A followed by a1 = A^T 1 (one slab reduction for both)
+    m.a1 = m.gram + (size_t)K * K;
+    m.a1part = nullptr;
     m.GW = A.get<float>((n + ".GW").c_str(), (size_t)K * C);
     m.Pm = A.get<float>((n + ".Pm").c_str(), (size_t)K * K);
     m.q = A.get<float>((n + ".q").c_str(), K);
@@ -299,7 +299,9 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
     size_t sf = 0;
     const int shapes[][2] = {{64, 64}, {64, 128}, {128, 128}, {64, 512}, {512, 256}, {256, 128}};
     for (auto& s : shapes) {
-      const size_t f = wgrad_slab_floats(B, N, s[0], s[1]);
+      int spc_;
+      wgrad_slab_rows(B, N, s[0], s[1], &spc_);
+      const size_t f = wgrad_slab_floats(B, N, s[0], s[1]) + (size_t)B * spc_ * s[0];   // + the optional column-sum row per slab
       if (f > sf) sf = f;
     }
     const size_t c3f = (size_t)T * 3 * 64;
@@ -550,16 +552,19 @@ struct Run {
   int wgrad_to(const pn_operand& a, const pn_operand& b, int Ci, int Cj, float* out, bool per_cloud) {
     return wgrad_general(a, b, B, N, Ci, Cj, out, per_cloud, prec);
   }
-  int wgrad_general(const pn_operand& a, const pn_operand& b, int Bq, int Nq, int Ci, int Cj, float* out, bool per_cloud, int pr) {
+  // colsum: `out` receives Ci*Cj products followed by Ci column sums of operand a (Gram matrix + a1 in one pass over the rows)
+  int wgrad_general(const pn_operand& a, const pn_operand& b, int Bq, int Nq, int Ci, int Cj, float* out, bool per_cloud, int pr,
+                    bool colsum = false) {
     int spc;
     const int rows = (int)wgrad_slab_rows(Bq, Nq, Ci, Cj, &spc);
     float* sl = cur_slabs();
-    if ((size_t)Bq * spc * Ci * Cj > (sl == w.slabs ? w.slab_floats : w.slab_main_floats)) {
+    const size_t elems = (size_t)Ci * Cj + (colsum ? Ci : 0);
+    if ((size_t)Bq * spc * elems > (sl == w.slabs ? w.slab_floats : w.slab_main_floats)) {
       set_error("wgrad: slab scratch too small");
       return PN_ERR_WORKSPACE;
     }
-    PN_TRY(conv_wgrad(&a, &b, Bq, Nq, Ci, Cj, rows, sl, pr, st));
-    return slab_reduce(sl, Bq * spc, per_cloud ? spc : Bq * spc, (long long)Ci * Cj, out, st);
+    PN_TRY(conv_wgrad(&a, &b, Bq, Nq, Ci, Cj, rows, sl, pr, st, colsum ? 1 : 0));
+    return slab_reduce(sl, Bq * spc, per_cloud ? spc : Bq * spc, (long long)elems, out, st);
   }
   int bn_bwd_fin(const CL& l, const LRef& r, const float* part) {
     const int bs = bn_batch(r.block) ? 1 : 0;
@@ -591,9 +596,7 @@ struct Run {
       float* dw = gr(r.kernel);
       const float* Wk = p(r.kernel);
       PN_TRY(side([=] {
-        PN_TRY(wgrad_to(xop, xop, K, K, mm.gram, false));
-        PN_TRY(colsum_lazy(&xop, B, N, K, mm.a1part, st));
-        PN_TRY(slab_reduce(mm.a1part, T, T, K, mm.a1, st));
+        PN_TRY(wgrad_general(xop, xop, B, N, K, K, mm.gram, false, prec, true));   // Gram matrix and a1 = column sums together
         const pn_operand gop = plain(mm.gram, K);
         PN_TRY(conv_fwd(&gop, Wk, 0, 1, K, K, C, nullptr, mm.GW, nullptr, PN_PREC_BF16X3, st));
         return maxbwd_dw(&xop, mm.arg, mm.hs, B, N, K, C, mm.a1, mm.f, mm.e, mm.GW, dw, st);

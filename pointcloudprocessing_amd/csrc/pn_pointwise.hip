@@ -337,11 +337,19 @@ __global__ __launch_bounds__(256) void max_finalize_kernel(const float* __restri
   if (c >= C) return;
   float best = -INFINITY;
   int bi = 0x7fffffff;
-  for (int t = 0; t < tiles_per_cloud; ++t) {
-    const long long o = ((long long)b * tiles_per_cloud + t) * C + c;
-    const float v = pmax[o];
-    const int i = pidx[o];
-    if (v > best || (v == best && i < bi)) { best = v; bi = i; }
+  for (int t0 = 0; t0 < tiles_per_cloud; t0 += 16) {      // 16 tiles per pass: all 32 loads in flight before the compare chain
+    float v[16];
+    int ix[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int t = min(t0 + q, tiles_per_cloud - 1);
+      const long long o = ((long long)b * tiles_per_cloud + t) * C + c;
+      v[q] = pmax[o];
+      ix[q] = pidx[o];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q)
+      if (t0 + q < tiles_per_cloud && (v[q] > best || (v[q] == best && ix[q] < bi))) { best = v[q]; bi = ix[q]; }
   }
   const float zs = (sgn[c] < 0.f ? -1.f : 1.f) * best;   // sgn may be gamma itself
   const long long o = (long long)b * C + c;
