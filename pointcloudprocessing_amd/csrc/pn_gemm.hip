@@ -551,7 +551,9 @@ static int dispatch_rows(const GemmArgs& g, int prec, hipStream_t st) {
     if (prec == PN_PREC_BF16X3) return launch<128, 128, 3, MODE, A2, false, EPI>(g, grid, st);
     return launch<128, 128, 1, MODE, A2, false, EPI>(g, grid, st);
   }
-  if (wide) {
+  // a handful of row tiles (the Gram-sized products of the max-pool backward: 128 rows): 64-wide column tiles double the workgroups
+  const bool few = (long long)g.B * g.tiles_per_cloud * (g.C / 128) < 64;
+  if (wide && !few) {
     dim3 grid(g.B * g.tiles_per_cloud, g.C / 128);
     if (prec == PN_PREC_BF16X3) return launch<128, 128, 3, MODE, A2, false, EPI, ADD, MASK>(g, grid, st);
     return launch<128, 128, 1, MODE, A2, false, EPI, ADD, MASK>(g, grid, st);

@@ -760,9 +760,9 @@ struct Run {
     }
     if (!d.vanilla) {
       // ---- feature transform: X_64 = A_12 . R_64 ----
-      PN_TRY(zero_fill(w.fT.dR, (long long)B * 4096, st));
       const pn_operand a12 = lazy(w.m12);
       const bool have_dx = has_seg || has_cls;
+      if (!have_dx) PN_TRY(zero_fill(w.fT.dR, (long long)B * 4096, st));     // otherwise the slab reduction below is its first writer
       if (have_dx) {
         const pn_operand dx = plain(w.dX64, 64);
         PN_TRY(wgrad_to(a12, dx, 64, 64, w.fT.dR, true));
@@ -787,7 +787,6 @@ struct Run {
       return PN_OK;
     }
     PN_TRY(slab_reduce(cur_slabs(), T, tpc, 3 * 64, w.dWeff1, st));
-    PN_TRY(zero_fill(w.iT.dR, (long long)B * 9, st));
     PN_TRY(fold3_bwd(w.dWeff1, w.iT.R, p(L.m11.kernel), B, 64, w.iT.dR, tr(BLK_M11) ? gr(L.m11.kernel) : nullptr, st));
     // ---- input transform ----
     if (d_R) PN_TRY(axpy(d_R, 1.f, w.iT.dR, (long long)B * 9, st));

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(64) void fold3_bwd_r_kernel(const float* __restrict
   float s = 0.f;
   for (int c = threadIdx.x; c < C; c += 64) s = fmaf(dWeff[((long long)b * 3 + i) * C + c], W[k * C + c], s);
   s = wave_sum(s);
-  if (threadIdx.x == 0) dR[(long long)b * 9 + ik] += s;
+  if (threadIdx.x == 0) dR[(long long)b * 9 + ik] = s;      // first writer of dR: later terms (d_R, MSE, regulariser) add to it
 }
 // dW[k][c] = sum_b sum_i R[b][i][k] dWeff[b][i][c]
 __global__ __launch_bounds__(256) void fold3_bwd_w_kernel(const float* __restrict__ dWeff, const float* __restrict__ R, int B, int C,
