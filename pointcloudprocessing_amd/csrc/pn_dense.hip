@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256) void dense_bwd_pre_kernel(const float* __restr
 // dw[k][j] = sum_r x[r][k] * dz[r][j]     thread <-> column j, block <-> 16 consecutive k; rows in chunks of 32 whose
 // dz values are loaded up front (unconditional, clamped) so they are all in flight together
 __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ dz, int R,
-                                                          int K, int C, float* __restrict__ dw) {
+                                                          int K, int C, float* __restrict__ dw, float* __restrict__ db) {
   constexpr int KT = 16;
   constexpr int WRC = 32;
   __shared__ float xs[KT][WRC];
@@ -494,6 +494,7 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* __restric
   const int jc = j < C ? j : C - 1;
   const int k0 = blockIdx.y * KT;
   float acc[KT];
+  float colsum = 0.f;                      // db[j] = sum_r dz[r][j] (optional, written by the first k tile's blocks)
 #pragma unroll
   for (int k = 0; k < KT; ++k) acc[k] = 0.f;
   for (int rc = 0; rc < R; rc += WRC) {
@@ -501,6 +502,8 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* __restric
     float d[WRC];
 #pragma unroll
     for (int r = 0; r < WRC; ++r) d[r] = dz[(long long)(rc + min(r, nr - 1)) * C + jc];
+#pragma unroll
+    for (int r = 0; r < WRC; ++r) colsum += (r < nr) ? d[r] : 0.f;
     __syncthreads();
     for (int t = threadIdx.x; t < KT * WRC; t += 256) {
       const int k = t / WRC, r = t % WRC;
@@ -518,6 +521,7 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(const float* __restric
 #pragma unroll
     for (int k = 0; k < KT; ++k)
       if (k0 + k < K) dw[(long long)(k0 + k) * C + j] = acc[k];
+    if (db && blockIdx.y == 0) db[j] = colsum;
   }
 }
 
@@ -551,7 +555,7 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const float* __restrict
 }
 
 // Row softmax + keras SparseCategoricalCrossentropy (clip 1e-7, log, sparse_softmax_xent) + its gradient
-// w.r.t. the logits.  Used for the classification head (rows = B).  32 lanes per row (8 rows per pass of the single block);
+// w.r.t. the logits.  Used for the classification head (rows = B).  32 lanes per row (32 rows per pass of the single 1024-thread block);
 // every reduction is a fixed xor-shuffle tree, so the result does not depend on anything but the inputs.
 //   loss_sum[0] = sum_r nll_r ; correct[0] = #(argmax == label)
 __device__ __forceinline__ float grp_sum(float v) {
@@ -559,14 +563,14 @@ __device__ __forceinline__ float grp_sum(float v) {
   for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
   return v;
 }
-__global__ __launch_bounds__(256) void softmax_xent_rows_kernel(const float* __restrict__ logits, int R, int C,
+__global__ __launch_bounds__(1024) void softmax_xent_rows_kernel(const float* __restrict__ logits, int R, int C,
                                                                 const int* __restrict__ labels, float grad_scale,
                                                                 float* __restrict__ probs, float* __restrict__ dlogits,
                                                                 float* __restrict__ loss_sum, float* __restrict__ correct) {
-  __shared__ float rl[8], rc[8];
-  const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  __shared__ float rl[32], rc[32];
+  const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;      // 32 groups of 32 lanes: 32 rows per pass
   float myloss = 0.f, mycorr = 0.f;       // lane 0 of each group accumulates its rows in row order
-  for (int r0 = 0; r0 < R; r0 += 8) {
+  for (int r0 = 0; r0 < R; r0 += 32) {
     const int r = r0 + grp;
     if (r >= R) continue;                 // group-uniform (a group is half a wave; shuffles below use width 32)
     const float* l = logits + (long long)r * C;
@@ -624,7 +628,7 @@ __global__ __launch_bounds__(256) void softmax_xent_rows_kernel(const float* __r
   __syncthreads();
   if (threadIdx.x == 0 && labels) {
     float x = 0.f, y = 0.f;
-    for (int i = 0; i < 8; ++i) { x += rl[i]; y += rc[i]; }
+    for (int i = 0; i < 32; ++i) { x += rl[i]; y += rc[i]; }
     if (loss_sum) loss_sum[0] = x;
     if (correct) correct[0] = y;
   }
@@ -689,9 +693,9 @@ int dense_bwd_pre(const float* da, const float* z, int R, int C, const float* ga
   return PN_OK;
 }
 
-int dense_wgrad(const float* x, int ldx, const float* dz, int R, int K, int C, float* dw, hipStream_t st) {
+int dense_wgrad(const float* x, int ldx, const float* dz, int R, int K, int C, float* dw, hipStream_t st, float* db) {
   PN_CHECK_ARG(x && dz && dw, "dense_wgrad: null pointer");
-  hipLaunchKernelGGL(dense_wgrad_kernel, dim3(cdiv(C, 256), cdiv(K, 16)), dim3(256), 0, st, x, ldx, dz, R, K, C, dw);
+  hipLaunchKernelGGL(dense_wgrad_kernel, dim3(cdiv(C, 256), cdiv(K, 16)), dim3(256), 0, st, x, ldx, dz, R, K, C, dw, db);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -713,7 +717,7 @@ int transpose2(const float* in, int R, int C, const float* rowscale, float* out,
 int softmax_xent_rows(const float* logits, int R, int C, const int* labels, float grad_scale, float* probs, float* dlogits,
                       float* loss_sum, float* correct, hipStream_t st) {
   PN_CHECK_ARG(logits && probs && R > 0 && C > 0, "softmax_xent_rows: bad arguments");
-  hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3(1), dim3(256), 0, st, logits, R, C, labels, grad_scale, probs, dlogits,
+  hipLaunchKernelGGL(softmax_xent_rows_kernel, dim3(1), dim3(1024), 0, st, logits, R, C, labels, grad_scale, probs, dlogits,
                      loss_sum, correct);
   PN_CHECK_LAUNCH();
   return PN_OK;

@@ -48,7 +48,7 @@ int dense_bwd_fused(const float* da, const float* z, const float* x, int ldx, in
 int dense_bwd_pre(const float* da, const float* z, int R, int C, const float* gamma, const float* beta, const float* mean,
                   const float* invstd, int bn_mode, int act, const unsigned char* keep, float keep_scale, float* dz, float* dgamma,
                   float* dbeta, float* dbias, hipStream_t st);
-int dense_wgrad(const float* x, int ldx, const float* dz, int R, int K, int C, float* dw, hipStream_t st);
+int dense_wgrad(const float* x, int ldx, const float* dz, int R, int K, int C, float* dw, hipStream_t st, float* db = nullptr);   // db: column sums of dz
 int transpose(const float* in, int R, int C, float* out, hipStream_t st);
 int weights_prep3(const float* const* w, const float* const* sgn, const int* K, const int* C, void* const* hi, void* const* lo,
                   unsigned* zero_p, int zero_n, hipStream_t st);
@@ -69,7 +69,7 @@ int seg_out_bwd(const pn_operand* x, const float* w, const float* dlogits, int B
 int sum_partials(const float* part, int n, int stride, int elems, float* out, hipStream_t st);
 
 // pn_maxbwd.hip
-int maxbwd_prep(const float* dg, const float* g, const float* zstar, int B, int C, const float* mean, const float* invstd,
+int maxbwd_prep(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean, const float* invstd,
                 const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege, float* f, float* dgamma,
                 float* dbeta, const float* W, int K, float* Wt, float* We, hipStream_t st);
 int colsum_lazy(const pn_operand* x, int B, int N, int C, float* part, hipStream_t st);
@@ -94,7 +94,7 @@ int adam(float* p, const float* g, float* m, float* v, long long n, const float*
          float grad_scale, hipStream_t st);
 int mse(const float* R, const float* T, int n, float gscale, float* dR, float* loss_sum, hipStream_t st);
 int orth_reg(const float* R, int B, int K, float c, float* dR, float* loss_part, hipStream_t st);
-int fold3_fwd(const float* R, const float* W, int B, int C, float* Weff, hipStream_t st);
+int fold3_fwd(const float* R, const float* W, int B, int C, float* Weff, hipStream_t st, float* R_copy = nullptr);
 int fold3_bwd(const float* dWeff, const float* R, const float* W, int B, int C, float* dR, float* dW, hipStream_t st);
 int fill_eye3(float* out, int B, hipStream_t st);
 int axpy(const float* x, float a, float* y, long long n, hipStream_t st);

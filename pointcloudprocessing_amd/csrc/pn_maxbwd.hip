@@ -17,7 +17,7 @@
 namespace pn {
 
 // block = 32 channels x 8 partitions of the clouds: h, S1, S2 -> hs (B,C), e, f, dgamma, dbeta
-__global__ __launch_bounds__(256) void maxbwd_prep_kernel(const float* __restrict__ dg, const float* __restrict__ g,
+__global__ __launch_bounds__(256) void maxbwd_prep_kernel(const float* __restrict__ dg, const float* __restrict__ dg2, const float* __restrict__ g,
                                                           const float* __restrict__ zstar, int B, int C,
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ scale, int batch_stats, double inv_count,
@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void maxbwd_prep_kernel(const float* __restric
     sc = scale[c]; mu = mean[c]; is = invstd[c];
     for (int b = ty; b < B; b += 8) {
       const long long o = (long long)b * C + c;
-      const float h = g[o] > 0.f ? dg[o] : 0.f;
+      const float up = (dg ? dg[o] : 0.f) + (dg2 ? dg2[o] : 0.f);   // the heads' gradients meet here (no separate add)
+      const float h = g[o] > 0.f ? up : 0.f;
       hs[o] = sc * h;
       S1 += (double)h;
       S2 += (double)h * (double)((zstar[o] - mu) * is);
@@ -241,12 +242,12 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restri
   }
 }
 
-int maxbwd_prep(const float* dg, const float* g, const float* zstar, int B, int C, const float* mean, const float* invstd,
+int maxbwd_prep(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean, const float* invstd,
                 const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege, float* f, float* dgamma,
                 float* dbeta, const float* W, int K, float* Wt, float* We, hipStream_t st) {
-  PN_CHECK_ARG(dg && g && zstar && mean && invstd && scale && hs && e && nege && f, "maxbwd_prep: null pointer");
+  PN_CHECK_ARG((dg || dg2) && g && zstar && mean && invstd && scale && hs && e && nege && f, "maxbwd_prep: null pointer");
   PN_CHECK_ARG(!W || (Wt && We && K > 0), "maxbwd_prep: the transposed copies need Wt and We");
-  hipLaunchKernelGGL(maxbwd_prep_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, dg, g, zstar, B, C, mean, invstd, scale, batch_stats,
+  hipLaunchKernelGGL(maxbwd_prep_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, dg, dg2, g, zstar, B, C, mean, invstd, scale, batch_stats,
                      1.0 / (double)count, hs, e, nege, f, dgamma, dbeta, W, K, Wt, We);
   PN_CHECK_LAUNCH();
   return PN_OK;

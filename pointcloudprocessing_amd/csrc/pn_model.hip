@@ -477,7 +477,7 @@ struct Run {
     PN_TRY(normalize(io.pc, B, N, w.pcn, w.cent, w.scl, st));
     if (!d.vanilla) {
       PN_TRY(fwd_tnet(w.iT, L.iT, nullptr));
-      PN_TRY(fold3_fwd(w.iT.R, p(L.m11.kernel), B, 64, w.Weff1, st));
+      PN_TRY(fold3_fwd(w.iT.R, p(L.m11.kernel), B, 64, w.Weff1, st, io.out_R));   // also copies R to the third output
       PN_TRY(conv3_fwd(w.pcn, w.Weff1, 192, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st));
     } else {
       PN_TRY(conv3_fwd(w.pcn, p(L.m11.kernel), 0, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st));
@@ -522,12 +522,7 @@ struct Run {
 
     // third output: the input transform (PointNet.py:292); identity for vanilla (:211)
     if (io.out_R) {
-      if (!d.vanilla) {
-        if (hipMemcpyAsync(io.out_R, w.iT.R, (size_t)B * 9 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess) {
-          set_error("pn_model_forward: copy of R failed");
-          return PN_ERR_LAUNCH;
-        }
-      } else {
+      if (d.vanilla) {
         PN_TRY(fill_eye3(io.out_R, B, st));
       }
     }
@@ -584,12 +579,12 @@ struct Run {
     return conv_bwd_data(&dz, p(rc.kernel), 0, B, N, rc.cout, rc.cin, nullptr, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st);
   }
   // backward of a max-pooled layer: dG (B,C) -> prev.dy (+stats in w.bpart), this layer's parameter gradients
-  int bwd_max(CL& l, ML& m, const LRef& r, const pn_operand& xop, CL& prev, const float* dG) {
+  int bwd_max(CL& l, ML& m, const LRef& r, const pn_operand& xop, CL& prev, const float* dG, const float* dG2 = nullptr) {
     const int K = r.cin, C = r.cout;
     const int bs = bn_batch(r.block) ? 1 : 0;
     const bool wg = tr(r.block) && G;
     // + the channel-major copies Wt, We = -e (.) Wt used below, written by the same launch
-    PN_TRY(maxbwd_prep(dG, m.g, m.zstar, B, C, l.mean, l.invstd, l.scale, bs, M, m.hs, m.e, m.nege, m.f, wg ? gr(r.gamma) : nullptr,
+    PN_TRY(maxbwd_prep(dG, dG2, m.g, m.zstar, B, C, l.mean, l.invstd, l.scale, bs, M, m.hs, m.e, m.nege, m.f, wg ? gr(r.gamma) : nullptr,
                        wg ? gr(r.beta) : nullptr, p(r.kernel), K, m.Wt, m.We, st));
     if (wg) {
       const ML mm = m;
@@ -644,8 +639,7 @@ struct Run {
       const float *dR = t.dR, *a2 = t.d2.a;
       float *gb = gr(r.b), *gw = gr(r.w);
       PN_TRY(side([=] {
-        PN_TRY(sum_partials(dR, B, KK, KK, gb, st));                      // db = sum_b dR
-        return dense_wgrad(a2, 256, dR, B, 256, KK, gw, st);               // dw = a2^T dR
+        return dense_wgrad(a2, 256, dR, B, 256, KK, gw, st, gb);           // dw = a2^T dR and db = sum_b dR in one launch
       }));
       PN_TRY(flush());
     }
@@ -735,14 +729,15 @@ struct Run {
       PN_TRY(bwd_dense(w.c1, L.c1, w.mm23.g, w.c2.din, 1, io.keep1, w.dGcls));
       have_dGcls = true;
     }
-    float* dG = w.mm23.dG;
-    PN_TRY(add2(have_dGcls ? w.dGcls : nullptr, have_dGseg ? w.dGseg : nullptr, dG, (long long)B * 1024, st));
+    // d(global feature) = classification-head part + segmentation-head part: summed inside maxbwd_prep
+    const float* dGa = have_dGcls ? w.dGcls : nullptr;
+    const float* dGb = have_dGseg ? w.dGseg : nullptr;
 
     if (!trunk && !have_R_grad) return PN_OK;
 
     // ---- mlp_2 ----
     if (has_seg || has_cls) {
-      PN_TRY(bwd_max(w.m23, w.mm23, L.m23, lazy(w.m22), w.m22, dG));
+      PN_TRY(bwd_max(w.m23, w.mm23, L.m23, lazy(w.m22), w.m22, dGa, dGb));
       PN_TRY(bwd_step(w.m22, L.m22, w.m21, lazy(w.m21)));
       PN_TRY(bn_bwd_fin(w.m21, L.m21, w.bpart));
       const pn_operand dz21 = dzop(w.m21);

@@ -134,27 +134,34 @@ __global__ __launch_bounds__(256) void orth_reg_kernel(const float* __restrict__
 
 // Weff[b] (3,C) = R[b] (3,3) @ W (3,C)           -- tf.matmul(pc, R) folded into the first kernel
 __global__ __launch_bounds__(256) void fold3_fwd_kernel(const float* __restrict__ R, const float* __restrict__ W, int C,
-                                                        float* __restrict__ Weff) {
+                                                        float* __restrict__ Weff, float* __restrict__ R_copy) {
   const int b = blockIdx.x;
+  if (R_copy && threadIdx.x < 9) R_copy[(long long)b * 9 + threadIdx.x] = R[(long long)b * 9 + threadIdx.x];   // the model's third output
   for (int t = threadIdx.x; t < 3 * C; t += 256) {
     const int i = t / C, c = t % C;
     const float* r = R + (long long)b * 9 + i * 3;
     Weff[(long long)b * 3 * C + t] = fmaf(r[2], W[2 * C + c], fmaf(r[1], W[C + c], r[0] * W[c]));
   }
 }
-// dR[b][i][k] += sum_c dWeff[b][i][c] W[k][c]
-__global__ __launch_bounds__(64) void fold3_bwd_r_kernel(const float* __restrict__ dWeff, const float* __restrict__ W, int C,
-                                                         float* __restrict__ dR) {
-  const int b = blockIdx.x, ik = blockIdx.y, i = ik / 3, k = ik % 3;
-  float s = 0.f;
-  for (int c = threadIdx.x; c < C; c += 64) s = fmaf(dWeff[((long long)b * 3 + i) * C + c], W[k * C + c], s);
-  s = wave_sum(s);
-  if (threadIdx.x == 0) dR[(long long)b * 9 + ik] = s;      // first writer of dR: later terms (d_R, MSE, regulariser) add to it
-}
-// dW[k][c] = sum_b sum_i R[b][i][k] dWeff[b][i][c]
-__global__ __launch_bounds__(256) void fold3_bwd_w_kernel(const float* __restrict__ dWeff, const float* __restrict__ R, int B, int C,
-                                                          float* __restrict__ dW) {
-  const int t = blockIdx.x * 256 + threadIdx.x;
+// One launch for both gradients of Weff[b] = R[b] W:   blocks [0, B): dR[b][i][k] = sum_c dWeff[b][i][c] W[k][c]  (first writer of
+// dR: later terms add to it);   blocks [B, ...): dW[k][c] = sum_b sum_i R[b][i][k] dWeff[b][i][c]
+__global__ __launch_bounds__(256) void fold3_bwd_kernel(const float* __restrict__ dWeff, const float* __restrict__ R,
+                                                        const float* __restrict__ W, int B, int C, float* __restrict__ dR,
+                                                        float* __restrict__ dW) {
+  if ((int)blockIdx.x < B) {
+    if (!dR) return;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int ik = wave; ik < 9; ik += 4) {
+      const int i = ik / 3, k = ik % 3;
+      float s = 0.f;
+      for (int c = lane; c < C; c += 64) s = fmaf(dWeff[((long long)b * 3 + i) * C + c], W[k * C + c], s);
+      s = wave_sum(s);
+      if (lane == 0) dR[(long long)b * 9 + ik] = s;
+    }
+    return;
+  }
+  if (!dW) return;
+  const int t = ((int)blockIdx.x - B) * 256 + threadIdx.x;
   if (t >= 3 * C) return;
   const int k = t / C, c = t % C;
   float s = 0.f;
@@ -282,20 +289,15 @@ int orth_reg(const float* R, int B, int K, float c, float* dR, float* loss_part,
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
-int fold3_fwd(const float* R, const float* W, int B, int C, float* Weff, hipStream_t st) {
-  hipLaunchKernelGGL(fold3_fwd_kernel, dim3(B), dim3(256), 0, st, R, W, C, Weff);
+int fold3_fwd(const float* R, const float* W, int B, int C, float* Weff, hipStream_t st, float* R_copy) {
+  hipLaunchKernelGGL(fold3_fwd_kernel, dim3(B), dim3(256), 0, st, R, W, C, Weff, R_copy);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
 int fold3_bwd(const float* dWeff, const float* R, const float* W, int B, int C, float* dR, float* dW, hipStream_t st) {
-  if (dR) {
-    hipLaunchKernelGGL(fold3_bwd_r_kernel, dim3(B, 9), dim3(64), 0, st, dWeff, W, C, dR);
-    PN_CHECK_LAUNCH();
-  }
-  if (dW) {
-    hipLaunchKernelGGL(fold3_bwd_w_kernel, dim3(cdiv(3 * C, 256)), dim3(256), 0, st, dWeff, R, B, C, dW);
-    PN_CHECK_LAUNCH();
-  }
+  if (!dR && !dW) return PN_OK;
+  hipLaunchKernelGGL(fold3_bwd_kernel, dim3(B + cdiv(3 * C, 256)), dim3(256), 0, st, dWeff, R, W, B, C, dR, dW);
+  PN_CHECK_LAUNCH();
   return PN_OK;
 }
 // Zero fill as an ordinary kernel.  hipMemsetAsync is avoided on purpose: captured into a hipGraph (ROCm 7.2) the
