@@ -9,54 +9,105 @@ constexpr int SEG_CM = 16;   // class slots held in registers; Cseg <= 16
 constexpr int SEG_RPB = 128; // rows (threads) per block of the forward kernel: 256 blocks at 32,768 points, one per CU
 
 // one thread per point: logits -> softmax -> (loss, accuracy, dlogits).
-// CT > 0: the segmentation width is a compile-time constant, so the (wave-uniform) weights and BN coefficients come through scalar
-// loads as SGPR operands of the FMAs; the LDS copy (one ds_read per FMA) made the generic form LDS-bound.
-template <int CT>
+// MF = 1 (K = 128): the logits of a wave's 64 points come from the matrix cores -- two 32-row tiles, 8 k-steps, operands split
+// into bf16 hi + lo (3 products, fp32-grade), weights staged once per block as a bf16 channel-major LDS image, the BN + ReLU of
+// the input applied on load -- and are handed to their points through an LDS tile.  MF = 0: the vector-ALU form (any K % 4 == 0),
+// which reads one weight from LDS per FMA and is LDS-bound (30 us vs the MFMA form's time at M = 32,768).
+typedef __attribute__((ext_vector_type(8))) __bf16 seg_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float seg_f32x16;
+constexpr int SEG_WP = 128 + 8;   // LDS pitch (bf16) of the weight image: conflict-free 16-byte rows
+
+template <int MF>
 __global__ __launch_bounds__(SEG_RPB) void seg_out_fwd_kernel(const pn_operand x, const float* __restrict__ w, const float* __restrict__ bias,
                                                           long long M, int K, int C, const int* __restrict__ labels, float grad_scale,
                                                           float* __restrict__ probs, float* __restrict__ dlogits,
                                                           float* __restrict__ part /* [blocks][2 + SEG_CM] */) {
   extern __shared__ float sm[];
-  float* ws = sm;                 // [K][SEG_CM]
-  float* ca = ws + K * SEG_CM;    // [K]
+  float* ws = sm;                 // MF 0: [K][SEG_CM] fp32 weights.  MF 1: bf16 image [hi|lo][32][SEG_WP] + logit tiles (see below)
+  // MF 1 layout: [hi image 32 x SEG_WP bf16][lo image][logit tile SEG_RPB x (SEG_CM+1) fp32][ca K][cc K]
+  float* ca = MF == 1 ? reinterpret_cast<float*>(reinterpret_cast<char*>(sm) + 2 * 32 * SEG_WP * sizeof(__bf16)) + SEG_RPB * (SEG_CM + 1)
+                      : ws + K * SEG_CM;    // [K]
   float* cc = ca + K;             // [K]
-  if (CT == 0) {
+  if (MF == 0) {
     for (int t = threadIdx.x; t < K * SEG_CM; t += SEG_RPB) {
       const int k = t / SEG_CM, c = t % SEG_CM;
       ws[t] = c < C ? w[(long long)k * C + c] : 0.f;
     }
-    for (int t = threadIdx.x; t < K; t += SEG_RPB) {
-      ca[t] = x.ca ? x.ca[t] : 1.f;
-      cc[t] = x.cc ? x.cc[t] : 0.f;
+  } else {
+    __bf16* whi = reinterpret_cast<__bf16*>(ws);
+    __bf16* wlo = whi + 32 * SEG_WP;
+    for (int t = threadIdx.x; t < 32 * 128; t += SEG_RPB) {
+      const int c = t >> 7, k = t & 127;            // channel-major image W^T[c][k], channels >= C are zero
+      const float v = c < C ? w[(long long)k * C + c] : 0.f;
+      const __bf16 h = (__bf16)v;
+      whi[c * SEG_WP + k] = h;
+      wlo[c * SEG_WP + k] = (__bf16)(v - (float)h);
     }
-    __syncthreads();
   }
+  for (int t = threadIdx.x; t < K; t += SEG_RPB) {
+    ca[t] = x.ca ? x.ca[t] : 1.f;
+    cc[t] = x.cc ? x.cc[t] : 0.f;
+  }
+  __syncthreads();
   const long long row = (long long)blockIdx.x * SEG_RPB + threadIdx.x;
   float loss = 0.f, corr = 0.f;
   float dl[SEG_CM];
 #pragma unroll
   for (int c = 0; c < SEG_CM; ++c) dl[c] = 0.f;
+  float* lgt = nullptr;           // MF 1: this block's logit tile [SEG_RPB rows][SEG_CM + 1]
+  if (MF == 1) {
+    const __bf16* whi = reinterpret_cast<const __bf16*>(ws);
+    const __bf16* wlo = whi + 32 * SEG_WP;
+    lgt = reinterpret_cast<float*>(const_cast<__bf16*>(wlo + 32 * SEG_WP));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lg = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const long long r0 = (long long)blockIdx.x * SEG_RPB + wave * 64 + 32 * t;
+      const long long rr = r0 + lr < M ? r0 + lr : M - 1;          // clamped: loads are unconditional
+      const float* src = x.s1 + rr * x.ld + 8 * lg;
+      seg_f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+      float4 xv[8][2];
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        xv[ks][0] = *reinterpret_cast<const float4*>(src + ks * 16);
+        xv[ks][1] = *reinterpret_cast<const float4*>(src + ks * 16 + 4);
+      }
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const int k0 = ks * 16 + 8 * lg;
+        const float v[8] = {xv[ks][0].x, xv[ks][0].y, xv[ks][0].z, xv[ks][0].w, xv[ks][1].x, xv[ks][1].y, xv[ks][1].z, xv[ks][1].w};
+        seg_bf16x8 ah, al;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = fmaxf(fmaf(ca[k0 + e], v[e], cc[k0 + e]), x.lo);
+          ah[e] = (__bf16)a;
+          al[e] = (__bf16)(a - (float)ah[e]);
+        }
+        const seg_bf16x8 bh = *reinterpret_cast<const seg_bf16x8*>(whi + lr * SEG_WP + k0);
+        const seg_bf16x8 bl = *reinterpret_cast<const seg_bf16x8*>(wlo + lr * SEG_WP + k0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+      }
+      if (lr < SEG_CM) {          // acc[e]: row (e & 3) + 8 (e >> 2) + 4 g of the tile, class lr
+#pragma unroll
+        for (int e = 0; e < 16; ++e) lgt[(wave * 64 + 32 * t + (e & 3) + 8 * (e >> 2) + 4 * lg) * (SEG_CM + 1) + lr] = acc[e];
+      }
+    }
+    __syncthreads();
+  }
   if (row < M) {
     float acc[SEG_CM];
 #pragma unroll
     for (int c = 0; c < SEG_CM; ++c) acc[c] = (c < C && bias) ? bias[c] : 0.f;
-    const float* src = x.s1 + row * x.ld;
-    if (CT > 0) {
-      const float* __restrict__ gca = x.ca;
-      const float* __restrict__ gcc = x.cc;
-#pragma unroll 2
-      for (int k = 0; k < K; k += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(src + k);
-        const float vv[4] = {v.x, v.y, v.z, v.w};
+    if (MF == 1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float a = fmaxf(fmaf(gca ? gca[k + q] : 1.f, vv[q], gcc ? gcc[k + q] : 0.f), x.lo);
-          const float* __restrict__ wk = w + (long long)(k + q) * CT;      // wave-uniform address: scalar loads
-#pragma unroll
-          for (int c = 0; c < CT; ++c) acc[c] = fmaf(a, wk[c], acc[c]);
-        }
-      }
+      for (int c = 0; c < SEG_CM; ++c) acc[c] += lgt[threadIdx.x * (SEG_CM + 1) + c];
     } else {
+      const float* src = x.s1 + row * x.ld;
 #pragma unroll 4
       for (int k = 0; k < K; k += 4) {
         const float4 v = *reinterpret_cast<const float4*>(src + k);
@@ -221,10 +272,16 @@ int seg_out_fwd(const pn_operand* x, const float* w, const float* bias, long lon
   PN_CHECK_ARG(C >= 1 && C <= SEG_CM, "seg_out_fwd: segmentation width %d not in [1,%d]", C, SEG_CM);
   PN_CHECK_ARG(K % 4 == 0 && K <= 1024 && x->ld % 4 == 0, "seg_out_fwd: bad K/ld");
   const size_t shm = (size_t)(K * SEG_CM + 2 * K) * sizeof(float);
-  // seg_out_fwd_kernel<12> (weights through scalar loads) measured 39.7 us against 30.6 us for the LDS form at M = 32,768: kept
-  // only as the template's second instantiation for experiments
-  hipLaunchKernelGGL(seg_out_fwd_kernel<0>, dim3((unsigned)cdivll(M, SEG_RPB)), dim3(SEG_RPB), shm, st, *x, w, bias, M, K, C, labels,
-                     grad_scale, probs, dlogits, part);
+  if (K == 128) {
+    const size_t img = (size_t)2 * 32 * SEG_WP * sizeof(__bf16);
+    const size_t tile = (size_t)SEG_RPB * (SEG_CM + 1) * sizeof(float);
+    const size_t shm_mf = img + tile + (size_t)2 * K * sizeof(float);
+    hipLaunchKernelGGL(seg_out_fwd_kernel<1>, dim3((unsigned)cdivll(M, SEG_RPB)), dim3(SEG_RPB), shm_mf, st, *x, w, bias, M, K, C, labels,
+                       grad_scale, probs, dlogits, part);
+  } else {
+    hipLaunchKernelGGL(seg_out_fwd_kernel<0>, dim3((unsigned)cdivll(M, SEG_RPB)), dim3(SEG_RPB), shm, st, *x, w, bias, M, K, C, labels,
+                       grad_scale, probs, dlogits, part);
+  }
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
