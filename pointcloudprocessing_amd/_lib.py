@@ -15,6 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 PN_PREC_BF16 = 1
 PN_PREC_BF16X3 = 3
+ABI_VERSION = 2            # PN_ABI_VERSION of include/pointnet_hip.h this binding was written against
 PN_NUM_BLOCKS = 15
 PREC = {"bf16": PN_PREC_BF16, "bf16x3": PN_PREC_BF16X3}
 
@@ -135,7 +136,7 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.pn_abi_version() != 2:
+        if l.pn_abi_version() != ABI_VERSION:
             raise PointNetHipError("libpointnet_hip.so ABI version mismatch")
         _lib = l
     return _lib
