@@ -95,8 +95,21 @@ class _LayerBase:
 
     def _w(self, suffix):
         if self._owner is None:
-            raise PointNetHipError(f"layer {self.name} is not built")
+            own = getattr(self, "_own", None)
+            if own is None or suffix not in own:
+                raise PointNetHipError(f"layer {self.name} is not built")
+            return own[suffix]
         return self._owner._weights.view(f"{self._prefix}.{suffix}")
+
+    # ---- free-standing use (a layer that is not part of a PointNet owns its tensors) ----
+    def _own_bn(self, width, device):
+        self._own.update({"bn.gamma": torch.ones(width, device=device), "bn.beta": torch.zeros(width, device=device),
+                          "bn.moving_mean": torch.zeros(width, device=device), "bn.moving_var": torch.ones(width, device=device)})
+
+    @staticmethod
+    def _device_of(x):
+        _lib.require_gpu_tensor(x, "input", torch.float32)
+        return x.device
 
 
 class _BN:
@@ -144,6 +157,50 @@ class ConvLayer(_LayerBase):
         if self.apply_bn:
             self.bn.trainable = True
 
+    def build(self, input_shape, device="cuda"):
+        """free-standing layer: Keras-style lazy weights (GlorotUniform kernel; BN gamma 1, beta 0, moving 0 / 1) -- PointNet.py:526-542"""
+        cin = int(input_shape[-1])
+        self._own = {"kernel": _glorot_uniform((cin, self.filters), self.seed).to(device)}
+        if self.apply_bn:
+            self._own_bn(self.filters, device)
+        else:
+            self._own["bias"] = torch.zeros(self.filters, device=device)
+
+    def __call__(self, inputs, training: bool = False):
+        """(B, N, 1, Cin) or (B, N, Cin) -> same rank with ``filters`` channels: Conv2D 1x1 -> BatchNormalization -> activation
+        (PointNet.py:554-566), forward only, through the op-level C ABI (pn_conv_fwd / pn_conv3_fwd, pn_bn_finalize)."""
+        from .. import ops
+        if self._owner is not None:
+            raise PointNetHipError("a layer inside a PointNet is executed by the model's plan; call the model")
+        dev = self._device_of(inputs)
+        if getattr(self, "_own", None) is None:
+            self.build(inputs.shape, dev)
+        shape = inputs.shape
+        B, N, cin = shape[0], shape[1], shape[-1]
+        x = inputs.reshape(B * N, cin).contiguous()
+        w = self.kernel
+        if cin == 3:
+            z, part = ops.conv3_fwd(x, w, B, N)
+        elif cin % 64 == 0 and self.filters % 64 == 0:
+            z, part = ops.conv_fwd(_lib.operand(x, ld=cin), w, B, N, cin, self.filters, _lib.PN_PREC_BF16X3)
+        else:
+            raise PointNetHipError(f"ConvLayer: channel widths must be 3 or multiples of 64 (got {cin} -> {self.filters})")
+        if self.apply_bn:
+            batch = bool(training) and self.bn.trainable          # a frozen BN runs in inference mode (PointNet.py:585-591)
+            _, _, scale, shift = ops.bn_finalize(part if batch else None, B * N, self.bn.gamma, self.bn.beta, self.bn.moving_mean,
+                                                 self.bn.moving_variance, use_batch_stats=batch, update_moving=batch,
+                                                 momentum=self.bn_momentum, eps=self.bn.epsilon)
+            y = z * scale + shift
+        else:
+            y = z + self.bias
+        if self.activation in ("relu", torch.relu) or getattr(self.activation, "__name__", "") == "relu":
+            y = torch.relu(y)
+        elif self.activation is not None:
+            raise PointNetHipError(f"ConvLayer: activation {self.activation!r} is not implemented (the reference uses relu / None)")
+        return y.reshape(*shape[:-1], self.filters)
+
+    call = __call__
+
     def get_config(self):
         return {'filters': self.filters, 'name': self.name, 'kernel_size': self.kernel_size, 'strides': self.strides,
                 'padding': self.padding, 'activation': self.activation, 'apply_bn': self.apply_bn,
@@ -175,6 +232,37 @@ class DenseLayer(_LayerBase):
         self.trainable = True
         if self.apply_bn:
             self.bn.trainable = True
+
+    def build(self, input_shape, device="cuda"):
+        cin = int(input_shape[-1])
+        self._own = {"kernel": _glorot_uniform((cin, self.units), self.seed).to(device)}
+        if self.apply_bn:
+            self._own_bn(self.units, device)
+        else:
+            self._own["bias"] = torch.zeros(self.units, device=device)
+
+    def __call__(self, inputs, training: bool = False):
+        """(B, Cin) -> (B, units): Dense -> BatchNormalization -> activation (PointNet.py:642-654) in one native launch (pn_dense_layer)"""
+        from .. import ops
+        if self._owner is not None:
+            raise PointNetHipError("a layer inside a PointNet is executed by the model's plan; call the model")
+        dev = self._device_of(inputs)
+        if getattr(self, "_own", None) is None:
+            self.build(inputs.shape, dev)
+        relu = self.activation in ("relu", torch.relu) or getattr(self.activation, "__name__", "") == "relu"
+        if self.activation is not None and not relu:
+            raise PointNetHipError(f"DenseLayer: activation {self.activation!r} is not implemented (the reference uses relu / None)")
+        x = inputs.reshape(inputs.shape[0], -1).contiguous()
+        if self.apply_bn:
+            mode = 1 if (training and self.bn.trainable) else 2
+            _, a, _, _ = ops.dense_layer(x, self.kernel, gamma=self.bn.gamma, beta=self.bn.beta, moving_mean=self.bn.moving_mean,
+                                         moving_var=self.bn.moving_variance, bn_mode=mode, act=int(relu), momentum=self.bn_momentum,
+                                         eps=self.bn.epsilon)
+        else:
+            _, a, _, _ = ops.dense_layer(x, self.kernel, bias=self.bias, bn_mode=0, act=int(relu))
+        return a
+
+    call = __call__
 
     def get_config(self):
         return {'units': self.units, 'name': self.name, 'activation': self.activation, 'apply_bn': self.apply_bn,
@@ -228,6 +316,34 @@ class TNet(_LayerBase):
 
     def get_last_predicted_transformation(self):
         return self._last_predicted
+
+    def build(self, input_shape, device="cuda"):
+        """free-standing T-Net: w = zeros (256, K^2), b = identity (K, K) -- PointNet.py:412-416"""
+        K = int(input_shape[-1])
+        self._own = {"w": torch.zeros(256, K * K, device=device), "b": torch.eye(K, device=device)}
+
+    def __call__(self, inputs, training: bool = False):
+        """(B, N, K), K in {3, 64} -> (B, K, K): three ConvLayers, max over the points, two DenseLayers, ``@ w + b`` (PointNet.py:418-454).
+        Forward only, layer by layer through the op-level C ABI; inside a PointNet the fused plan runs instead."""
+        from .. import ops
+        if self._owner is not None:
+            raise PointNetHipError("a T-Net inside a PointNet is executed by the model's plan; call the model")
+        dev = self._device_of(inputs)
+        if getattr(self, "_own", None) is None:
+            self.build(inputs.shape, dev)
+        B, N, K = inputs.shape
+        x = self.conv_layer_1(inputs, training)
+        x = self.conv_layer_2(x, training)
+        x = self.conv_layer_3(x, training)
+        g = torch.amax(x, dim=1)                                   # tf.reduce_max(X, axis=1)
+        g = self.dense_layer_1(g, training)
+        g = self.dense_layer_2(g, training)
+        _, out, _, _ = ops.dense_layer(g, self.w, bias=self.b.reshape(-1).contiguous(), bn_mode=0, act=0)
+        R = out.reshape(B, K, K)
+        self._last_predicted = R
+        return R
+
+    call = __call__
 
     def get_config(self):
         return {'name': self.name, 'add_regularization': self.add_regularization, 'bn_momentum': self.bn_momentum,
