@@ -45,7 +45,7 @@ def synth_batch(B, N, seed, device):
     return [t.to(device) for t in (pc, y_cls, y_seg, se3)]
 
 
-def cpu_baseline(B, N, steps=3, warmup=1):
+def cpu_baseline(B, N, steps=6, warmup=1):
     from oracle import pointnet_oracle as O          # reported baseline only
     # the GPU box gives one GPU a 16-CPU share even though os.cpu_count() reports the whole host
     torch.set_num_threads(min(16, os.cpu_count() or 1))
