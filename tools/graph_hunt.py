@@ -1,4 +1,6 @@
-"""Find what makes the hipGraph arm produce garbage gradients when other (differently initialised) models run between replays.
+"""(Historical reproducer -- at commit c5040b3 the backward pass cleared the gradient buffer with hipMemsetAsync and modes eg / ege / gg
+failed within a few steps; the library has used a zero-fill kernel since, so every mode is clean now.  DESIGN.md section 8a.)
+Find what makes the hipGraph arm produce garbage gradients when other (differently initialised) models run between replays.
 usage: graph_hunt.py MODE ; detector = gradient slots of the moving statistics must stay exactly 0."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
