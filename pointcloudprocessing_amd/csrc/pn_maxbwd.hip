@@ -206,12 +206,14 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restri
     }
     __syncthreads();
     const int total = nhit;
-    // wave w takes hits w, w+4, ...; four of them (8 row loads per lane) are in flight at a time
-    for (int i0 = wave; i0 < total; i0 += 16) {
-      int pk[4];
-      float h[4], w0[4], w1[4];
+    // wave w takes hits w, w+4, ...; eight of them (16 row loads per lane) are in flight at a time: the arg-max rows of a cloud
+    // concentrate on a few points, so some tiles carry hundreds of hits and the launch lasts as long as its heaviest tile
+    constexpr int UF = 8;                      // 16 in flight measured no better
+    for (int i0 = wave; i0 < total; i0 += 4 * UF) {
+      int pk[UF];
+      float h[UF], w0[UF], w1[UF];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UF; ++u) {
         const int i = min(i0 + 4 * u, total - 1);
         pk[u] = hit_pk[i];
         const int c = c0 + (pk[u] & 0xffff);
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restri
         w1[u] = wt[(long long)c * K + min(lane + 64, K - 1)];
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < UF; ++u) {
         if (i0 + 4 * u < total) {              // wave-uniform
           const int m = pk[u] >> 16;
           if (lane < K) atomicAdd(&tile[m][lane], (unsigned long long)__double2ll_rn((double)(h[u] * w0[u]) * FX));
