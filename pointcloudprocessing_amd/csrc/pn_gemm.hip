@@ -341,18 +341,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
     float cs = 0.f;
     const int rbeg = tin * g.K;
     const int rend = min(g.N, rbeg + g.K);
-    for (int r0 = rbeg; r0 < rend; r0 += BK) {
-      const long long rowbase = (long long)cloud * g.N + r0;
-      const int nk = min(BK, rend - r0);
-      TrnStage<BM, BK, A2> sa;
-      TrnStage<BN, BK, B2> sb;
+    // the loads of chunk i+1 are issued before the MFMAs of chunk i and converted after them: one register set, global latency
+    // hidden behind the matrix cores
+    TrnStage<BM, BK, A2> sa;
+    TrnStage<BN, BK, B2> sb;
+    if (rbeg < rend) {
+      const long long rowbase = (long long)cloud * g.N + rbeg;
+      const int nk = min(BK, rend - rbeg);
       sa.issue(g.a, rowbase * g.a.ld + i0, nk, g.Ci - i0, tid);
       sb.issue(g.b, rowbase * g.b.ld + j0, nk, g.C - j0, tid);
+    }
+    for (int r0 = rbeg; r0 < rend; r0 += BK) {
+      const int nk = min(BK, rend - r0);
       sa.pin();
       cs += sa.template finish<NS>(Ahi, Alo, g.a, nk, g.Ci - i0, i0, tid, want_cs);
       sb.pin();
       sb.template finish<NS>(Bhi, Blo, g.b, nk, g.C - j0, j0, tid);
       __syncthreads();
+      if (r0 + BK < rend) {
+        const long long rowbase = (long long)cloud * g.N + r0 + BK;
+        const int nk2 = min(BK, rend - (r0 + BK));
+        sa.issue(g.a, rowbase * g.a.ld + i0, nk2, g.Ci - i0, tid);
+        sb.issue(g.b, rowbase * g.b.ld + j0, nk2, g.C - j0, tid);
+      }
       mma_chunk<MT, NT, BK, NS>(acc, Ahi, Alo, Bhi, Blo, wrow0, wcol0, lane);
       __syncthreads();
     }
@@ -398,25 +409,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   wop.lo = -INFINITY;
   wop.ld = (MODE == MODE_FWD) ? g.C : g.K;
 
-  for (int k0 = 0; k0 < g.K; k0 += BK) {
-    NatStage<BM, BK, A2> sa;
+  // same one-chunk-ahead pipeline as the weight-gradient loop: chunk k+1's loads fly under chunk k's MFMAs
+  NatStage<BM, BK, A2> sa;
+  TrnStage<BN, BK, false> sbT;      // FWD: weights W[k][j], k slow
+  NatStage<BN, BK, false> sbN;      // BWD: weights W[j][k], k fast
+  auto issue_chunk = [&](int k0) {
     if (!(g.dbg & 4)) sa.issue(g.a, row0 * g.a.ld, nrows, k0, tid);
     if (MODE == MODE_FWD) {
-      TrnStage<BN, BK, false> sb;
-      if (!(g.dbg & 8)) sb.issue(wop, wbase + (long long)k0 * g.C + col0, BK, g.C - col0, tid);
-      sa.pin();
-      sa.template finish<NS>(Ahi, Alo, g.a, nrows, k0, tid);
-      sb.pin();
-      sb.template finish<NS>(Bhi, Blo, wop, BK, g.C - col0, 0, tid);
+      if (!(g.dbg & 8)) sbT.issue(wop, wbase + (long long)k0 * g.C + col0, BK, g.C - col0, tid);
     } else {
-      NatStage<BN, BK, false> sb;
-      sb.issue(wop, wbase + (long long)col0 * g.K, g.C - col0, k0, tid);
-      sa.pin();
-      sa.template finish<NS>(Ahi, Alo, g.a, nrows, k0, tid);
-      sb.pin();
-      sb.template finish<NS>(Bhi, Blo, wop, g.C - col0, k0, tid);
+      sbN.issue(wop, wbase + (long long)col0 * g.K, g.C - col0, k0, tid);
+    }
+  };
+  if (g.K > 0) issue_chunk(0);
+  for (int k0 = 0; k0 < g.K; k0 += BK) {
+    sa.pin();
+    sa.template finish<NS>(Ahi, Alo, g.a, nrows, k0, tid);
+    if (MODE == MODE_FWD) {
+      sbT.pin();
+      sbT.template finish<NS>(Bhi, Blo, wop, BK, g.C - col0, 0, tid);
+    } else {
+      sbN.pin();
+      sbN.template finish<NS>(Bhi, Blo, wop, g.C - col0, k0, tid);
     }
     __syncthreads();
+    if (k0 + BK < g.K) issue_chunk(k0 + BK);
     mma_chunk<MT, NT, BK, NS>(acc, Ahi, Alo, Bhi, Blo, wrow0, wcol0, lane);
     __syncthreads();
   }
