@@ -138,7 +138,7 @@ __device__ __forceinline__ void panel_write_b(const u32x4 (&pf)[NT][PF], __bf16*
   }
 }
 
-template <int NS, int K>
+template <int NS, int K, bool STATS>
 __global__ __launch_bounds__(256) void panel_max_kernel(const PanelArgs g) {
   constexpr int BM = 64, BN = 128;
   constexpr int PA = K + 8;                          // LDS row pitch (bf16 elements): conflict-free b128 rows
@@ -253,15 +253,17 @@ __global__ __launch_bounds__(256) void panel_max_kernel(const PanelArgs g) {
       float a1 = 0.f, a2 = 0.f, best = -INFINITY;
       int besti = 0x7fffffff;
       if (full) {
-        f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};         // packed pairs: v_pk_add_f32 / v_pk_fma_f32
+        if (STATS) {                                     // inference (moving statistics) needs no sums: a quarter of the epilogue
+          f32x2 s1 = {0.f, 0.f}, s2 = {0.f, 0.f};       // packed pairs: v_pk_add_f32 / v_pk_fma_f32
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const f32x2 v2 = {acc[n][e], acc[n][e + 1]};
-          s1 += v2;
-          s2 = __builtin_elementwise_fma(v2, v2, s2);
+          for (int e = 0; e < 16; e += 2) {
+            const f32x2 v2 = {acc[n][e], acc[n][e + 1]};
+            s1 += v2;
+            s2 = __builtin_elementwise_fma(v2, v2, s2);
+          }
+          a1 = s1.x + s1.y;
+          a2 = s2.x + s2.y;
         }
-        a1 = s1.x + s1.y;
-        a2 = s2.x + s2.y;
         if (g.presigned) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
@@ -285,8 +287,10 @@ __global__ __launch_bounds__(256) void panel_max_kernel(const PanelArgs g) {
           const int il = wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
           const bool ok = il < nrows;
           const float v = ok ? acc[n][e] : 0.f;
-          a1 += v;
-          a2 = fmaf(v, v, a2);
+          if (STATS) {
+            a1 += v;
+            a2 = fmaf(v, v, a2);
+          }
           const float t = ok ? sg * v : -INFINITY;
           const bool better = t > best;
           best = better ? t : best;
@@ -294,16 +298,20 @@ __global__ __launch_bounds__(256) void panel_max_kernel(const PanelArgs g) {
         }
       }
       if (g.presigned) a1 *= sgc;                         // the column sum of z itself
-      a1 += __shfl_xor(a1, 32, 64);
-      a2 += __shfl_xor(a2, 32, 64);
+      if (STATS) {
+        a1 += __shfl_xor(a1, 32, 64);
+        a2 += __shfl_xor(a2, 32, 64);
+      }
       const float ob = __shfl_xor(best, 32, 64);
       const int oi = __shfl_xor(besti, 32, 64);
       const bool take = ob > best || (ob == best && oi < besti);
       best = take ? ob : best;
       besti = take ? oi : besti;
       if (h == 0) {
-        red[wm][0][jl] = a1;
-        red[wm][1][jl] = a2;
+        if (STATS) {
+          red[wm][0][jl] = a1;
+          red[wm][1][jl] = a2;
+        }
         red[wm][2][jl] = best;
         reinterpret_cast<int*>(red[wm][3])[jl] = besti;
       }
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(256) void panel_max_kernel(const PanelArgs g) {
     __syncthreads();                                 // red complete; every wave is done reading Bt
     if (tid < BN) {
       const int j = ct * BN + tid;
-      if (g.stat_partials) {
+      if (STATS && g.stat_partials) {
         float* p = g.stat_partials + (long long)bx * 2 * g.C + j;
         p[0] = red[0][0][tid] + red[1][0][tid];
         p[g.C] = red[0][1][tid] + red[1][1][tid];
@@ -343,13 +351,20 @@ int conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo
   g.tiles_per_cloud = cdiv(N, 64);
   g.sgn = sgn; g.pmax = pmax; g.pidx = pidx; g.stat_partials = stat_partials; g.presigned = presigned;
   const dim3 grid(B * g.tiles_per_cloud);
+  const bool st_ = stat_partials != nullptr;
+#define PN_PANEL_LAUNCH(NS_, K_)                                                                         \
+  do {                                                                                                  \
+    if (st_) hipLaunchKernelGGL((panel_max_kernel<NS_, K_, true>), grid, dim3(256), 0, st, g);          \
+    else hipLaunchKernelGGL((panel_max_kernel<NS_, K_, false>), grid, dim3(256), 0, st, g);             \
+  } while (0)
   if (prec == PN_PREC_BF16X3) {
-    if (K == 128) hipLaunchKernelGGL((panel_max_kernel<3, 128>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((panel_max_kernel<3, 64>), grid, dim3(256), 0, st, g);
+    if (K == 128) PN_PANEL_LAUNCH(3, 128);
+    else PN_PANEL_LAUNCH(3, 64);
   } else {
-    if (K == 128) hipLaunchKernelGGL((panel_max_kernel<1, 128>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((panel_max_kernel<1, 64>), grid, dim3(256), 0, st, g);
+    if (K == 128) PN_PANEL_LAUNCH(1, 128);
+    else PN_PANEL_LAUNCH(1, 64);
   }
+#undef PN_PANEL_LAUNCH
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
