@@ -118,6 +118,11 @@ int pn_conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, in
 int pn_weights_prep(const float* w, int K, int C, void* wb_hi, void* wb_lo, pn_stream stream);
 int pn_conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C,
                           const float* sgn, float* pmax, int32_t* pidx, float* stat_partials, int prec, pn_stream stream);
+/* the same with 128-row panels (panel_rows = 64 or 128; tiles = B * ceil(N / panel_rows)): every panel streams the whole bf16
+ * kernel from L2, so the larger panel halves that traffic.  The model plan uses 128. */
+int pn_conv_fwd_max_panel_rows(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C,
+                               const float* sgn, float* pmax, int32_t* pidx, float* stat_partials, int prec, int panel_rows,
+                               pn_stream stream);
 
 /* --- data gradient of a ConvLayer: out = [relu-mask] (dz . W^T + addend), plus the two partial sums
  * BatchNormalization's backward needs (sum dy_hat, sum dy_hat*z) per channel.

@@ -41,6 +41,10 @@ int pn_conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, in
 int pn_weights_prep(const float* w, int K, int C, void* wb_hi, void* wb_lo, pn_stream stream) {
   return weights_prep(w, K, C, wb_hi, wb_lo, S(stream));
 }
+int pn_conv_fwd_max_panel_rows(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C, const float* sgn,
+                               float* pmax, int32_t* pidx, float* part, int prec, int panel_rows, pn_stream stream) {
+  return conv_fwd_max_panel(x, wb_hi, wb_lo, B, N, K, C, sgn, pmax, pidx, part, prec, S(stream), 0, panel_rows);
+}
 int pn_conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C, const float* sgn,
                           float* pmax, int32_t* pidx, float* part, int prec, pn_stream stream) {
   return conv_fwd_max_panel(x, wb_hi, wb_lo, B, N, K, C, sgn, pmax, pidx, part, prec, S(stream));

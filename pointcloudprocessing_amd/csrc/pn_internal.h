@@ -18,7 +18,7 @@ int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, i
 // pn_panel.hip
 int weights_prep(const float* w, int K, int C, void* hi, void* lo, hipStream_t st);
 int conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C, const float* sgn,
-                       float* pmax, int* pidx, float* stat_partials, int prec, hipStream_t st, int presigned = 0);
+                       float* pmax, int* pidx, float* stat_partials, int prec, hipStream_t st, int presigned = 0, int panel_rows = 64);
 
 // pn_pointwise.hip
 int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st);

@@ -195,13 +195,18 @@ static void plan_cl(Arena& A, CL& l, const char* nm, long long M, int T, int C, 
     l.dy = store_z ? A.get<float>((n + ".dy").c_str(), (size_t)M * C) : nullptr;
   }
 }
+// rows per panel of the fused 128->1024 + max kernel (pn_panel.hip): 128 halves the L2 traffic of the weight stream
+static int panel_rows() {
+  static const int r = getenv("PN_PANEL_ROWS") ? atoi(getenv("PN_PANEL_ROWS")) : 128;
+  return r == 64 ? 64 : 128;
+}
 static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, int T, int K, int C, bool training) {
   std::string n(nm);
-  m.tpc64 = cdiv(N, 64);
+  m.tpc64 = cdiv(N, panel_rows());          // panel tiles per cloud (the buffers below are sized for 64-row panels, the finer case)
   m.T64 = B * m.tpc64;
   m.sgn = A.get<float>((n + ".sgn").c_str(), C);
-  m.pmax = A.get<float>((n + ".pmax").c_str(), (size_t)m.T64 * C);
-  m.pidx = A.get<int>((n + ".pidx").c_str(), (size_t)m.T64 * C);
+  m.pmax = A.get<float>((n + ".pmax").c_str(), (size_t)B * cdiv(N, 64) * C);
+  m.pidx = A.get<int>((n + ".pidx").c_str(), (size_t)B * cdiv(N, 64) * C);
   m.wb_hi = A.get<unsigned short>((n + ".wb_hi").c_str(), (size_t)K * C);
   m.wb_lo = A.get<unsigned short>((n + ".wb_lo").c_str(), (size_t)K * C);
   m.g = A.get<float>((n + ".g").c_str(), (size_t)B * C);
@@ -431,7 +436,7 @@ struct Run {
     void** ev = io.prof_events;
     if (ev && ev[2 * prof_slot]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot]), st);
     PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.sgn, m.pmax, m.pidx, bn_batch(r.block) ? l.part : nullptr,
-                              prec, st, 1));
+                              prec, st, 1, panel_rows()));
     if (ev && ev[2 * prof_slot + 1]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot + 1]), st);
     // (a fused statistics + reduce_max finaliser was measured slower than the pair: 17.5 vs 5.0 + 7.6 us)
     PN_TRY(bn_fin(l, r, m.T64));

@@ -113,40 +113,42 @@ struct PanelArgs {
 
 // 256 threads = 4 waves as 2 (row halves of 32) x 2 (column halves of 64); wave tile 32 x 64 = 1 x 2 MFMA 32x32 blocks.
 // K is a compile-time constant so that every loop over k unrolls and every staging array stays in registers.
-template <int NT, int PF, int K, int PA>
+template <int NT, int PF, int K, int PA, int THREADS>
 __device__ __forceinline__ void panel_issue_b(u32x4 (&pf)[NT][PF], const __bf16* __restrict__ whi, const __bf16* __restrict__ wlo,
                                               int ct, int tid) {
   constexpr int CHB = K / 8;
 #pragma unroll
   for (int p = 0; p < PF; ++p) {
-    const int c = tid + 256 * p;                     // 128 * CHB chunks per tile, PF * 256 == 128 * CHB
+    const int c = tid + THREADS * p;                 // 128 * CHB chunks per tile, PF * THREADS == 128 * CHB
     const int j = c / CHB, kc = (c % CHB) * 8;
     const long long o = (long long)(ct * 128 + j) * K + kc;
     pf[0][p] = *reinterpret_cast<const u32x4*>(whi + o);
     if (NT == 2) pf[NT - 1][p] = *reinterpret_cast<const u32x4*>(wlo + o);
   }
 }
-template <int NT, int PF, int K, int PA>
+template <int NT, int PF, int K, int PA, int THREADS>
 __device__ __forceinline__ void panel_write_b(const u32x4 (&pf)[NT][PF], __bf16* __restrict__ bhi, __bf16* __restrict__ blo, int tid) {
   constexpr int CHB = K / 8;
 #pragma unroll
   for (int p = 0; p < PF; ++p) {
-    const int c = tid + 256 * p;
+    const int c = tid + THREADS * p;
     const int j = c / CHB, kc = (c % CHB) * 8;
     *reinterpret_cast<u32x4*>(bhi + j * PA + kc) = pf[0][p];
     if (NT == 2) *reinterpret_cast<u32x4*>(blo + j * PA + kc) = pf[NT - 1][p];
   }
 }
 
-template <int NS, int K, bool STATS>
-__global__ __launch_bounds__(256) void panel_max_kernel(const PanelArgs g) {
-  constexpr int BM = 64, BN = 128;
+// RG = row groups of 32 per panel: 2 -> 64-row panels, 256 threads; 4 -> 128-row panels, 512 threads.  Every panel streams the
+// whole bf16 kernel (256 KB at 128 x 1024) from L2, so a 128-row panel halves that traffic (131 -> 66 MB per launch at B*N = 32,768).
+template <int NS, int K, bool STATS, int RG>
+__global__ __launch_bounds__(128 * RG) void panel_max_kernel(const PanelArgs g) {
+  constexpr int BM = 32 * RG, BN = 128, THREADS = 128 * RG;
   constexpr int PA = K + 8;                          // LDS row pitch (bf16 elements): conflict-free b128 rows
   constexpr int NT = (NS == 3) ? 2 : 1;
-  constexpr int PF = (BN * (K / 8)) / 256;           // 16-byte weight chunks per thread per tile (8 at K = 128)
+  constexpr int PF = (BN * (K / 8)) / THREADS;       // 16-byte weight chunks per thread per tile (8 at K = 128, 256 threads)
   __shared__ __attribute__((aligned(16))) __bf16 Ap[NT][BM * PA];
   __shared__ __attribute__((aligned(16))) __bf16 Bt[NT][BN * PA];
-  __shared__ float red[2][4][BN];                    // [row half][sum, sumsq, max, idx][channel]
+  __shared__ float red[RG][4][BN];                   // [row group][sum, sumsq, max, idx][channel]
   __shared__ float sgn_s[1024];                      // sign per channel, staged once (C <= 1024 per pass)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -160,12 +162,12 @@ __global__ __launch_bounds__(256) void panel_max_kernel(const PanelArgs g) {
 
   // first weight tile in flight while the activation panel is staged
   u32x4 pf[NT][PF];
-  panel_issue_b<NT, PF, K, PA>(pf, g.wb_hi, g.wb_lo, 0, tid);
+  panel_issue_b<NT, PF, K, PA, THREADS>(pf, g.wb_hi, g.wb_lo, 0, tid);
 
   // ---- stage the activation panel: thread <-> (row, 8 consecutive k); coefficients indexed by k -----------------
   {
     constexpr int CH = K / 8;                        // 16-byte chunks per row
-    constexpr int RP = 256 / CH;                     // rows per pass
+    constexpr int RP = THREADS / CH;                 // rows per pass
     constexpr int P = BM / RP;
     const int ch = tid % CH, rin = tid / CH;
     const int k = ch * 8;
@@ -210,8 +212,8 @@ __global__ __launch_bounds__(256) void panel_max_kernel(const PanelArgs g) {
       if (NS == 3) *reinterpret_cast<bf16x8*>(&Ap[NT - 1][rr * PA + k]) = lv;
     }
   }
-  for (int c = tid; c < g.C && c < 1024; c += 256) sgn_s[c] = (g.sgn[c] < 0.f) ? -1.f : 1.f;
-  panel_write_b<NT, PF, K, PA>(pf, Bt[0], Bt[NT - 1], tid);
+  for (int c = tid; c < g.C && c < 1024; c += THREADS) sgn_s[c] = (g.sgn[c] < 0.f) ? -1.f : 1.f;
+  panel_write_b<NT, PF, K, PA, THREADS>(pf, Bt[0], Bt[NT - 1], tid);
   __syncthreads();
 
   // ---- channel tiles -------------------------------------------------------------------------------------------
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void panel_max_kernel(const PanelArgs g) {
   const bool full = nrows == BM;                      // block-uniform
   const int rbase_lane = row_in_cloud0 + wm * 32 + 4 * h;
   for (int ct = 0; ct < n_ct; ++ct) {
-    if (ct + 1 < n_ct) panel_issue_b<NT, PF, K, PA>(pf, g.wb_hi, g.wb_lo, ct + 1, tid);   // flies under the MFMAs
+    if (ct + 1 < n_ct) panel_issue_b<NT, PF, K, PA, THREADS>(pf, g.wb_hi, g.wb_lo, ct + 1, tid);   // flies under the MFMAs
     f32x16 acc[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n)
@@ -321,22 +323,30 @@ __global__ __launch_bounds__(256) void panel_max_kernel(const PanelArgs g) {
       const int j = ct * BN + tid;
       if (STATS && g.stat_partials) {
         float* p = g.stat_partials + (long long)bx * 2 * g.C + j;
-        p[0] = red[0][0][tid] + red[1][0][tid];
-        p[g.C] = red[0][1][tid] + red[1][1][tid];
+        float t1 = red[0][0][tid], t2 = red[0][1][tid];
+#pragma unroll
+        for (int q = 1; q < RG; ++q) { t1 += red[q][0][tid]; t2 += red[q][1][tid]; }
+        p[0] = t1;
+        p[g.C] = t2;
       }
-      float v0 = red[0][2][tid], v1 = red[1][2][tid];
-      int i0 = reinterpret_cast<int*>(red[0][3])[tid], i1 = reinterpret_cast<int*>(red[1][3])[tid];
-      if (v1 > v0 || (v1 == v0 && i1 < i0)) { v0 = v1; i0 = i1; }
+      float v0 = red[0][2][tid];
+      int i0 = reinterpret_cast<int*>(red[0][3])[tid];
+#pragma unroll
+      for (int q = 1; q < RG; ++q) {                   // row groups ascend: a later group wins only with a strictly larger value
+        const float v1 = red[q][2][tid];
+        const int i1 = reinterpret_cast<int*>(red[q][3])[tid];
+        if (v1 > v0 || (v1 == v0 && i1 < i0)) { v0 = v1; i0 = i1; }
+      }
       g.pmax[(long long)bx * g.C + j] = v0;
       g.pidx[(long long)bx * g.C + j] = i0;
     }
-    if (ct + 1 < n_ct) panel_write_b<NT, PF, K, PA>(pf, Bt[0], Bt[NT - 1], tid);
+    if (ct + 1 < n_ct) panel_write_b<NT, PF, K, PA, THREADS>(pf, Bt[0], Bt[NT - 1], tid);
     __syncthreads();                                 // next tile visible; red free again
   }
 }
 
 int conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C, const float* sgn,
-                       float* pmax, int* pidx, float* stat_partials, int prec, hipStream_t st, int presigned) {
+                       float* pmax, int* pidx, float* stat_partials, int prec, hipStream_t st, int presigned, int panel_rows) {
   PN_CHECK_ARG(x && x->s1 && !x->s2, "pn_conv_fwd_max_panel: bad operand");
   PN_CHECK_ARG((reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && x->ld % 4 == 0 && x->ld >= K, "pn_conv_fwd_max_panel: operand alignment");
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_fwd_max_panel: B and N must be positive");
@@ -348,14 +358,20 @@ int conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo
   memset(&g, 0, sizeof(g));
   g.a = *x; g.wb_hi = reinterpret_cast<const __bf16*>(wb_hi); g.wb_lo = reinterpret_cast<const __bf16*>(wb_lo);
   g.B = B; g.N = N; g.K = K; g.C = C;
-  g.tiles_per_cloud = cdiv(N, 64);
+  PN_CHECK_ARG(panel_rows == 64 || panel_rows == 128, "pn_conv_fwd_max_panel: panel_rows must be 64 or 128");
+  g.tiles_per_cloud = cdiv(N, panel_rows);
   g.sgn = sgn; g.pmax = pmax; g.pidx = pidx; g.stat_partials = stat_partials; g.presigned = presigned;
   const dim3 grid(B * g.tiles_per_cloud);
   const bool st_ = stat_partials != nullptr;
-#define PN_PANEL_LAUNCH(NS_, K_)                                                                         \
-  do {                                                                                                  \
-    if (st_) hipLaunchKernelGGL((panel_max_kernel<NS_, K_, true>), grid, dim3(256), 0, st, g);          \
-    else hipLaunchKernelGGL((panel_max_kernel<NS_, K_, false>), grid, dim3(256), 0, st, g);             \
+#define PN_PANEL_LAUNCH(NS_, K_)                                                                                       \
+  do {                                                                                                                \
+    if (panel_rows == 128) {                                                                                          \
+      if (st_) hipLaunchKernelGGL((panel_max_kernel<NS_, K_, true, 4>), grid, dim3(512), 0, st, g);                   \
+      else hipLaunchKernelGGL((panel_max_kernel<NS_, K_, false, 4>), grid, dim3(512), 0, st, g);                      \
+    } else {                                                                                                          \
+      if (st_) hipLaunchKernelGGL((panel_max_kernel<NS_, K_, true, 2>), grid, dim3(256), 0, st, g);                   \
+      else hipLaunchKernelGGL((panel_max_kernel<NS_, K_, false, 2>), grid, dim3(256), 0, st, g);                      \
+    }                                                                                                                 \
   } while (0)
   if (prec == PN_PREC_BF16X3) {
     if (K == 128) PN_PANEL_LAUNCH(3, 128);

@@ -66,18 +66,18 @@ def conv_fwd_max(x_op, w, B, N, K, C_, sgn, prec):
     return pmax, pidx, part
 
 
-def conv_fwd_max_panel(x_op, w, B, N, K, C_, sgn, prec, want_stats=True):
-    """row-panel variant: bf16 channel-major weight copy + 64-row tiles (want_stats=False: inference, no BN sums)"""
+def conv_fwd_max_panel(x_op, w, B, N, K, C_, sgn, prec, want_stats=True, panel_rows=64):
+    """row-panel variant: bf16 channel-major weight copy + 64- or 128-row panels (want_stats=False: inference, no BN sums)"""
     dev = w.device
-    T = B * ((N + 63) // 64)
+    T = B * ((N + panel_rows - 1) // panel_rows)
     hi = torch.empty(C_ * K, device=dev, dtype=torch.bfloat16)
     lo = torch.empty(C_ * K, device=dev, dtype=torch.bfloat16)
     check(lib().pn_weights_prep(ptr(w), K, C_, ptr(hi), ptr(lo), current_stream()), "pn_weights_prep")
     pmax = torch.empty(T, C_, device=dev, dtype=F32)
     pidx = torch.empty(T, C_, device=dev, dtype=torch.int32)
     part = torch.empty(T, 2, C_, device=dev, dtype=F32) if want_stats else None
-    check(lib().pn_conv_fwd_max_panel(C.byref(x_op), ptr(hi), ptr(lo), B, N, K, C_, ptr(sgn), ptr(pmax), ptr(pidx), ptr(part), prec,
-                                      current_stream()), "pn_conv_fwd_max_panel")
+    check(lib().pn_conv_fwd_max_panel_rows(C.byref(x_op), ptr(hi), ptr(lo), B, N, K, C_, ptr(sgn), ptr(pmax), ptr(pidx), ptr(part), prec,
+                                           panel_rows, current_stream()), "pn_conv_fwd_max_panel_rows")
     return pmax, pidx, part
 
 

@@ -156,7 +156,13 @@ def test_training_step_gradients_match_oracle(dev, profile, vanilla):
         a = ws(wn + ".a")
         decisions[on + ".relu"] = (a > 0).view(B, -1)
     for on, wn in max_map.items():
-        decisions[on + ".argmax"] = ws(wn + ".arg", torch.int32).view(B, 1024)
+        arg = ws(wn + ".arg", torch.int32).view(B, 1024)
+        decisions[on + ".argmax"] = arg
+        # the ReLU behind the max: relu(max) = max(relu), so only the arg-max row of each (cloud, channel) matters; impose the GPU's
+        # sign there (a BN output within rounding of 0 at that row may legitimately flip)
+        mask = torch.ones(B, N, 1024, dtype=torch.bool)
+        mask.scatter_(1, arg.long().unsqueeze(1), (ws(wn + ".g").view(B, 1024) > 0).unsqueeze(1))
+        decisions[(on if on.startswith("mlp") else on + ".conv3") + ".relu"] = mask
 
     p64 = {k: v.double().requires_grad_(O.is_trainable_name(k) and tr.get(O.block_of(k), True)) for k, v in params.items()}
     # (1) the oracle's own decisions, to see where they differ from the GPU's

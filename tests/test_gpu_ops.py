@@ -135,9 +135,9 @@ def test_conv_fwd_lazy_bn_relu_and_per_cloud_weights(dev, prec):
     assert err < tol * max(1.0, float(ref.abs().max())), float(err)
 
 
-@pytest.mark.parametrize("panel", [False, True])
+@pytest.mark.parametrize("panel", [0, 64, 128])          # 0: the tiled kernel; 64 / 128: rows per panel of the panel kernel
 @pytest.mark.parametrize("prec", [1, 3])
-@pytest.mark.parametrize("B,N", [(2, 256), (3, 200), (1, 1000), (2, 33)])
+@pytest.mark.parametrize("B,N", [(2, 256), (3, 200), (1, 1000), (2, 33), (16, 136)])
 def test_conv_fwd_max_matches_reduce_max(dev, prec, B, N, panel):
     """ConvLayer(128->1024)+BN+ReLU+reduce_max (PointNet.py:242-248) without the (B,N,1024) tensor."""
     ops = _ops()
@@ -151,7 +151,10 @@ def test_conv_fwd_max_matches_reduce_max(dev, prec, B, N, panel):
     mv = torch.ones(C)
     sgn = ops.sign(gamma.to(dev))
     op = _lib().operand(x.to(dev))
-    pmax, pidx, part = (ops.conv_fwd_max_panel if panel else ops.conv_fwd_max)(op, w.to(dev), B, N, K, C, sgn, prec)
+    if panel:
+        pmax, pidx, part = ops.conv_fwd_max_panel(op, w.to(dev), B, N, K, C, sgn, prec, panel_rows=panel)
+    else:
+        pmax, pidx, part = ops.conv_fwd_max(op, w.to(dev), B, N, K, C, sgn, prec)
     mean, invstd, scale, shift = ops.bn_finalize(part, B * N, gamma.to(dev), beta.to(dev), mm.to(dev), mv.to(dev))
     gfeat, zstar, arg = ops.max_finalize(pmax, pidx, B, sgn, scale, shift)
     z = (x.double() @ w.double()).view(B, N, C)
