@@ -176,7 +176,7 @@ def main():
     # algorithmic bytes: pre-BN input rows read once (fp32) + the bf16 kernel copy + per-(cloud, channel) max/argmax/2 sums
     bytes_per_launch = 128 * 4 * B * N + 128 * 1024 * 2 * (2 if args.precision == "bf16x3" else 1) + B * 1024 * 16
     traffic = None        # HBM bytes per launch from rocprofv3 PMC passes of this same workload (profiles/, corrected per the guide)
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1", "r1b_panel_pmc.json")
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "round1", "r1f_panel_pmc.json")
     if os.path.exists(pmc_file) and (B, N, args.precision) == (32, 1024, "bf16"):
         with open(pmc_file) as f:
             traffic = json.load(f)["traffic_bytes_per_launch"]
