@@ -3,15 +3,17 @@
 //
 // The generic engine (pn_gemm.hip) gives every (row tile, column tile) pair its own workgroup, so the fp32 activation
 // tile is re-staged C/128 times and the fp32 Keras kernel is gathered with 4-byte loads: at C = 1024 the launch is
-// bound by L2 -> CU traffic, not by MFMA.  Here a workgroup owns a PANEL of 64 point rows for ALL C channels:
-//   * the activation panel (64 x K, BN+ReLU applied on load, rounded once to bf16 hi [+lo]) is staged into LDS once;
+// bound by L2 -> CU traffic, not by MFMA.  Here a workgroup owns a PANEL of 128 (or 64) point rows for ALL C channels:
+//   * the activation panel (rows x K, BN+ReLU applied on load, rounded once to bf16 hi [+lo]) is staged into LDS once;
 //   * the kernel is read from a bf16, channel-major copy Wb[C][K] (pn_weights_prep: one launch per step) with
 //     16-byte loads straight into the LDS image, one 128-channel tile at a time, prefetched in registers while the
 //     previous tile is in the matrix cores;
-//   * per channel tile the epilogue keeps max / arg-max row / sum / sum of squares of the 64 rows and writes one
-//     partial per (64-row tile, channel); no (B*N) x C tensor ever exists.
-// 64-row panels give B*N/64 workgroups (512 at B=32, N=1024) at ~52 KB of LDS, i.e. 2-3 resident per CU, so one
-// workgroup's epilogue (vector ALU) overlaps another's MFMAs and loads.
+//   * per channel tile the epilogue keeps max / arg-max row / sum / sum of squares of the panel's rows and writes one
+//     partial per (panel, channel); no (B*N) x C tensor ever exists.
+// Every panel streams the whole bf16 kernel (256 KB at 128 x 1024) from L2, so the panel height sets that traffic: 128-row
+// panels (512 threads, 78 KB of LDS in bf16 mode -> two per CU) move 66 MB per launch at B*N = 32,768, 64-row panels 131 MB
+// (22.5 vs 19.9 us at N = 1024, 81 vs 59 us at N = 4096).  Two workgroups per CU let one's epilogue (vector ALU) overlap the
+// other's MFMAs and loads.
 #include "pn_common.h"
 
 namespace pn {
@@ -149,7 +151,6 @@ __global__ __launch_bounds__(128 * RG) void panel_max_kernel(const PanelArgs g) 
   __shared__ __attribute__((aligned(16))) __bf16 Ap[NT][BM * PA];
   __shared__ __attribute__((aligned(16))) __bf16 Bt[NT][BN * PA];
   __shared__ float red[RG][4][BN];                   // [row group][sum, sumsq, max, idx][channel]
-  __shared__ float sgn_s[1024];                      // sign per channel, staged once (C <= 1024 per pass)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -212,7 +213,6 @@ __global__ __launch_bounds__(128 * RG) void panel_max_kernel(const PanelArgs g) 
       if (NS == 3) *reinterpret_cast<bf16x8*>(&Ap[NT - 1][rr * PA + k]) = lv;
     }
   }
-  for (int c = tid; c < g.C && c < 1024; c += THREADS) sgn_s[c] = (g.sgn[c] < 0.f) ? -1.f : 1.f;
   panel_write_b<NT, PF, K, PA, THREADS>(pf, Bt[0], Bt[NT - 1], tid);
   __syncthreads();
 
@@ -222,6 +222,11 @@ __global__ __launch_bounds__(128 * RG) void panel_max_kernel(const PanelArgs g) 
   const int rbase_lane = row_in_cloud0 + wm * 32 + 4 * h;
   for (int ct = 0; ct < n_ct; ++ct) {
     if (ct + 1 < n_ct) panel_issue_b<NT, PF, K, PA, THREADS>(pf, g.wb_hi, g.wb_lo, ct + 1, tid);   // flies under the MFMAs
+    // this lane's two channel signs, loaded here so that they arrive under the MFMAs (no LDS copy: the 4 KB it took kept a
+    // 128-row panel's workgroup above half of the LDS, i.e. at one workgroup per CU)
+    float sgv[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) sgv[n] = g.sgn[ct * BN + wn * 64 + n * 32 + r];
     f32x16 acc[2];
 #pragma unroll
     for (int n = 0; n < 2; ++n)
@@ -250,7 +255,7 @@ __global__ __launch_bounds__(128 * RG) void panel_max_kernel(const PanelArgs g) 
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
       const int jl = wn * 64 + n * 32 + r;
-      const float sgc = sgn_s[(ct * BN + jl) & 1023];
+      const float sgc = (sgv[n] < 0.f) ? -1.f : 1.f;
       const float sg = g.presigned ? 1.f : sgc;          // presigned copies: acc = sgn*z already, no per-element multiply
       float a1 = 0.f, a2 = 0.f, best = -INFINITY;
       int besti = 0x7fffffff;
