@@ -118,8 +118,9 @@ int pn_conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, in
 int pn_weights_prep(const float* w, int K, int C, void* wb_hi, void* wb_lo, pn_stream stream);
 int pn_conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C,
                           const float* sgn, float* pmax, int32_t* pidx, float* stat_partials, int prec, pn_stream stream);
-/* the same with 128-row panels (panel_rows = 64 or 128; tiles = B * ceil(N / panel_rows)): every panel streams the whole bf16
- * kernel from L2, so the larger panel halves that traffic.  The model plan uses 128. */
+/* the same with taller panels (panel_rows = 64, 128 or 256; tiles = B * ceil(N / panel_rows)): every panel streams the whole bf16
+ * kernel from L2, so a taller panel cuts that traffic.  The model plan uses 128, and 256 (bf16 operands only) once B * ceil(N/256)
+ * still gives a workgroup per CU. */
 int pn_conv_fwd_max_panel_rows(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C,
                                const float* sgn, float* pmax, int32_t* pidx, float* stat_partials, int prec, int panel_rows,
                                pn_stream stream);

@@ -131,7 +131,7 @@ struct ML {   // extra state of a max-pooled layer
   float *sgn, *pmax, *g, *zstar, *hs, *e, *nege, *f, *a1part, *a1, *gram, *GW, *Pm, *q, *D, *Wt, *We, *dG;
   int *pidx, *arg;
   unsigned short *wb_hi, *wb_lo;   // bf16 channel-major copies of the kernel for the panel kernel
-  int T64, tpc64;
+  int T64, tpc64, rows;   // panel tiles (all clouds / per cloud) and rows per panel
 };
 struct DLs {  // dense layer state (rows = B)
   float *z, *a, *mean, *invstd, *dz, *din;
@@ -196,13 +196,19 @@ static void plan_cl(Arena& A, CL& l, const char* nm, long long M, int T, int C, 
   }
 }
 // rows per panel of the fused 128->1024 + max kernel (pn_panel.hip): 128 halves the L2 traffic of the weight stream
-static int panel_rows() {
-  static const int r = getenv("PN_PANEL_ROWS") ? atoi(getenv("PN_PANEL_ROWS")) : 128;
-  return r == 64 ? 64 : 128;
+// 128 rows.  PN_PANEL_ROWS = 64 / 256 for experiments (256: bf16 operands only, the lo images do not fit beside a 256-row panel);
+// measured at B = 32: N = 1024: 22.5 / 19.9 us for 64 / 128 rows; N = 4096: 81 / 59 / 64 us for 64 / 128 / 256 rows.
+static int panel_rows(int B, int N, int prec) {
+  static const int forced = getenv("PN_PANEL_ROWS") ? atoi(getenv("PN_PANEL_ROWS")) : 0;
+  (void)B; (void)N;
+  if (forced == 64) return 64;
+  if (forced == 256 && prec != PN_PREC_BF16X3) return 256;
+  return 128;
 }
-static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, int T, int K, int C, bool training) {
+static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, int T, int K, int C, bool training, int prec) {
   std::string n(nm);
-  m.tpc64 = cdiv(N, panel_rows());          // panel tiles per cloud (the buffers below are sized for 64-row panels, the finer case)
+  m.rows = panel_rows(B, N, prec);
+  m.tpc64 = cdiv(N, m.rows);          // panel tiles per cloud (the buffers below are sized for 64-row panels, the finer case)
   m.T64 = B * m.tpc64;
   m.sgn = A.get<float>((n + ".sgn").c_str(), C);
   m.pmax = A.get<float>((n + ".pmax").c_str(), (size_t)B * cdiv(N, 64) * C);
@@ -241,12 +247,12 @@ static void plan_dl(Arena& A, DLs& d, const char* nm, int B, int K, int C, bool 
     d.din = A.get<float>((n + ".din").c_str(), (size_t)B * K);
   }
 }
-static void plan_tn(Arena& A, TN& t, const char* nm, int B, int N, long long M, int T, int K, bool training) {
+static void plan_tn(Arena& A, TN& t, const char* nm, int B, int N, long long M, int T, int K, bool training, int prec) {
   std::string n(nm);
   plan_cl(A, t.c1, (n + ".c1").c_str(), M, T, 64, true, training);
   plan_cl(A, t.c2, (n + ".c2").c_str(), M, T, 128, true, training);
   plan_cl(A, t.c3, (n + ".c3").c_str(), M, B * cdiv(N, 64), 1024, false, training);   // 64-row panel tiles
-  plan_ml(A, t.m3, (n + ".m3").c_str(), B, N, M, T, 128, 1024, training);
+  plan_ml(A, t.m3, (n + ".m3").c_str(), B, N, M, T, 128, 1024, training, prec);
   plan_dl(A, t.d1, (n + ".d1").c_str(), B, 1024, 512, training);
   plan_dl(A, t.d2, (n + ".d2").c_str(), B, 512, 256, training);
   t.R = A.get<float>((n + ".R").c_str(), (size_t)B * K * K);
@@ -263,15 +269,15 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
   w.cent = A.get<float>("centroid", (size_t)B * 3);
   w.scl = A.get<float>("scale", B);
   if (!d.vanilla) {
-    plan_tn(A, w.iT, "iT", B, N, M, T, 3, training);
-    plan_tn(A, w.fT, "fT", B, N, M, T, 64, training);
+    plan_tn(A, w.iT, "iT", B, N, M, T, 3, training, d.prec);
+    plan_tn(A, w.fT, "fT", B, N, M, T, 64, training, d.prec);
   }
   plan_cl(A, w.m11, "m11", M, T, 64, true, training);
   plan_cl(A, w.m12, "m12", M, T, 64, true, training);
   plan_cl(A, w.m21, "m21", M, T, 64, true, training);
   plan_cl(A, w.m22, "m22", M, T, 128, true, training);
   plan_cl(A, w.m23, "m23", M, B * cdiv(N, 64), 1024, false, training);                // 64-row panel tiles
-  plan_ml(A, w.mm23, "mm23", B, N, M, T, 128, 1024, training);
+  plan_ml(A, w.mm23, "mm23", B, N, M, T, 128, 1024, training, d.prec);
   plan_cl(A, w.s1, "s1", M, T, 512, true, training);
   plan_cl(A, w.s2, "s2", M, T, 256, true, training);
   plan_cl(A, w.s3, "s3", M, T, 128, true, training);
@@ -436,7 +442,7 @@ struct Run {
     void** ev = io.prof_events;
     if (ev && ev[2 * prof_slot]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot]), st);
     PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.sgn, m.pmax, m.pidx, bn_batch(r.block) ? l.part : nullptr,
-                              prec, st, 1, panel_rows()));
+                              prec, st, 1, m.rows));
     if (ev && ev[2 * prof_slot + 1]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot + 1]), st);
     // (a fused statistics + reduce_max finaliser was measured slower than the pair: 17.5 vs 5.0 + 7.6 us)
     PN_TRY(bn_fin(l, r, m.T64));

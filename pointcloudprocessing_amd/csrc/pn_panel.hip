@@ -350,6 +350,22 @@ __global__ __launch_bounds__(128 * RG) void panel_max_kernel(const PanelArgs g) 
   }
 }
 
+template <int NS, int K>
+static void launch_panel(const PanelArgs& g, dim3 grid, bool stats, int panel_rows, hipStream_t st) {
+  if (panel_rows == 256) {
+    if constexpr (!(NS == 3 && K == 128)) {          // the hi + lo images of a 256-row panel at K = 128 exceed the LDS
+      if (stats) hipLaunchKernelGGL((panel_max_kernel<NS, K, true, 8>), grid, dim3(1024), 0, st, g);
+      else hipLaunchKernelGGL((panel_max_kernel<NS, K, false, 8>), grid, dim3(1024), 0, st, g);
+    }
+  } else if (panel_rows == 128) {
+    if (stats) hipLaunchKernelGGL((panel_max_kernel<NS, K, true, 4>), grid, dim3(512), 0, st, g);
+    else hipLaunchKernelGGL((panel_max_kernel<NS, K, false, 4>), grid, dim3(512), 0, st, g);
+  } else {
+    if (stats) hipLaunchKernelGGL((panel_max_kernel<NS, K, true, 2>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((panel_max_kernel<NS, K, false, 2>), grid, dim3(256), 0, st, g);
+  }
+}
+
 int conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C, const float* sgn,
                        float* pmax, int* pidx, float* stat_partials, int prec, hipStream_t st, int presigned, int panel_rows) {
   PN_CHECK_ARG(x && x->s1 && !x->s2, "pn_conv_fwd_max_panel: bad operand");
@@ -363,29 +379,19 @@ int conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo
   memset(&g, 0, sizeof(g));
   g.a = *x; g.wb_hi = reinterpret_cast<const __bf16*>(wb_hi); g.wb_lo = reinterpret_cast<const __bf16*>(wb_lo);
   g.B = B; g.N = N; g.K = K; g.C = C;
-  PN_CHECK_ARG(panel_rows == 64 || panel_rows == 128, "pn_conv_fwd_max_panel: panel_rows must be 64 or 128");
+  PN_CHECK_ARG(panel_rows == 64 || panel_rows == 128 || panel_rows == 256, "pn_conv_fwd_max_panel: panel_rows must be 64, 128 or 256");
+  PN_CHECK_ARG(!(panel_rows == 256 && prec == PN_PREC_BF16X3 && K == 128), "pn_conv_fwd_max_panel: 256-row panels do not fit LDS with bf16x3 operands at K = 128");
   g.tiles_per_cloud = cdiv(N, panel_rows);
   g.sgn = sgn; g.pmax = pmax; g.pidx = pidx; g.stat_partials = stat_partials; g.presigned = presigned;
   const dim3 grid(B * g.tiles_per_cloud);
   const bool st_ = stat_partials != nullptr;
-#define PN_PANEL_LAUNCH(NS_, K_)                                                                                       \
-  do {                                                                                                                \
-    if (panel_rows == 128) {                                                                                          \
-      if (st_) hipLaunchKernelGGL((panel_max_kernel<NS_, K_, true, 4>), grid, dim3(512), 0, st, g);                   \
-      else hipLaunchKernelGGL((panel_max_kernel<NS_, K_, false, 4>), grid, dim3(512), 0, st, g);                      \
-    } else {                                                                                                          \
-      if (st_) hipLaunchKernelGGL((panel_max_kernel<NS_, K_, true, 2>), grid, dim3(256), 0, st, g);                   \
-      else hipLaunchKernelGGL((panel_max_kernel<NS_, K_, false, 2>), grid, dim3(256), 0, st, g);                      \
-    }                                                                                                                 \
-  } while (0)
   if (prec == PN_PREC_BF16X3) {
-    if (K == 128) PN_PANEL_LAUNCH(3, 128);
-    else PN_PANEL_LAUNCH(3, 64);
+    if (K == 128) launch_panel<3, 128>(g, grid, st_, panel_rows, st);
+    else launch_panel<3, 64>(g, grid, st_, panel_rows, st);
   } else {
-    if (K == 128) PN_PANEL_LAUNCH(1, 128);
-    else PN_PANEL_LAUNCH(1, 64);
+    if (K == 128) launch_panel<1, 128>(g, grid, st_, panel_rows, st);
+    else launch_panel<1, 64>(g, grid, st_, panel_rows, st);
   }
-#undef PN_PANEL_LAUNCH
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -135,7 +135,7 @@ def test_conv_fwd_lazy_bn_relu_and_per_cloud_weights(dev, prec):
     assert err < tol * max(1.0, float(ref.abs().max())), float(err)
 
 
-@pytest.mark.parametrize("panel", [0, 64, 128])          # 0: the tiled kernel; 64 / 128: rows per panel of the panel kernel
+@pytest.mark.parametrize("panel", [0, 64, 128, 256])     # 0: the tiled kernel; 64 / 128 / 256: rows per panel of the panel kernel
 @pytest.mark.parametrize("prec", [1, 3])
 @pytest.mark.parametrize("B,N", [(2, 256), (3, 200), (1, 1000), (2, 33), (16, 136)])
 def test_conv_fwd_max_matches_reduce_max(dev, prec, B, N, panel):
@@ -151,6 +151,8 @@ def test_conv_fwd_max_matches_reduce_max(dev, prec, B, N, panel):
     mv = torch.ones(C)
     sgn = ops.sign(gamma.to(dev))
     op = _lib().operand(x.to(dev))
+    if panel == 256 and prec == 3:
+        pytest.skip("256-row panels do not fit the LDS with bf16x3 operands at K = 128")
     if panel:
         pmax, pidx, part = ops.conv_fwd_max_panel(op, w.to(dev), B, N, K, C, sgn, prec, panel_rows=panel)
     else:
