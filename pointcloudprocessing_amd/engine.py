@@ -98,7 +98,9 @@ class TrainStep:
         if not self.overlap:
             if lo != 0:
                 return None                                   # single collective: issued with the second bucket
-            hi = self.model.grads_flat.numel()
+            # a synchronous collective: recent PyTorch runs it on the CURRENT stream (no cross-stream fence at all)
+            self.dist.all_reduce(self.model.grads_flat)
+            return None
         return self.dist.all_reduce(self.model.grads_flat[lo:hi], async_op=True)
 
     @staticmethod
