@@ -708,6 +708,8 @@ struct Run {
       if (tr(BLK_S5)) {
         PN_TRY(side([=] {
           PN_TRY(slab_reduce(w.s5slab, T, T, (long long)128 * d.cseg, gr(L.s5.kernel), st));
+          // bias gradient = column sums of dlogits: the forward's per-block partials already hold them when it produced dlogits itself
+          if (!d_seg) return sum_partials(w.seg_part + 2, (int)cdivll(M, seg_out_part_rows()), seg_out_part_stride(), d.cseg, gr(L.s5.bias), st);
           return sum_partials(w.seg_dlogits, (int)M, d.cseg, d.cseg, gr(L.s5.bias), st);
         }));
         PN_TRY(flush());

@@ -254,16 +254,24 @@ __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, co
   }
 }
 
-// out[e] = sum_{i<n} part[i*stride + e]
-__global__ __launch_bounds__(64) void sum_partials_kernel(const float* __restrict__ part, int n, int stride, int elems,
-                                                          float* __restrict__ out) {
+// out[e] = sum_{i<n} part[i*stride + e]      one 1024-thread block per element: fixed assignment of rows to threads, wave
+// shuffles, then the 16 wave sums in order -> bitwise reproducible
+__global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ part, int n, int stride, int elems,
+                                                            float* __restrict__ out) {
+  __shared__ double wsum[16];
   const int e = blockIdx.x;
   if (e >= elems) return;
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 64) acc += (double)part[(long long)i * stride + e];
+  for (int i = threadIdx.x; i < n; i += 1024) acc += (double)part[(long long)i * stride + e];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if (threadIdx.x == 0) out[e] = (float)acc;
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += wsum[w];
+    out[e] = (float)t;
+  }
 }
 
 int seg_out_fwd(const pn_operand* x, const float* w, const float* bias, long long M, int K, int C, const int* labels,
@@ -301,7 +309,7 @@ int seg_out_bwd(const pn_operand* x, const float* w, const float* dlogits, int B
 
 int sum_partials(const float* part, int n, int stride, int elems, float* out, hipStream_t st) {
   PN_CHECK_ARG(part && out && n > 0 && elems > 0, "sum_partials: bad arguments");
-  hipLaunchKernelGGL(sum_partials_kernel, dim3(elems), dim3(64), 0, st, part, n, stride, elems, out);
+  hipLaunchKernelGGL(sum_partials_kernel, dim3(elems), dim3(1024), 0, st, part, n, stride, elems, out);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
