@@ -77,9 +77,12 @@ __global__ __launch_bounds__(256) void conv3_fwd_kernel(const float* __restrict_
   const int c = blockIdx.y * 64 + lane;
   const float* wb = w + (long long)cloud * wcs;
   const float w0 = wb[c], w1 = wb[C + c], w2 = wb[2 * C + c];
-  const int r0 = tin * 128 + wave * 32;
+  // readfirstlane: the wave index is uniform, but only this tells the compiler -- the three coordinates of a row then arrive through
+  // scalar loads instead of three vector loads of one address each
+  const int r0 = tin * 128 + __builtin_amdgcn_readfirstlane(wave) * 32;
   const int r1 = min(N, r0 + 32);
   float s1 = 0.f, s2 = 0.f;
+#pragma unroll 4
   for (int r = r0; r < r1; ++r) {
     const long long row = (long long)cloud * N + r;
     const float a0 = x3[row * 3], a1 = x3[row * 3 + 1], a2 = x3[row * 3 + 2];
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restric
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = blockIdx.y * 64 + lane;
   const float ca = dz.ca ? dz.ca[c] : 1.f, cb = (dz.s2 && dz.cb) ? dz.cb[c] : 0.f, cc = dz.cc ? dz.cc[c] : 0.f;
-  const int r0 = tin * 128 + wave * 32;
+  const int r0 = tin * 128 + __builtin_amdgcn_readfirstlane(wave) * 32;     // provably wave-uniform: x3 rows through scalar loads
   const int r1 = min(N, r0 + 32);
   float g0 = 0.f, g1 = 0.f, g2 = 0.f;
   const bool two = dz.s2 != nullptr;

@@ -206,6 +206,7 @@ __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, co
                                                           float* __restrict__ wslab) {
   constexpr int K = 128;
   __shared__ float red[128][2 + SEG_CM];
+  __shared__ float out_s[128 * SEG_CM];
   const int bx = blockIdx.x, cloud = bx / tiles_per_cloud, tin = bx - cloud * tiles_per_cloud;
   const int k = threadIdx.x & 127, stream = threadIdx.x >> 7;
   float wk[SEG_CM], gw[SEG_CM];
@@ -222,7 +223,9 @@ __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, co
     const float z = x.s1[row * x.ld + k];
     const float pre = fmaf(ca, z, cc);
     const float a = fmaxf(pre, lo);
-    const float* dl = dlogits + row * C;
+    // the row is the same for every lane of a wave (stream = threadIdx.x >> 7), but only readfirstlane lets the compiler see it:
+    // the 12 gradient values then come through scalar loads instead of 12 vector loads of one address per row
+    const float* dl = dlogits + ((long long)cloud * N + __builtin_amdgcn_readfirstlane(r)) * C;
     float d = 0.f;
 #pragma unroll
     for (int c = 0; c < SEG_CM; ++c)
@@ -247,11 +250,15 @@ __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, co
       stat_part[(long long)bx * 2 * K + k] = S1 + red[k][0];
       stat_part[(long long)bx * 2 * K + K + k] = S2 + red[k][1];
     }
-    float* s = wslab + ((long long)bx * K + k) * C;
 #pragma unroll
     for (int c = 0; c < SEG_CM; ++c)
-      if (c < C) s[c] = gw[c] + red[k][2 + c];
+      if (c < C) out_s[k * C + c] = gw[c] + red[k][2 + c];
   }
+  __syncthreads();
+  // the slab [K][C] of this tile is contiguous: written through LDS so that consecutive lanes store consecutive floats (a lane per
+  // channel k writing its C values put 48-byte strides between lanes: 12 partial cache lines per store instruction)
+  float* s = wslab + (long long)bx * K * C;
+  for (int i = threadIdx.x; i < K * C; i += 256) s[i] = out_s[i];
 }
 
 // out[e] = sum_{i<n} part[i*stride + e]      one 1024-thread block per element: fixed assignment of rows to threads, wave
