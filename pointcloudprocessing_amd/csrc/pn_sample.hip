@@ -11,11 +11,14 @@ int zero_fill(float* p, long long n, hipStream_t st);   // pn_optim.hip
 
 // ------------------------------------------------------------------------------------------------------
 // FPS.  M sequential rounds, each a full argmax over the cloud: latency bound, not bandwidth bound.  A
-// block keeps 16 points per thread (xyz + running min-distance) in registers, so a round touches no
-// memory except the selected point.  Clouds above 16384 points are split over `bpc` co-resident blocks
-// that exchange one 8-byte {distance, index, round-tag} granule per round through device-scope relaxed
-// atomics (a single naturally aligned 8-byte sc1 store/load needs no other ordering:
-// MI355X_MICROARCH.md, "R2's granule").  Every spin is bounded.
+// block keeps its points (xyz + running min-distance, 4..28 per thread) in registers, so a round touches no
+// memory at all: the winner's coordinates travel through LDS.  Measured per round (MI355X): ~0.75 us of
+// reductions / barriers / LDS round trips + the distance update (5.75 VALU instructions per point):
+// 0.76 us at N <= 1024 (4 waves), 0.93 us at 4096, 1.56 us at 16384 (16 waves), 1.77 us at 21504 (12 waves x 28
+// points).  512-thread variants with 32 / 42 points per thread measured the same or slower.  Clouds above 21504
+// points are split over `bpc` co-resident blocks that exchange one 8-byte {distance, index, round-tag} granule
+// per round through device-scope relaxed atomics (a single naturally aligned 8-byte sc1 store/load needs no
+// other ordering: MI355X_MICROARCH.md, "R2's granule").  Every spin is bounded.
 // ------------------------------------------------------------------------------------------------------
 constexpr int FPS_T_MULTI = 1024;
 constexpr int FPS_PPT_MULTI = 16;     // points per thread when a cloud is split over blocks (and for clouds <= 16384 points)
@@ -27,30 +30,65 @@ __device__ __forceinline__ void fps_better(float& best, int& bi, float ob, int o
   if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
 }
 
+// Wave-wide max / min in six DPP steps (quad swaps, half-row and row mirrors, then the two row broadcasts of gfx9): the
+// result is complete in lane 63 and handed back as a wave-uniform value.  A shuffle-based tree costs six LDS-crossbar
+// round trips instead, and this sits on the critical path of every sampling round.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_move(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false); }
+__device__ __forceinline__ int wave_max_i32(int v) {
+  v = max(v, dpp_move<0xB1, 0xf>(v));    // quad_perm [1,0,3,2]
+  v = max(v, dpp_move<0x4E, 0xf>(v));    // quad_perm [2,3,0,1]
+  v = max(v, dpp_move<0x141, 0xf>(v));   // row_half_mirror
+  v = max(v, dpp_move<0x140, 0xf>(v));   // row_mirror
+  v = max(v, dpp_move<0x142, 0xa>(v));   // row_bcast:15 into rows 1, 3
+  v = max(v, dpp_move<0x143, 0xc>(v));   // row_bcast:31 into rows 2, 3
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_min_i32(int v) {
+  v = min(v, dpp_move<0xB1, 0xf>(v));
+  v = min(v, dpp_move<0x4E, 0xf>(v));
+  v = min(v, dpp_move<0x141, 0xf>(v));
+  v = min(v, dpp_move<0x140, 0xf>(v));
+  v = min(v, dpp_move<0x142, 0xa>(v));
+  v = min(v, dpp_move<0x143, 0xc>(v));
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+typedef float fps_v2f __attribute__((ext_vector_type(2)));
+
+// A round is (1) distance update + running max of the VALUE only: packed fp32 math, 5.5 VALU instructions per point;
+// (2) wave max (DPP) -> LDS -> barrier -> block max; (3) only in the wave(s) that hold the block max: lowest point index
+// with that distance, and the winner lane's coordinates picked out of its registers through a wave-uniform switch -> LDS
+// -> barrier.  Tracking the arg-max index inside the update loop costs twice the instructions of step (1).
 template <int FPS_PPT, int FPS_T>
 __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xyz, int N, int M, int start_idx, int bpc,
                                                     int* __restrict__ idx_out, float* __restrict__ mindist,
                                                     unsigned long long* __restrict__ xchg, int* __restrict__ err) {
 #pragma clang fp contract(off)   // the distance is specified without fused multiply-add (bit-exact vs the oracle)
-  __shared__ float s_best[2][16];
-  __shared__ int s_idx[2][16];
-  __shared__ float s_xyz[2][16][3];   // coordinates of each wave's candidate: the next round starts without a global load
+  static_assert(FPS_PPT % 2 == 0 && FPS_PPT <= 32 && FPS_T % 256 == 0, "fps_kernel: shape");
+  constexpr int NW = FPS_T / 64;
+  __shared__ __attribute__((aligned(16))) int s_best[16];
+  __shared__ __attribute__((aligned(16))) int s_widx[16];
+  __shared__ __attribute__((aligned(16))) float s_xyz[16][4];   // coordinates of each wave's candidate: the next round starts without a global load
   __shared__ int s_cur;
   const int cloud = blockIdx.x / bpc, blk = blockIdx.x - cloud * bpc;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const float* p = xyz + (long long)cloud * N * 3;
   const int base = blk * (FPS_T * FPS_PPT);
-  float px[FPS_PPT], py[FPS_PPT], pz[FPS_PPT], md[FPS_PPT];
+  fps_v2f px[FPS_PPT / 2], py[FPS_PPT / 2], pz[FPS_PPT / 2];   // point j of this thread = cloud index base + j * FPS_T + tid
+  // Running min-distance, kept as the BIT PATTERN of the fp32 value: distances are sums of squares (>= +0, never -0 or NaN
+  // for finite input) and padding is -1.0f, and on that set signed-integer order equals float order -- so min / max are
+  // single integer instructions (a float min would first canonicalise its operand: one more instruction per point).
+  int md[FPS_PPT];
+  constexpr int MD_PAD = (int)0xbf800000u, MD_INF = 0x7f800000;   // -1.0f, +inf
 #pragma unroll
   for (int j = 0; j < FPS_PPT; ++j) {
     const int i = base + j * FPS_T + tid;
-    if (i < N) {
-      px[j] = p[3 * i]; py[j] = p[3 * i + 1]; pz[j] = p[3 * i + 2];
-      md[j] = INFINITY;
-    } else {
-      px[j] = py[j] = pz[j] = 0.f;
-      md[j] = -1.f;
-    }
+    float x = 0.f, y = 0.f, z = 0.f;
+    md[j] = MD_PAD;                                    // padding: min(-1, d) stays -1 and never wins a round
+    if (i < N) { x = p[3 * i]; y = p[3 * i + 1]; z = p[3 * i + 2]; md[j] = MD_INF; }
+    if (j & 1) { px[j / 2].y = x; py[j / 2].y = y; pz[j / 2].y = z; }
+    else       { px[j / 2].x = x; py[j / 2].x = y; pz[j / 2].x = z; }
   }
   int cur = start_idx;
   float cx = p[3 * cur], cy = p[3 * cur + 1], cz = p[3 * cur + 2];
@@ -58,52 +96,73 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
   for (int it = 0; it < M; ++it) {
     if (blk == 0 && tid == 0) idx_out[(long long)cloud * M + it] = cur;
     if (it == M - 1) break;
-    float best = -1.f;
-    int bi = 0x7fffffff;
+    // (1) update
+    // the centre is wave-uniform: keep it in scalar registers (the 28-point variant has no vector register to spare)
+    const float ux = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cx)));
+    const float uy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cy)));
+    const float uz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cz)));
+    const fps_v2f c_x = {ux, ux}, c_y = {uy, uy}, c_z = {uz, uz};
+    int best = MD_PAD;
 #pragma unroll
-    for (int j = 0; j < FPS_PPT; ++j) {
-      const float dx = px[j] - cx, dy = py[j] - cy, dz = pz[j] - cz;
-      const float d = (dx * dx + dy * dy) + dz * dz;   // no contraction: see the pragma above
-      if (md[j] >= 0.f) {
-        md[j] = fminf(md[j], d);
-        if (md[j] > best) { best = md[j]; bi = base + j * FPS_T + tid; }
+    for (int q = 0; q < FPS_PPT / 2; ++q) {
+      const fps_v2f dx = px[q] - c_x, dy = py[q] - c_y, dz = pz[q] - c_z;
+      const fps_v2f d = (dx * dx + dy * dy) + dz * dz;   // no contraction: see the pragma above
+      md[2 * q] = min(md[2 * q], __float_as_int(d.x));
+      md[2 * q + 1] = min(md[2 * q + 1], __float_as_int(d.y));
+      best = max(best, max(md[2 * q], md[2 * q + 1]));
+    }
+    // (2) block max of the value
+    const int wmax = wave_max_i32(best);
+    if (lane == 0) s_best[wave] = wmax;
+    __syncthreads();
+    int gmax = s_best[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) gmax = max(gmax, s_best[w]);
+    // (3) lowest index holding it
+    int widx = 0x7fffffff;
+    if (wmax == gmax) {                                 // wave-uniform
+      int jw = FPS_PPT;
+#pragma unroll
+      for (int j = FPS_PPT - 1; j >= 0; --j) jw = (md[j] == gmax) ? j : jw;
+      const int cand = jw < FPS_PPT ? base + jw * FPS_T + tid : 0x7fffffff;
+      widx = wave_min_i32(cand);
+      if (cand == widx && jw < FPS_PPT) {               // exactly one lane: publish its point's coordinates
+        const int ju = __builtin_amdgcn_readfirstlane(jw);
+        float bx = 0.f, by = 0.f, bz = 0.f;
+#define PN_FPS_CASE(J)                                                                                     \
+  case J:                                                                                                  \
+    if constexpr (J < FPS_PPT) {                                                                           \
+      bx = (J & 1) ? px[J / 2].y : px[J / 2].x;                                                            \
+      by = (J & 1) ? py[J / 2].y : py[J / 2].x;                                                            \
+      bz = (J & 1) ? pz[J / 2].y : pz[J / 2].x;                                                            \
+    }                                                                                                      \
+    break;
+        switch (ju) {
+          PN_FPS_CASE(0) PN_FPS_CASE(1) PN_FPS_CASE(2) PN_FPS_CASE(3) PN_FPS_CASE(4) PN_FPS_CASE(5) PN_FPS_CASE(6) PN_FPS_CASE(7)
+          PN_FPS_CASE(8) PN_FPS_CASE(9) PN_FPS_CASE(10) PN_FPS_CASE(11) PN_FPS_CASE(12) PN_FPS_CASE(13) PN_FPS_CASE(14) PN_FPS_CASE(15)
+          PN_FPS_CASE(16) PN_FPS_CASE(17) PN_FPS_CASE(18) PN_FPS_CASE(19) PN_FPS_CASE(20) PN_FPS_CASE(21) PN_FPS_CASE(22) PN_FPS_CASE(23)
+          PN_FPS_CASE(24) PN_FPS_CASE(25) PN_FPS_CASE(26) PN_FPS_CASE(27) PN_FPS_CASE(28) PN_FPS_CASE(29) PN_FPS_CASE(30) PN_FPS_CASE(31)
+          default: break;
+        }
+#undef PN_FPS_CASE
+        s_xyz[wave][0] = bx; s_xyz[wave][1] = by; s_xyz[wave][2] = bz;
       }
     }
-    const int mine = bi;                 // this lane's own candidate
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ob = __shfl_xor(best, o, 64);
-      const int oi = __shfl_xor(bi, o, 64);
-      fps_better(best, bi, ob, oi);
-    }
-    const int par = it & 1;
-    if (lane == 0) { s_best[par][wave] = best; s_idx[par][wave] = bi; }
-    constexpr bool LDS_XYZ = (FPS_PPT <= 16);      // a 32-way register select chain ends up in scratch: the wide variant re-loads instead
-    if (LDS_XYZ && mine == bi && bi != 0x7fffffff) {          // exactly one lane per wave: publish the candidate's coordinates
-      const int jw = (bi - base - tid) / FPS_T;
-      float bx = px[0], by = py[0], bz = pz[0];
-#pragma unroll
-      for (int j = 1; j < FPS_PPT; ++j)
-        if (j == jw) { bx = px[j]; by = py[j]; bz = pz[j]; }
-      s_xyz[par][wave][0] = bx; s_xyz[par][wave][1] = by; s_xyz[par][wave][2] = bz;
-    }
+    if (lane == 0) s_widx[wave] = widx;
     __syncthreads();
-    best = s_best[par][0]; bi = s_idx[par][0];
-    int bw = 0;
+    int bi = s_widx[0];
 #pragma unroll
-    for (int w = 1; w < FPS_T / 64; ++w) {
-      const float ob = s_best[par][w];
-      const int oi = s_idx[par][w];
-      if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; bw = w; }
-    }
+    for (int w = 1; w < NW; ++w) bi = min(bi, s_widx[w]);
+    const float bestv = __int_as_float(gmax);
     if (bpc == 1) {
-      if (LDS_XYZ) { cx = s_xyz[par][bw][0]; cy = s_xyz[par][bw][1]; cz = s_xyz[par][bw][2]; }
-      else { cx = p[3 * bi]; cy = p[3 * bi + 1]; cz = p[3 * bi + 2]; }
+      const int bw = ((bi - base) % FPS_T) >> 6;        // the wave that owns point bi
+      cx = s_xyz[bw][0]; cy = s_xyz[bw][1]; cz = s_xyz[bw][2];
     }
     if (bpc > 1) {
+      const int par = it & 1;
       const unsigned tag = (unsigned)(it + 1) & 0xfffu;
       if (tid == 0) {
-        const unsigned long long gr = ((unsigned long long)__float_as_uint(best) << 32) |
+        const unsigned long long gr = ((unsigned long long)__float_as_uint(bestv) << 32) |
                                       ((unsigned long long)((unsigned)bi & 0xfffffu) << 12) | tag;
         __hip_atomic_store(&xc[par * bpc + blk], gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -143,10 +202,12 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
     cur = bi;
   }
   if (mindist) {
+    int t2 = tid;
+    asm volatile("" : "+v"(t2));   // or the 28 point indices of the prologue stay live in registers across the whole loop
 #pragma unroll
     for (int j = 0; j < FPS_PPT; ++j) {
-      const int i = base + j * FPS_T + tid;
-      if (i < N) mindist[(long long)cloud * N + i] = md[j];
+      const int i = base + j * FPS_T + t2;
+      if (i < N) mindist[(long long)cloud * N + i] = __int_as_float(md[j]);
     }
   }
 }
@@ -158,13 +219,18 @@ size_t fps_workspace_bytes(int B, int N) {
   return 16 + (size_t)B * 2 * bpc * sizeof(unsigned long long);
 }
 
+template <int PPT, int T>
+static void fps_launch(int blocks, hipStream_t st, const float* xyz, int N, int M, int start_idx, int bpc, int* idx_out, float* mindist,
+                       unsigned long long* xchg, int* err) {
+  hipLaunchKernelGGL((fps_kernel<PPT, T>), dim3(blocks), dim3(T), 0, st, xyz, N, M, start_idx, bpc, idx_out, mindist, xchg, err);
+}
+
 int fps(const float* xyz, int B, int N, int M, int start_idx, int* idx_out, float* mindist, void* ws, size_t ws_bytes,
         hipStream_t st) {
   PN_CHECK_ARG(xyz && idx_out, "pn_fps: null pointer");
   PN_CHECK_ARG(B > 0 && N > 0 && M > 0, "pn_fps: B, N, M must be positive (B=%d N=%d M=%d)", B, N, M);
   PN_CHECK_ARG(start_idx >= 0 && start_idx < N, "pn_fps: start_idx %d outside [0,%d)", start_idx, N);
   const int bpc = fps_blocks_per_cloud(N);
-  const bool wide = bpc == 1 && N > FPS_PER_BLOCK;
   PN_CHECK_ARG(bpc <= 64, "pn_fps: N=%d exceeds %d points per cloud", N, 64 * FPS_PER_BLOCK);
   PN_CHECK_ARG(ws && ws_bytes >= fps_workspace_bytes(B, N), "pn_fps: workspace too small");
   int* err = reinterpret_cast<int*>(ws);
@@ -174,14 +240,17 @@ int fps(const float* xyz, int B, int N, int M, int start_idx, int* idx_out, floa
   const int clouds_per_launch = bpc > 1 ? (128 / bpc > 0 ? 128 / bpc : 1) : B;
   for (int b0 = 0; b0 < B; b0 += clouds_per_launch) {
     const int nb = (B - b0) < clouds_per_launch ? (B - b0) : clouds_per_launch;
-    if (wide)
-      hipLaunchKernelGGL((fps_kernel<FPS_PPT_WIDE, FPS_T_WIDE>), dim3(nb * bpc), dim3(FPS_T_WIDE), 0, st, xyz + (long long)b0 * N * 3, N, M, start_idx, bpc,
-                         idx_out + (long long)b0 * M, mindist ? mindist + (long long)b0 * N : nullptr,
-                         xchg + (long long)b0 * 2 * bpc, err);
-    else
-      hipLaunchKernelGGL((fps_kernel<FPS_PPT_MULTI, FPS_T_MULTI>), dim3(nb * bpc), dim3(FPS_T_MULTI), 0, st, xyz + (long long)b0 * N * 3, N, M, start_idx, bpc,
-                         idx_out + (long long)b0 * M, mindist ? mindist + (long long)b0 * N : nullptr,
-                         xchg + (long long)b0 * 2 * bpc, err);
+    const float* x0 = xyz + (long long)b0 * N * 3;
+    int* i0 = idx_out + (long long)b0 * M;
+    float* m0 = mindist ? mindist + (long long)b0 * N : nullptr;
+    unsigned long long* c0 = xchg + (long long)b0 * 2 * bpc;
+    // a round costs a fixed ~1 us of reductions and barriers plus the distance update: small clouds take fewer waves
+    // (cheaper barriers, one wave per SIMD) and fewer points per thread
+    if (bpc > 1) fps_launch<FPS_PPT_MULTI, FPS_T_MULTI>(nb * bpc, st, x0, N, M, start_idx, bpc, i0, m0, c0, err);
+    else if (N <= 256 * 4) fps_launch<4, 256>(nb, st, x0, N, M, start_idx, 1, i0, m0, c0, err);
+    else if (N <= 256 * 16) fps_launch<16, 256>(nb, st, x0, N, M, start_idx, 1, i0, m0, c0, err);
+    else if (N <= FPS_PER_BLOCK) fps_launch<FPS_PPT_MULTI, FPS_T_MULTI>(nb, st, x0, N, M, start_idx, 1, i0, m0, c0, err);
+    else fps_launch<FPS_PPT_WIDE, FPS_T_WIDE>(nb, st, x0, N, M, start_idx, 1, i0, m0, c0, err);
     PN_CHECK_LAUNCH();
   }
   return PN_OK;

@@ -272,13 +272,19 @@ def test_bn_finalize_and_backward_coefficients(dev):
     assert torch.allclose(dbeta.cpu().double(), bt.grad, atol=1e-3, rtol=1e-4)
 
 
-@pytest.mark.parametrize("B,N,M", [(2, 1000, 64), (1, 5000, 512), (3, 17, 17), (1, 40000, 256), (2, 20000, 100), (1, 21504, 40), (1, 21505, 40), (1, 16384, 40), (1, 16385, 40)])
+@pytest.mark.parametrize("B,N,M", [(2, 1000, 64), (1, 5000, 512), (3, 17, 17), (1, 40000, 256), (2, 20000, 100), (1, 21504, 40), (1, 21505, 40), (1, 16384, 40), (1, 16385, 40),
+                                   (2, 1024, 300), (2, 1025, 100), (2, 4096, 200), (1, 4097, 100), (1, 131072, 64)])
 def test_fps_bit_exact_indices(dev, B, N, M):
     ops = _ops()
     rng = np.random.default_rng(9)
     xyz = rng.uniform(-10, 10, size=(B, N, 3)).astype(np.float32)
     if N >= 1000:
         xyz[:, 500:520] = xyz[:, 100:120]           # duplicated points: distance ties -> lowest index
+    if N >= 5000:                                   # ties inside one lane (i and i + block width), inside one wave, across waves
+        xyz[:, 140 + 768] = xyz[:, 140]
+        xyz[:, 141 + 1024] = xyz[:, 141]
+        xyz[:, 150] = xyz[:, 151]
+        xyz[:, 4000] = xyz[:, 152]
     idx, md = ops.farthest_point_sample(torch.from_numpy(xyz).to(dev), M, start_idx=0, return_mindist=True)
     for b in range(B):
         ri, rmd = SO.fps(xyz[b], M, 0)
