@@ -200,6 +200,11 @@ int pn_dense_bwd(const float* da, const float* z, const float* x, int ldx, int R
 int pn_softmax_xent(const float* logits, int R, int C, const int32_t* labels, float grad_scale, float* probs, float* dlogits,
                     float* loss_sum, float* correct, pn_stream stream);
 
+/* --- predicted class / part index of every row of a (R, C) probability (or logit) matrix: the FIRST maximum, as np.argmax and
+ * tf.math.argmax return it (the reference's notebooks: examples/pointnet_train.ipynb:445,499, examples/pointnet_example.ipynb:2244;
+ * keras' sparse_categorical_accuracy of pointnet_train.py:340-345 compares the same index with the label). */
+int pn_argmax_rows(const float* values, int64_t R, int C, int32_t* index, pn_stream stream);
+
 /* --- seg_l5_output (ConvLayer K -> Cseg <= 16 with bias, no BN; PointNet.py:141,288-290) fused with its softmax and the
  * per-point loss: probs (M, C) = softmax(x . w + bias) over M = B*N rows of a lazy operand; with labels: part[] receives
  * per-block partial (sum nll, #correct) pairs -- one block per pn_seg_out_part_rows() rows -- at stride pn_seg_out_part_stride()

@@ -85,6 +85,7 @@ SIGNATURES = {
     "pn_dense_layer": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
     "pn_dense_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _F, _P, _P, _P, _P, _P, _P]),
     "pn_softmax_xent": (_I, [_P, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
+    "pn_argmax_rows": (_I, [_P, _I64, _I, _P, _P]),
     "pn_seg_out_part_stride": (_I, []),
     "pn_seg_out_part_rows": (_I, []),
     "pn_seg_out_fwd": (_I, [_OP, _P, _P, _I64, _I, _I, _P, _F, _P, _P, _P, _P]),

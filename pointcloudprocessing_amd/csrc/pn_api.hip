@@ -94,6 +94,9 @@ int pn_softmax_xent(const float* logits, int R, int C, const int32_t* labels, fl
                     float* loss_sum, float* correct, pn_stream stream) {
   return softmax_xent_rows(logits, R, C, labels, grad_scale, probs, dlogits, loss_sum, correct, S(stream));
 }
+int pn_argmax_rows(const float* values, int64_t R, int C, int32_t* index, pn_stream stream) {
+  return argmax_rows(values, (long long)R, C, index, S(stream));
+}
 int pn_seg_out_part_stride(void) { return seg_out_part_stride(); }
 int pn_seg_out_part_rows(void) { return seg_out_part_rows(); }
 int pn_seg_out_fwd(const pn_operand* x, const float* w, const float* bias, int64_t M, int K, int C, const int32_t* labels, float grad_scale,

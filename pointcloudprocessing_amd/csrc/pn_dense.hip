@@ -648,6 +648,21 @@ __global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const float* __re
   for (int c = 0; c < C; ++c) d[c] = p[c] * (dp[c] - dot);
 }
 
+// class / part index of every row: the first maximum (np.argmax / tf.math.argmax order).  Rows are 48..92 bytes, so a
+// thread per row reads whole cache lines between neighbours; the launch is bandwidth-trivial (3 MB at B=32, N=2048).
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ v, long long R, int C, int* __restrict__ out) {
+  const long long r = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= R) return;
+  const float* p = v + r * C;
+  float best = p[0];
+  int bi = 0;
+  for (int c = 1; c < C; ++c) {
+    const float x = p[c];
+    if (x > best) { best = x; bi = c; }
+  }
+  out[r] = bi;
+}
+
 // ---- host wrappers ---------------------------------------------------------------------------------------
 size_t dense_partial_floats(int R, int K, int C) { return (size_t)dl_nsplit(K) * R * C; }
 
@@ -727,6 +742,13 @@ int softmax_xent_rows(const float* logits, int R, int C, const int* labels, floa
 int softmax_bwd_rows(const float* probs, const float* dprobs, long long R, int C, float* dlogits, hipStream_t st) {
   PN_CHECK_ARG(probs && dprobs && dlogits, "softmax_bwd_rows: null pointer");
   hipLaunchKernelGGL(softmax_bwd_rows_kernel, dim3((unsigned)cdivll(R, 256)), dim3(256), 0, st, probs, dprobs, R, C, dlogits);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+int argmax_rows(const float* values, long long R, int C, int* index, hipStream_t st) {
+  PN_CHECK_ARG(values && index && R > 0 && C > 0, "argmax_rows: bad arguments (R=%lld C=%d)", R, C);
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)cdivll(R, 256)), dim3(256), 0, st, values, R, C, index);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -56,6 +56,7 @@ int transpose2(const float* in, int R, int C, const float* rowscale, float* out,
 int softmax_xent_rows(const float* logits, int R, int C, const int* labels, float grad_scale, float* probs, float* dlogits,
                       float* loss_sum, float* correct, hipStream_t st);
 int softmax_bwd_rows(const float* probs, const float* dprobs, long long R, int C, float* dlogits, hipStream_t st);
+int argmax_rows(const float* values, long long R, int C, int* index, hipStream_t st);
 
 int bmm3(const float* x, const float* R, int B, int N, float* out, hipStream_t st);
 

@@ -151,6 +151,16 @@ def max_finalize(pmax, pidx, B, sgn, scale, shift):
     return g, zstar, arg
 
 
+def argmax_rows(values: torch.Tensor) -> torch.Tensor:
+    """index of the first maximum along the last axis (np.argmax order), int32; any leading shape"""
+    require_gpu_tensor(values, "values", F32)
+    v = values.contiguous()
+    C_ = v.shape[-1]
+    out = torch.empty(v.shape[:-1], dtype=torch.int32, device=v.device)
+    check(lib().pn_argmax_rows(ptr(v), v.numel() // C_, C_, ptr(out), current_stream()), "pn_argmax_rows")
+    return out
+
+
 def farthest_point_sample(xyz: torch.Tensor, m: int, start_idx: int = 0, return_mindist: bool = False):
     """xyz (B,N,3) -> idx (B,m) int32 in selection order (spec: include/pointnet_hip.h, pn_fps)."""
     require_gpu_tensor(xyz, "xyz", F32)

@@ -703,6 +703,13 @@ class PointNet(torch.nn.Module):
 
     call = forward
 
+    def predict(self, pc):
+        """inference entry: ``(class index (B,), part index per point (B, N), R (B,3,3))`` -- the arg-max of the two softmax
+        outputs (first maximum, np.argmax order), taken on the device (pn_argmax_rows).  Indices are int32."""
+        from .. import ops
+        cls, seg, R = self._run_forward(pc, False, None)
+        return ops.argmax_rows(cls), ops.argmax_rows(seg), R
+
     def grad_bucket_boundary(self) -> int:
         """offset (floats) in ``grads_flat`` from which every slot is final after backward phase 1"""
         for n, s in self._weights.slots.items():

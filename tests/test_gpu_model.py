@@ -431,6 +431,12 @@ def test_inference_against_committed_golden_vectors(dev):
     assert safe.mean() > 0.9
     assert np.array_equal(seg.argmax(-1)[safe], gv["inf_seg"].argmax(-1)[safe])
     assert np.array_equal(cls.argmax(-1), gv["inf_cls"].argmax(-1))
+    # the inference entry (indices taken on the device by pn_argmax_rows): the same indices, int32
+    ci, si, R2 = m.predict(pc)
+    assert ci.dtype == torch.int32 and si.dtype == torch.int32 and tuple(si.shape) == seg.shape[:2]
+    assert np.array_equal(ci.cpu().numpy(), cls.argmax(-1)) and np.array_equal(si.cpu().numpy(), seg.argmax(-1))
+    assert np.array_equal(si.cpu().numpy()[safe], gv["inf_seg"].argmax(-1)[safe])
+    assert np.array_equal(R2.double().cpu().numpy(), R)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

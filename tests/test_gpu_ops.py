@@ -449,6 +449,19 @@ def test_dropout_masks_counter_based(dev):
 
 # ---------------------------------------------------------------------------------------------------------------------
 # classification loss, segmentation output layer, per-cloud matmul: the remaining SURVEY 8(b) exports
+@pytest.mark.parametrize("shape", [(32, 23), (4, 1000, 12), (1, 1), (70000, 3), (5, 300)])
+def test_argmax_rows_is_first_maximum(dev, shape):
+    ops = _ops()
+    g = torch.Generator().manual_seed(sum(shape))
+    v = torch.randint(0, 6, shape, generator=g).float()        # few distinct values: most rows hold ties
+    v[..., -1:] += (torch.rand(shape[:-1] + (1,), generator=g) > 0.5).float() * 7   # and some rows peak in the last column
+    got = ops.argmax_rows(v.to(dev))
+    assert got.dtype == torch.int32 and tuple(got.shape) == tuple(shape[:-1])
+    assert np.array_equal(got.cpu().numpy(), np.argmax(v.numpy(), axis=-1))
+    with pytest.raises(_lib().PointNetHipError):
+        ops.argmax_rows(v)                                      # CPU tensor: no CPU fallback
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("R,C_", [(32, 23), (5, 2), (70, 40), (32, 300)])
 def test_softmax_xent_matches_keras_restatement(dev, R, C_):

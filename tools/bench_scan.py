@@ -61,7 +61,7 @@ def main():
         idx = ops.farthest_point_sample(cent.unsqueeze(0).contiguous(), M)
         ev[2].record()
         cloud = cent[idx[0].long()].unsqueeze(0).contiguous()
-        cls, seg, R = model(cloud, training=False)
+        cls_idx, part_idx, R = model.predict(cloud)          # class index, per-point part indices (device-side arg-max), pose
         ev[3].record()
         torch.cuda.synchronize()
         if rep:
@@ -71,7 +71,7 @@ def main():
     out = {"workload": f"scan N={args.points} -> voxel {args.leaf} m ({V} voxels) -> FPS M={M} -> PointNet(vanilla) inference",
            **{k: float(np.median(v)) for k, v in times.items()},
            "fps_distance_updates_per_s": float(M * V / (np.median(times["fps_ms"]) * 1e-3)),
-           "class": int(cls.argmax(-1)[0])}
+           "class": int(cls_idx[0]), "part_histogram": torch.bincount(part_idx[0].long(), minlength=12).tolist()}
     if args.check:
         from oracle import sampling_oracle as SO
         rc, rn, _ = SO.voxel_downsample(xyz, leaf, origin)
