@@ -25,6 +25,14 @@ int normalize(const float* xyz, int B, int N, float* out, float* centroid, float
 int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st);
 int conv3_wgrad(const float* x3, const pn_operand* dz, int B, int N, int C, float* slabs, hipStream_t st);
 int slab_reduce(const float* slabs, int n_slabs, int per_group, long long elems, float* out, hipStream_t st);
+// several whole-range slab reductions (out_j = sum over the n_slabs_j slabs of job j, same summation order as slab_reduce) in one launch
+struct SlabJob {
+  const float* slabs;
+  float* out;
+  long long elems;
+  int n_slabs;
+};
+int slab_reduce_batch(const SlabJob* jobs, int n_jobs, hipStream_t st);
 int bn_finalize(const float* part, int n_tiles, int C, long long count, const float* gamma, const float* beta, float* mm,
                 float* mv, float momentum, float eps, int use_batch, int update, float* mean, float* invstd, float* scale,
                 float* shift, hipStream_t st);

@@ -153,6 +153,8 @@ struct WS {
   float *Weff1, *dWeff1, *X64, *dX64, *tmpA12, *gb, *dgb, *dGseg, *dGcls;
   float *cls_logits, *cls_dlogits, *seg_dlogits, *seg_part, *dense_part, *slabs, *slabs_main, *bpart, *s5slab, *R3eye, *regpart;
   size_t slab_floats, slab_main_floats;
+  float* slab_pool;          // slabs of the parameter-gradient jobs whose reduction is deferred to the end of the (phase of the) pass
+  size_t slab_pool_floats;
   unsigned* dcount;
 };
 
@@ -294,8 +296,8 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
   w.dcount = A.get<unsigned>("dcount", DENSE_MAX_COUNTERS);                 // their in-launch arrival counters
   w.R3eye = A.get<float>("R3eye", (size_t)B * 9);
   w.regpart = A.get<float>("regpart", (size_t)2 * B);
-  w.slab_floats = w.slab_main_floats = 0;
-  w.slabs = w.slabs_main = nullptr;
+  w.slab_floats = w.slab_main_floats = w.slab_pool_floats = 0;
+  w.slabs = w.slabs_main = w.slab_pool = nullptr;
   if (training) {
     w.dWeff1 = A.get<float>("dWeff1", (size_t)B * 3 * 64);
     w.dX64 = A.get<float>("dX64", (size_t)M * 64);
@@ -329,6 +331,12 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
     if (rf > mf) mf = rf;
     w.slab_main_floats = mf;
     w.slabs_main = A.get<float>("slabs_main", mf);
+    // one region per deferred job (Run::pool_take): every per-point layer whose kernel gradient nobody reads before the optimizer
+    const int pool_shapes[][2] = {{64, 128}, {64, 64}, {64, 128}, {64, 64}, {64, 64}, {64, 128}, {64, 512}, {512, 256}, {256, 128}, {128, 128}};
+    size_t pf = 2 * (c3f + 64);                            // the two Cin = 3 layers
+    for (auto& s : pool_shapes) pf += wgrad_slab_floats(B, N, s[0], s[1]) + 64;
+    w.slab_pool_floats = pf;
+    w.slab_pool = A.get<float>("slab_pool", pf);
   }
 }
 
@@ -353,6 +361,24 @@ struct Run {
   int n_flush = 0;
   bool on_aux = false;
   float* cur_slabs() const { return on_aux || !aux ? w.slabs : w.slabs_main; }
+  // Deferred slab reductions (slab_reduce_batch): a job keeps its slabs in a region of its own until flush_jobs().  Not with an
+  // auxiliary stream (its launches are already off the main chain), and PN_SLAB_DEFER=0 restores one reduction per layer.
+  std::vector<SlabJob> jobs;
+  size_t pool_used = 0;
+  float* pool_take(size_t floats) {
+    static const bool on = !(getenv("PN_SLAB_DEFER") && atoi(getenv("PN_SLAB_DEFER")) == 0);
+    floats = (floats + 63) & ~(size_t)63;
+    if (!on || aux || !w.slab_pool || pool_used + floats > w.slab_pool_floats) return nullptr;
+    float* r = w.slab_pool + pool_used;
+    pool_used += floats;
+    return r;
+  }
+  int flush_jobs() {
+    if (jobs.empty()) return PN_OK;
+    const int rc = slab_reduce_batch(jobs.data(), (int)jobs.size(), st);
+    jobs.clear();
+    return rc;
+  }
 
   static hipEvent_t pooled_event(int i) {
     static thread_local std::vector<hipEvent_t> pool;
@@ -555,16 +581,34 @@ struct Run {
   }
 
   // ---------------- backward pieces ----------------
-  int wgrad_to(const pn_operand& a, const pn_operand& b, int Ci, int Cj, float* out, bool per_cloud) {
-    return wgrad_general(a, b, B, N, Ci, Cj, out, per_cloud, prec);
+  int wgrad_to(const pn_operand& a, const pn_operand& b, int Ci, int Cj, float* out, bool per_cloud, bool deferrable = false) {
+    return wgrad_general(a, b, B, N, Ci, Cj, out, per_cloud, prec, false, deferrable);
+  }
+  // parameter gradient of a Cin = 3 layer from T row-tile slabs
+  int wgrad3_to(const pn_operand& dz, float* out) {
+    float* sl = pool_take((size_t)T * 3 * 64);
+    if (sl) {
+      PN_TRY(conv3_wgrad(w.pcn, &dz, B, N, 64, sl, st));
+      jobs.push_back(SlabJob{sl, out, 3 * 64, T});
+      return PN_OK;
+    }
+    PN_TRY(conv3_wgrad(w.pcn, &dz, B, N, 64, cur_slabs(), st));
+    return slab_reduce(cur_slabs(), T, T, 3 * 64, out, st);
   }
   // colsum: `out` receives Ci*Cj products followed by Ci column sums of operand a (Gram matrix + a1 in one pass over the rows)
   int wgrad_general(const pn_operand& a, const pn_operand& b, int Bq, int Nq, int Ci, int Cj, float* out, bool per_cloud, int pr,
-                    bool colsum = false) {
+                    bool colsum = false, bool deferrable = false) {
     int spc;
     const int rows = (int)wgrad_slab_rows(Bq, Nq, Ci, Cj, &spc);
-    float* sl = cur_slabs();
     const size_t elems = (size_t)Ci * Cj + (colsum ? Ci : 0);
+    if (deferrable && !per_cloud) {
+      if (float* ps = pool_take((size_t)Bq * spc * elems)) {
+        PN_TRY(conv_wgrad(&a, &b, Bq, Nq, Ci, Cj, rows, ps, pr, st, colsum ? 1 : 0));
+        jobs.push_back(SlabJob{ps, out, (long long)elems, Bq * spc});
+        return PN_OK;
+      }
+    }
+    float* sl = cur_slabs();
     if ((size_t)Bq * spc * elems > (sl == w.slabs ? w.slab_floats : w.slab_main_floats)) {
       set_error("wgrad: slab scratch too small");
       return PN_ERR_WORKSPACE;
@@ -584,7 +628,7 @@ struct Run {
     if (tr(rc.block) && G) {
       float* out = gr(rc.kernel);
       const int ci = rc.cin, cj = rc.cout;
-      PN_TRY(side([=] { return wgrad_to(prev_act, dz, ci, cj, out, false); }));
+      PN_TRY(side([=] { return wgrad_to(prev_act, dz, ci, cj, out, false, true); }));
       PN_TRY(flush());
     }
     return conv_bwd_data(&dz, p(rc.kernel), 0, B, N, rc.cout, rc.cin, nullptr, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st);
@@ -665,13 +709,10 @@ struct Run {
     if (wg) {
       float* out = gr(r.c1.kernel);
       if (r.K == 3) {
-        PN_TRY(side([=] {
-          PN_TRY(conv3_wgrad(w.pcn, &dz1, B, N, 64, cur_slabs(), st));
-          return slab_reduce(cur_slabs(), T, T, 3 * 64, out, st);
-        }));
+        PN_TRY(side([=] { return wgrad3_to(dz1, out); }));
       } else {
         const pn_operand xin = *x;
-        PN_TRY(side([=] { return wgrad_to(xin, dz1, 64, 64, out, false); }));
+        PN_TRY(side([=] { return wgrad_to(xin, dz1, 64, 64, out, false, true); }));
       }
       PN_TRY(flush());
     }
@@ -679,6 +720,11 @@ struct Run {
   }
 
   int backward(const float* d_cls, const float* d_seg, const float* d_R) {
+    const int rc = backward_body(d_cls, d_seg, d_R);
+    if (rc != PN_OK) return rc;
+    return flush_jobs();                       // every deferred parameter gradient of this pass (or phase of it) is final after this
+  }
+  int backward_body(const float* d_cls, const float* d_seg, const float* d_R) {
     if (!G) {
       set_error("pn_model_backward: grads buffer is NULL");
       return PN_ERR_INVALID_ARGUMENT;
@@ -707,7 +753,8 @@ struct Run {
       PN_TRY(seg_out_bwd(&a4, p(L.s5.kernel), w.seg_dlogits, B, N, 128, d.cseg, w.s4.dy, w.bpart, w.s5slab, st));
       if (tr(BLK_S5)) {
         PN_TRY(side([=] {
-          PN_TRY(slab_reduce(w.s5slab, T, T, (long long)128 * d.cseg, gr(L.s5.kernel), st));
+          if (!aux) jobs.push_back(SlabJob{w.s5slab, gr(L.s5.kernel), (long long)128 * d.cseg, T});     // s5slab is this job's own region
+          else PN_TRY(slab_reduce(w.s5slab, T, T, (long long)128 * d.cseg, gr(L.s5.kernel), st));
           // bias gradient = column sums of dlogits: the forward's per-block partials already hold them when it produced dlogits itself
           if (!d_seg) return sum_partials(w.seg_part + 2, (int)cdivll(M, seg_out_part_rows()), seg_out_part_stride(), d.cseg, gr(L.s5.bias), st);
           return sum_partials(w.seg_dlogits, (int)M, d.cseg, d.cseg, gr(L.s5.bias), st);
@@ -722,7 +769,7 @@ struct Run {
       PN_TRY(cloud_bias_grad(w.bpart, w.s1.part, B, tpc, N, 512, w.s1.ca, w.s1.cb, w.s1.cc, w.dgb, st));
       if (tr(BLK_S1)) {
         PN_TRY(side([=] {
-          PN_TRY(wgrad_to(x64, dz1, 64, 512, gr(L.s1.kernel), false));
+          PN_TRY(wgrad_to(x64, dz1, 64, 512, gr(L.s1.kernel), false, true));
           return dense_wgrad(w.mm23.g, 1024, w.dgb, B, 1024, 512, gr(L.s1.kernel) + 64 * 512, st);
         }));
         PN_TRY(flush());
@@ -755,7 +802,7 @@ struct Run {
       PN_TRY(bn_bwd_fin(w.m21, L.m21, w.bpart));
       const pn_operand dz21 = dzop(w.m21);
       if (tr(BLK_M21)) {
-        PN_TRY(side([=] { return wgrad_to(x64, dz21, 64, 64, gr(L.m21.kernel), false); }));
+        PN_TRY(side([=] { return wgrad_to(x64, dz21, 64, 64, gr(L.m21.kernel), false, true); }));
         PN_TRY(flush());
       }
       if (d.vanilla) {
@@ -789,11 +836,11 @@ struct Run {
     PN_TRY(bwd_step(w.m12, L.m12, w.m11, lazy(w.m11)));
     PN_TRY(bn_bwd_fin(w.m11, L.m11, w.bpart));
     const pn_operand dz11 = dzop(w.m11);
-    PN_TRY(conv3_wgrad(w.pcn, &dz11, B, N, 64, cur_slabs(), st));
     if (d.vanilla) {
-      if (tr(BLK_M11)) PN_TRY(slab_reduce(cur_slabs(), T, T, 3 * 64, gr(L.m11.kernel), st));
+      if (tr(BLK_M11)) PN_TRY(wgrad3_to(dz11, gr(L.m11.kernel)));
       return PN_OK;
     }
+    PN_TRY(conv3_wgrad(w.pcn, &dz11, B, N, 64, cur_slabs(), st));
     PN_TRY(slab_reduce(cur_slabs(), T, tpc, 3 * 64, w.dWeff1, st));
     PN_TRY(fold3_bwd(w.dWeff1, w.iT.R, p(L.m11.kernel), B, 64, w.iT.dR, tr(BLK_M11) ? gr(L.m11.kernel) : nullptr, st));
     // ---- input transform ----

@@ -1,5 +1,7 @@
 // Bandwidth-bound per-point kernels and the small finalisers between contractions (gfx950).
+#include <cstring>
 #include "pn_common.h"
+#include "pn_internal.h"
 
 namespace pn {
 
@@ -167,12 +169,10 @@ int conv3_wgrad(const float* x3, const pn_operand* dz, int B, int N, int C, floa
 // ------------------------------------------------------------------------------------------------------
 // block = 32 consecutive elements x 8 partitions of the slab range; each partition is summed with 4 independent
 // accumulators, partitions are combined in a fixed order -> bitwise reproducible
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int per_group, long long elems,
-                                                          float* __restrict__ out) {
-  __shared__ float red[8][32];
+__device__ __forceinline__ void slab_reduce_block(const float* __restrict__ slabs, int per_group, long long elems, float* __restrict__ out,
+                                                  long long bx, int grp, float (*red)[32]) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const long long e = (long long)blockIdx.x * 32 + tx;
-  const int grp = blockIdx.y;
+  const long long e = bx * 32 + tx;
   float acc = 0.f;
   if (e < elems) {
     const float* s = slabs + (long long)grp * per_group * elems + e;
@@ -192,12 +192,58 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
     out[(long long)grp * elems + e] = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
 }
 
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int per_group, long long elems,
+                                                          float* __restrict__ out) {
+  __shared__ float red[8][32];
+  slab_reduce_block(slabs, per_group, elems, out, blockIdx.x, blockIdx.y, red);
+}
+
+// The parameter gradients of a backward pass are read by nobody before the optimizer, so their slab reductions wait and go out
+// together: one launch instead of one per layer (every dependent launch costs >= 4.5 us on this stack).
+constexpr int SLAB_BATCH_MAX = 12;
+struct SlabBatch {
+  const float* slabs[SLAB_BATCH_MAX];
+  float* out[SLAB_BATCH_MAX];
+  long long elems[SLAB_BATCH_MAX];
+  int n_slabs[SLAB_BATCH_MAX];
+  int blk_end[SLAB_BATCH_MAX];      // exclusive prefix of 32-element blocks
+  int n_jobs;
+};
+__global__ __launch_bounds__(256) void slab_reduce_batch_kernel(const SlabBatch jb) {
+  __shared__ float red[8][32];
+  const int bx = blockIdx.x;
+  int j = 0;
+  while (j + 1 < jb.n_jobs && bx >= jb.blk_end[j]) ++j;          // block-uniform
+  const int first = j ? jb.blk_end[j - 1] : 0;
+  slab_reduce_block(jb.slabs[j], jb.n_slabs[j], jb.elems[j], jb.out[j], bx - first, 0, red);
+}
+
 int slab_reduce(const float* slabs, int n_slabs, int per_group, long long elems, float* out, hipStream_t st) {
   PN_CHECK_ARG(slabs && out, "pn_slab_reduce: null pointer");
   PN_CHECK_ARG(n_slabs > 0 && per_group > 0 && n_slabs % per_group == 0 && elems > 0, "pn_slab_reduce: bad sizes");
   hipLaunchKernelGGL(slab_reduce_kernel, dim3((unsigned)cdivll(elems, 32), n_slabs / per_group), dim3(256), 0, st, slabs,
                      per_group, elems, out);
   PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+int slab_reduce_batch(const SlabJob* jobs, int n_jobs, hipStream_t st) {
+  for (int j0 = 0; j0 < n_jobs; j0 += SLAB_BATCH_MAX) {
+    SlabBatch jb;
+    memset(&jb, 0, sizeof(jb));
+    jb.n_jobs = (n_jobs - j0) < SLAB_BATCH_MAX ? (n_jobs - j0) : SLAB_BATCH_MAX;
+    long long blocks = 0;
+    for (int j = 0; j < jb.n_jobs; ++j) {
+      const SlabJob& q = jobs[j0 + j];
+      PN_CHECK_ARG(q.slabs && q.out && q.n_slabs > 0 && q.elems > 0, "slab_reduce_batch: bad job %d", j0 + j);
+      jb.slabs[j] = q.slabs; jb.out[j] = q.out; jb.elems[j] = q.elems; jb.n_slabs[j] = q.n_slabs;
+      blocks += cdivll(q.elems, 32);
+      PN_CHECK_ARG(blocks < (1ll << 30), "slab_reduce_batch: too many elements");
+      jb.blk_end[j] = (int)blocks;
+    }
+    hipLaunchKernelGGL(slab_reduce_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, jb);
+    PN_CHECK_LAUNCH();
+  }
   return PN_OK;
 }
 
