@@ -335,6 +335,11 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
     const int pool_shapes[][2] = {{64, 128}, {64, 64}, {64, 128}, {64, 64}, {64, 64}, {64, 128}, {64, 512}, {512, 256}, {256, 128}, {128, 128}};
     size_t pf = 2 * (c3f + 64);                            // the two Cin = 3 layers
     for (auto& s : pool_shapes) pf += wgrad_slab_floats(B, N, s[0], s[1]) + 64;
+    {                                                      // + the three Gram matrices (A^T A and the column sums) of the max-pooled layers
+      int spc_;
+      wgrad_slab_rows(B, N, 128, 128, &spc_);
+      pf += 3 * (wgrad_slab_floats(B, N, 128, 128) + (size_t)B * spc_ * 128 + 64);
+    }
     w.slab_pool_floats = pf;
     w.slab_pool = A.get<float>("slab_pool", pf);
   }
@@ -364,6 +369,8 @@ struct Run {
   // Deferred slab reductions (slab_reduce_batch): a job keeps its slabs in a region of its own until flush_jobs().  Not with an
   // auxiliary stream (its launches are already off the main chain), and PN_SLAB_DEFER=0 restores one reduction per layer.
   std::vector<SlabJob> jobs;
+  std::vector<std::function<int()>> after_jobs;      // launches that consume a deferred reduction (and feed only the optimizer)
+  bool last_deferred = false;
   size_t pool_used = 0;
   float* pool_take(size_t floats) {
     static const bool on = !(getenv("PN_SLAB_DEFER") && atoi(getenv("PN_SLAB_DEFER")) == 0);
@@ -374,9 +381,13 @@ struct Run {
     return r;
   }
   int flush_jobs() {
-    if (jobs.empty()) return PN_OK;
-    const int rc = slab_reduce_batch(jobs.data(), (int)jobs.size(), st);
+    int rc = jobs.empty() ? PN_OK : slab_reduce_batch(jobs.data(), (int)jobs.size(), st);
     jobs.clear();
+    for (auto& f : after_jobs) {
+      if (rc != PN_OK) break;
+      rc = f();
+    }
+    after_jobs.clear();
     return rc;
   }
 
@@ -601,10 +612,12 @@ struct Run {
     int spc;
     const int rows = (int)wgrad_slab_rows(Bq, Nq, Ci, Cj, &spc);
     const size_t elems = (size_t)Ci * Cj + (colsum ? Ci : 0);
+    last_deferred = false;
     if (deferrable && !per_cloud) {
       if (float* ps = pool_take((size_t)Bq * spc * elems)) {
         PN_TRY(conv_wgrad(&a, &b, Bq, Nq, Ci, Cj, rows, ps, pr, st, colsum ? 1 : 0));
         jobs.push_back(SlabJob{ps, out, (long long)elems, Bq * spc});
+        last_deferred = true;
         return PN_OK;
       }
     }
@@ -645,11 +658,17 @@ struct Run {
       const ML mm = m;
       float* dw = gr(r.kernel);
       const float* Wk = p(r.kernel);
+      // this whole branch feeds only dW: the Gram slabs are reduced with the other deferred jobs and the two consumers follow them
       PN_TRY(side([=] {
-        PN_TRY(wgrad_general(xop, xop, B, N, K, K, mm.gram, false, prec, true));   // Gram matrix and a1 = column sums together
-        const pn_operand gop = plain(mm.gram, K);
-        PN_TRY(conv_fwd(&gop, Wk, 0, 1, K, K, C, nullptr, mm.GW, nullptr, PN_PREC_BF16X3, st));
-        return maxbwd_dw(&xop, mm.arg, mm.hs, B, N, K, C, mm.a1, mm.f, mm.e, mm.GW, dw, st);
+        PN_TRY(wgrad_general(xop, xop, B, N, K, K, mm.gram, false, prec, true, true));   // Gram matrix and a1 = column sums together
+        auto rest = [=] {
+          const pn_operand gop = plain(mm.gram, K);
+          PN_TRY(conv_fwd(&gop, Wk, 0, 1, K, K, C, nullptr, mm.GW, nullptr, PN_PREC_BF16X3, st));
+          return maxbwd_dw(&xop, mm.arg, mm.hs, B, N, K, C, mm.a1, mm.f, mm.e, mm.GW, dw, st);
+        };
+        if (!last_deferred) return rest();
+        after_jobs.push_back(rest);
+        return (int)PN_OK;
       }));
       PN_TRY(flush());
     }
