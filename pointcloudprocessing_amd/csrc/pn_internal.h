@@ -82,6 +82,18 @@ int maxbwd_prep(const float* dg, const float* dg2, const float* g, const float* 
                 const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege, float* f, float* dgamma,
                 float* dbeta, const float* W, int K, float* Wt, float* We, hipStream_t st);
 int colsum_lazy(const pn_operand* x, int B, int N, int C, float* part, hipStream_t st);
+// dW of a max-pooled layer (see pn_maxbwd.hip); the layers of one pass can share a launch
+struct DwJob {
+  pn_operand x;
+  const int* arg;
+  const float* hs;
+  const float* a1;
+  const float* f;
+  const float* e;
+  const float* GW;
+  float* dW;
+};
+int maxbwd_dw_batch(const DwJob* jobs, int n_jobs, int B, int N, int K, int C, hipStream_t st);
 int maxbwd_dw(const pn_operand* x, const int* arg, const float* hs, int B, int N, int K, int C, const float* a1, const float* f,
               const float* e, const float* GW, float* dW, hipStream_t st);
 int maxbwd_q(const float* w, const float* f, int K, int C, float* q, hipStream_t st);

@@ -12,7 +12,9 @@
 // so only the K x K Gram matrix A^T A and two K-wide contractions are needed: 1/8 of the dense backward
 // FLOPs at K = 128, C = 1024.  The Gram matrix, (A^T A) W and W diag(e) W^T run on the MFMA engine
 // (pn_conv_wgrad / pn_conv_fwd / pn_conv_bwd_data); this file holds the small glue kernels.
+#include <cstring>
 #include "pn_common.h"
+#include "pn_internal.h"
 
 namespace pn {
 
@@ -120,14 +122,18 @@ __global__ __launch_bounds__(256) void colsum_lazy_kernel(const pn_operand x, in
 
 // dW[k][c] = sum_b A[row(b,c)][k]*hs[b,c] + a1[k]*f[c] - e[c]*GW[k][c]     block per channel c, thread per k.
 // The B (row, weight) pairs of the channel are staged in LDS first so the gathered rows can be loaded 8 at a time.
-__global__ __launch_bounds__(128) void maxbwd_dw_kernel(const pn_operand x, const int* __restrict__ arg, const float* __restrict__ hs,
-                                                        int B, int N, int K, int C, const float* __restrict__ a1,
-                                                        const float* __restrict__ f, const float* __restrict__ e,
-                                                        const float* __restrict__ GW, float* __restrict__ dW) {
+struct DwBatch {
+  DwJob job[3];
+};
+__global__ __launch_bounds__(128) void maxbwd_dw_kernel(const DwBatch jb, int B, int N, int K, int C) {
   __shared__ long long srow[128];
   __shared__ float sw[128];
+  const DwJob& J = jb.job[blockIdx.y];          // the max-pooled layers of one pass share a launch (grid.y = layer)
+  const pn_operand& x = J.x;
+  const int* __restrict__ arg = J.arg;
+  const float* __restrict__ hs = J.hs;
   const int c = blockIdx.x;
-  const float fc = f[c], ec = e[c];
+  const float fc = J.f[c], ec = J.e[c];
   float acc[2] = {0.f, 0.f};        // K <= 256
   for (int b0 = 0; b0 < B; b0 += 128) {
     const int nb = min(128, B - b0);
@@ -158,9 +164,9 @@ __global__ __launch_bounds__(128) void maxbwd_dw_kernel(const pn_operand x, cons
   for (int kk = 0; kk < 2; ++kk) {
     const int k = threadIdx.x + 128 * kk;
     if (k < K) {
-      float a = fmaf(a1[k], fc, acc[kk]);
-      a = fmaf(-ec, GW[(long long)k * C + c], a);
-      dW[(long long)k * C + c] = a;
+      float a = fmaf(J.a1[k], fc, acc[kk]);
+      a = fmaf(-ec, J.GW[(long long)k * C + c], a);
+      J.dW[(long long)k * C + c] = a;
     }
   }
 }
@@ -263,12 +269,28 @@ int colsum_lazy(const pn_operand* x, int B, int N, int C, float* part, hipStream
   return PN_OK;
 }
 
+int maxbwd_dw_batch(const DwJob* jobs, int n_jobs, int B, int N, int K, int C, hipStream_t st) {
+  PN_CHECK_ARG(K <= 256, "maxbwd_dw: K must be <= 256 (K=%d)", K);
+  for (int j0 = 0; j0 < n_jobs; j0 += 3) {
+    DwBatch jb;
+    memset(&jb, 0, sizeof(jb));
+    const int n = (n_jobs - j0) < 3 ? (n_jobs - j0) : 3;
+    for (int j = 0; j < n; ++j) {
+      const DwJob& q = jobs[j0 + j];
+      PN_CHECK_ARG(q.x.s1 && q.arg && q.hs && q.a1 && q.f && q.e && q.GW && q.dW, "maxbwd_dw: null pointer");
+      jb.job[j] = q;
+    }
+    hipLaunchKernelGGL(maxbwd_dw_kernel, dim3(C, n), dim3(128), 0, st, jb, B, N, K, C);
+    PN_CHECK_LAUNCH();
+  }
+  return PN_OK;
+}
+
 int maxbwd_dw(const pn_operand* x, const int* arg, const float* hs, int B, int N, int K, int C, const float* a1, const float* f,
               const float* e, const float* GW, float* dW, hipStream_t st) {
-  PN_CHECK_ARG(x && x->s1 && arg && hs && a1 && f && e && GW && dW, "maxbwd_dw: null pointer");
-  hipLaunchKernelGGL(maxbwd_dw_kernel, dim3(C), dim3(128), 0, st, *x, arg, hs, B, N, K, C, a1, f, e, GW, dW);
-  PN_CHECK_LAUNCH();
-  return PN_OK;
+  PN_CHECK_ARG(x != nullptr, "maxbwd_dw: null pointer");
+  const DwJob j{*x, arg, hs, a1, f, e, GW, dW};
+  return maxbwd_dw_batch(&j, 1, B, N, K, C, st);
 }
 
 int maxbwd_q(const float* w, const float* f, int K, int C, float* q, hipStream_t st) {

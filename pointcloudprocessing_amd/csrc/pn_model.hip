@@ -370,6 +370,8 @@ struct Run {
   // auxiliary stream (its launches are already off the main chain), and PN_SLAB_DEFER=0 restores one reduction per layer.
   std::vector<SlabJob> jobs;
   std::vector<std::function<int()>> after_jobs;      // launches that consume a deferred reduction (and feed only the optimizer)
+  std::vector<DwJob> dw_jobs;                        // ... and the dW kernels of the max-pooled layers behind those, one launch
+  int dw_K = 0, dw_C = 0;
   bool last_deferred = false;
   size_t pool_used = 0;
   float* pool_take(size_t floats) {
@@ -388,6 +390,8 @@ struct Run {
       rc = f();
     }
     after_jobs.clear();
+    if (rc == PN_OK && !dw_jobs.empty()) rc = maxbwd_dw_batch(dw_jobs.data(), (int)dw_jobs.size(), B, N, dw_K, dw_C, st);
+    dw_jobs.clear();
     return rc;
   }
 
@@ -667,7 +671,16 @@ struct Run {
           return maxbwd_dw(&xop, mm.arg, mm.hs, B, N, K, C, mm.a1, mm.f, mm.e, mm.GW, dw, st);
         };
         if (!last_deferred) return rest();
-        after_jobs.push_back(rest);
+        if (!dw_jobs.empty() && (dw_K != K || dw_C != C)) {     // another shape than the batch so far: keep this layer's own launch
+          after_jobs.push_back(rest);
+          return (int)PN_OK;
+        }
+        after_jobs.push_back([=] {
+          const pn_operand gop = plain(mm.gram, K);
+          return conv_fwd(&gop, Wk, 0, 1, K, K, C, nullptr, mm.GW, nullptr, PN_PREC_BF16X3, st);
+        });
+        dw_K = K; dw_C = C;
+        dw_jobs.push_back(DwJob{xop, mm.arg, mm.hs, mm.a1, mm.f, mm.e, mm.GW, dw});
         return (int)PN_OK;
       }));
       PN_TRY(flush());
