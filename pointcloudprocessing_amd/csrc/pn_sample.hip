@@ -15,7 +15,8 @@ int zero_fill(float* p, long long n, hipStream_t st);   // pn_optim.hip
 // memory at all: the winner's coordinates travel through LDS.  Measured per round (MI355X): ~0.75 us of
 // reductions / barriers / LDS round trips + the distance update (5.75 VALU instructions per point):
 // 0.76 us at N <= 1024 (4 waves), 0.93 us at 4096, 1.56 us at 16384 (16 waves), 1.77 us at 21504 (12 waves x 28
-// points).  512-thread variants with 32 / 42 points per thread measured the same or slower.  Clouds above 21504
+// points).  512-thread variants with 32 / 42 points per thread measured the same or slower, and so did a fast path
+// for "one wave holds the maximum" (winner published in a single 16-byte LDS slot: +0.07 us from counting candidates).  Clouds above 21504
 // points are split over `bpc` co-resident blocks that exchange one 8-byte {distance, index, round-tag} granule
 // per round through device-scope relaxed atomics (a single naturally aligned 8-byte sc1 store/load needs no
 // other ordering: MI355X_MICROARCH.md, "R2's granule").  Every spin is bounded.
