@@ -20,7 +20,9 @@
 // MFMA lane maps used (cdna_hip_programming.md section 3): v_mfma_f32_32x32x16_bf16, lane l: r = l&31, h = l>>5
 //   A fragment element e (0..7) = A[row r][k = 8h+e];   B fragment element e = B[k = 8h+e][col r]
 //   C/D register g (0..15)      = D[row (g&3) + 8*(g>>2) + 4h][col r]
+#include <vector>
 #include "pn_common.h"
+#include "pn_internal.h"
 
 namespace pn {
 
@@ -301,6 +303,119 @@ __device__ __forceinline__ void epi_store_block(const f32x16& acc, const GemmArg
   }
 }
 
+// ---- one weight-gradient tile: slab bx of output tile (by, bz) ----------------------------------------------
+template <int BM, int BN, int NS, bool A2, bool B2>
+__device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, const int by, const int bz, unsigned char* lds_raw) {
+  constexpr int BK = (NS == 3) ? 32 : 64;
+  constexpr int PITCH = Geo<BK>::PITCH;
+  constexpr int MT = BM / 64, NT = BN / 64;
+  constexpr int WTM = BM / 2, WTN = BN / 2;
+  constexpr int TILE_A = BM * PITCH, TILE_B = BN * PITCH;
+  __bf16* Ahi = reinterpret_cast<__bf16*>(lds_raw);
+  __bf16* Bhi = Ahi + TILE_A;
+  __bf16* Alo = (NS == 3) ? (Bhi + TILE_B) : Ahi;
+  __bf16* Blo = (NS == 3) ? (Alo + TILE_A) : Bhi;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int wrow0 = wm * WTM, wcol0 = wn * WTN;
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
+  const int cloud = bx / g.tiles_per_cloud, tin = bx - cloud * g.tiles_per_cloud;
+  const int i0 = by * BM, j0 = bz * BN;
+  const bool want_cs = g.colsum != 0 && bz == 0;     // block-uniform
+  float cs = 0.f;
+  const int rbeg = tin * g.K;
+  const int rend = min(g.N, rbeg + g.K);
+  // the loads of chunk i+1 are issued before the MFMAs of chunk i and converted after them: one register set, global latency
+  // hidden behind the matrix cores
+  TrnStage<BM, BK, A2> sa;
+  TrnStage<BN, BK, B2> sb;
+  if (rbeg < rend) {
+    const long long rowbase = (long long)cloud * g.N + rbeg;
+    const int nk = min(BK, rend - rbeg);
+    sa.issue(g.a, rowbase * g.a.ld + i0, nk, g.Ci - i0, tid);
+    sb.issue(g.b, rowbase * g.b.ld + j0, nk, g.C - j0, tid);
+  }
+  for (int r0 = rbeg; r0 < rend; r0 += BK) {
+    const int nk = min(BK, rend - r0);
+    sa.pin();
+    cs += sa.template finish<NS>(Ahi, Alo, g.a, nk, g.Ci - i0, i0, tid, want_cs);
+    sb.pin();
+    sb.template finish<NS>(Bhi, Blo, g.b, nk, g.C - j0, j0, tid);
+    __syncthreads();
+    if (r0 + BK < rend) {
+      const long long rowbase = (long long)cloud * g.N + r0 + BK;
+      const int nk2 = min(BK, rend - (r0 + BK));
+      sa.issue(g.a, rowbase * g.a.ld + i0, nk2, g.Ci - i0, tid);
+      sb.issue(g.b, rowbase * g.b.ld + j0, nk2, g.C - j0, tid);
+    }
+    mma_chunk<MT, NT, BK, NS>(acc, Ahi, Alo, Bhi, Blo, wrow0, wcol0, lane);
+    __syncthreads();
+  }
+  // slab store
+  const long long slab_stride = (long long)g.Ci * g.C + (g.colsum ? g.Ci : 0);
+  float* slab = g.out + (long long)bx * slab_stride;
+  if (want_cs) {
+    // the 256 / BM threads that share a channel combine through LDS (the tiles are dead after the last barrier), fixed order
+    constexpr int TPGA = 256 / BM;
+    float* red = reinterpret_cast<float*>(lds_raw);
+    red[(tid / BM) * BM + (tid % BM)] = cs;
+    __syncthreads();
+    if (tid < BM && i0 + tid < g.Ci) {
+      float t = red[tid];
+#pragma unroll
+      for (int q = 1; q < TPGA; ++q) t += red[q * BM + tid];
+      slab[(long long)g.Ci * g.C + i0 + tid] = t;
+    }
+  }
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int m = 0; m < MT; ++m)
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int j = j0 + wcol0 + n * 32 + r;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = i0 + wrow0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (i < g.Ci && j < g.C) slab[(long long)i * g.C + j] = acc[m][n][e];
+      }
+    }
+}
+
+template <int BM, int BN, int NS>
+struct GemmLds {
+  static constexpr int BK = (NS == 3) ? 32 : 64;
+  static constexpr int TILES = (BM + BN) * Geo<BK>::PITCH * ((NS == 3) ? 2 : 1) * 2;
+  static constexpr int EPI = 2 * BN * 4 * 4;
+  static constexpr int BYTES = TILES > EPI ? TILES : EPI;
+};
+
+// Several weight-gradient jobs of one tile shape in one launch (the parameter gradients of a backward pass wait for the end
+// of the pass, pn_model.hip): the linear block index walks job -> (bz, by, slab).
+constexpr int WGRAD_BATCH_MAX = 4;
+struct WgradBatch {
+  GemmArgs g[WGRAD_BATCH_MAX];
+  int blk_end[WGRAD_BATCH_MAX];
+  int nslab[WGRAD_BATCH_MAX];
+  int ny[WGRAD_BATCH_MAX];
+  int n;
+};
+template <int BM, int BN, int NS, bool B2>
+__global__ __launch_bounds__(256) void wgrad_batch_kernel(const WgradBatch wb) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[GemmLds<BM, BN, NS>::BYTES];
+  int j = 0;
+  while (j + 1 < wb.n && (int)blockIdx.x >= wb.blk_end[j]) ++j;      // block-uniform
+  const int local = (int)blockIdx.x - (j ? wb.blk_end[j - 1] : 0);
+  const int nslab = wb.nslab[j], ny = wb.ny[j];
+  const int bx = local % nslab, rest = local / nslab;
+  wgrad_tile<BM, BN, NS, false, B2>(wb.g[j], bx, rest % ny, rest / ny, lds_raw);
+}
+
 // ---- the kernel ----------------------------------------------------------------------------------------
 // 256 threads = 4 waves arranged 2 (rows) x 2 (cols); wave tile (BM/2) x (BN/2) = MT x NT MFMA tiles.
 template <int BM, int BN, int NS, int MODE, bool A2, bool B2, int EPI, bool ADD = false, bool MASK = false>
@@ -336,65 +451,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   const int cloud = bx / g.tiles_per_cloud, tin = bx - cloud * g.tiles_per_cloud;
 
   if (MODE == MODE_WGRAD) {
-    const int i0 = blockIdx.y * BM, j0 = blockIdx.z * BN;
-    const bool want_cs = g.colsum != 0 && blockIdx.z == 0;     // block-uniform
-    float cs = 0.f;
-    const int rbeg = tin * g.K;
-    const int rend = min(g.N, rbeg + g.K);
-    // the loads of chunk i+1 are issued before the MFMAs of chunk i and converted after them: one register set, global latency
-    // hidden behind the matrix cores
-    TrnStage<BM, BK, A2> sa;
-    TrnStage<BN, BK, B2> sb;
-    if (rbeg < rend) {
-      const long long rowbase = (long long)cloud * g.N + rbeg;
-      const int nk = min(BK, rend - rbeg);
-      sa.issue(g.a, rowbase * g.a.ld + i0, nk, g.Ci - i0, tid);
-      sb.issue(g.b, rowbase * g.b.ld + j0, nk, g.C - j0, tid);
-    }
-    for (int r0 = rbeg; r0 < rend; r0 += BK) {
-      const int nk = min(BK, rend - r0);
-      sa.pin();
-      cs += sa.template finish<NS>(Ahi, Alo, g.a, nk, g.Ci - i0, i0, tid, want_cs);
-      sb.pin();
-      sb.template finish<NS>(Bhi, Blo, g.b, nk, g.C - j0, j0, tid);
-      __syncthreads();
-      if (r0 + BK < rend) {
-        const long long rowbase = (long long)cloud * g.N + r0 + BK;
-        const int nk2 = min(BK, rend - (r0 + BK));
-        sa.issue(g.a, rowbase * g.a.ld + i0, nk2, g.Ci - i0, tid);
-        sb.issue(g.b, rowbase * g.b.ld + j0, nk2, g.C - j0, tid);
-      }
-      mma_chunk<MT, NT, BK, NS>(acc, Ahi, Alo, Bhi, Blo, wrow0, wcol0, lane);
-      __syncthreads();
-    }
-    // slab store
-    const long long slab_stride = (long long)g.Ci * g.C + (g.colsum ? g.Ci : 0);
-    float* slab = g.out + (long long)bx * slab_stride;
-    if (want_cs) {
-      // the 256 / BM threads that share a channel combine through LDS (the tiles are dead after the last barrier), fixed order
-      constexpr int TPGA = 256 / BM;
-      float* red = reinterpret_cast<float*>(lds_raw);
-      red[(tid / BM) * BM + (tid % BM)] = cs;
-      __syncthreads();
-      if (tid < BM && i0 + tid < g.Ci) {
-        float t = red[tid];
-#pragma unroll
-        for (int q = 1; q < TPGA; ++q) t += red[q * BM + tid];
-        slab[(long long)g.Ci * g.C + i0 + tid] = t;
-      }
-    }
-    const int r = lane & 31, h = lane >> 5;
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        const int j = j0 + wcol0 + n * 32 + r;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int i = i0 + wrow0 + m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          if (i < g.Ci && j < g.C) slab[(long long)i * g.C + j] = acc[m][n][e];
-        }
-      }
+    wgrad_tile<BM, BN, NS, A2, B2>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds_raw);
     return;
   }
 
@@ -655,6 +712,76 @@ static int dispatch_wgrad(const GemmArgs& g, bool b2, int prec, dim3 grid, hipSt
   }
   if (b2) return launch<BM, BN, 1, MODE_WGRAD, false, true, EPI_SLAB>(g, grid, st);
   return launch<BM, BN, 1, MODE_WGRAD, false, false, EPI_SLAB>(g, grid, st);
+}
+
+static int wgrad_args(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, int Cj, int slab_rows, float* slabs, int prec,
+                      int colsum, GemmArgs& g) {
+  PN_TRY(check_operand(a, "pn_conv_wgrad.a"));
+  PN_TRY(check_operand(b, "pn_conv_wgrad.b"));
+  PN_CHECK_ARG(!a->s2, "pn_conv_wgrad: operand a has no second source");
+  PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_wgrad: B and N must be positive");
+  PN_CHECK_ARG(Ci >= 64 && Ci % 64 == 0 && Cj >= 64 && Cj % 64 == 0, "pn_conv_wgrad: Ci, Cj must be multiples of 64 (%d, %d)",
+               Ci, Cj);
+  PN_CHECK_ARG(slab_rows >= 64 && slab_rows % 64 == 0, "pn_conv_wgrad: slab_rows must be a multiple of 64");
+  PN_CHECK_ARG(a->ld >= Ci && b->ld >= Cj, "pn_conv_wgrad: ld too small");
+  PN_CHECK_ARG(slabs != nullptr, "pn_conv_wgrad: null slabs");
+  PN_CHECK_ARG(prec == PN_PREC_BF16 || prec == PN_PREC_BF16X3, "pn_conv_wgrad: bad prec %d", prec);
+  memset(&g, 0, sizeof(g));
+  g.a = *a; g.b = *b; g.B = B; g.N = N; g.K = slab_rows; g.C = Cj; g.Ci = Ci;
+  g.tiles_per_cloud = cdiv(N, slab_rows);
+  g.out = slabs; g.colsum = colsum;
+  return PN_OK;
+}
+
+template <int BM, int BN>
+static int launch_wgrad_batch(const WgradBatch& wb, bool b2, int prec, int blocks, hipStream_t st) {
+  if (prec == PN_PREC_BF16X3) {
+    if (b2) hipLaunchKernelGGL((wgrad_batch_kernel<BM, BN, 3, true>), dim3(blocks), dim3(256), 0, st, wb);
+    else hipLaunchKernelGGL((wgrad_batch_kernel<BM, BN, 3, false>), dim3(blocks), dim3(256), 0, st, wb);
+  } else {
+    if (b2) hipLaunchKernelGGL((wgrad_batch_kernel<BM, BN, 1, true>), dim3(blocks), dim3(256), 0, st, wb);
+    else hipLaunchKernelGGL((wgrad_batch_kernel<BM, BN, 1, false>), dim3(blocks), dim3(256), 0, st, wb);
+  }
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// jobs of the same tile shape / operand form / precision share a launch (up to WGRAD_BATCH_MAX each)
+int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st) {
+  std::vector<char> done(n > 0 ? n : 0, 0);
+  auto key = [&](const WgradDesc& q) {
+    const int shape = (q.Ci % 128 == 0 && q.Cj % 128 == 0) ? 0 : (q.Cj % 128 == 0 ? 1 : 2);
+    return shape * 8 + (q.b.s2 ? 4 : 0) + (q.prec == PN_PREC_BF16X3 ? 1 : 0);
+  };
+  for (int i = 0; i < n; ++i) {
+    if (done[i]) continue;
+    const int k = key(jobs[i]);
+    WgradBatch wb;
+    memset(&wb, 0, sizeof(wb));
+    long long blocks = 0;
+    for (int j = i; j < n && wb.n < WGRAD_BATCH_MAX; ++j) {
+      if (done[j] || key(jobs[j]) != k) continue;
+      const WgradDesc& q = jobs[j];
+      GemmArgs& g = wb.g[wb.n];
+      PN_TRY(wgrad_args(&q.a, &q.b, q.B, q.N, q.Ci, q.Cj, q.slab_rows, q.slabs, q.prec, q.colsum, g));
+      const int shape = k / 8;
+      const int bm = shape == 0 ? 128 : 64, bn = shape == 2 ? 64 : 128;
+      const int nslab = q.B * g.tiles_per_cloud, ny = q.Ci / bm, nz = q.Cj / bn;
+      blocks += (long long)nslab * ny * nz;
+      PN_CHECK_ARG(blocks < (1ll << 30), "pn_conv_wgrad: batch too large");
+      wb.nslab[wb.n] = nslab; wb.ny[wb.n] = ny; wb.blk_end[wb.n] = (int)blocks;
+      ++wb.n;
+      done[j] = 1;
+    }
+    const bool b2 = (k & 4) != 0;
+    const int prec = (k & 1) ? PN_PREC_BF16X3 : PN_PREC_BF16;
+    switch (k / 8) {
+      case 0: PN_TRY((launch_wgrad_batch<128, 128>(wb, b2, prec, (int)blocks, st))); break;
+      case 1: PN_TRY((launch_wgrad_batch<64, 128>(wb, b2, prec, (int)blocks, st))); break;
+      default: PN_TRY((launch_wgrad_batch<64, 64>(wb, b2, prec, (int)blocks, st))); break;
+    }
+  }
+  return PN_OK;
 }
 
 int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, int Cj, int slab_rows, float* slabs, int prec,

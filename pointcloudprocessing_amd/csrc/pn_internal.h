@@ -12,6 +12,14 @@ int conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C
 int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, int N, int K, int C, const float* addend,
                   const float* zmask, const float* msc, const float* msh, float* out, float* stat_partials, int prec,
                   hipStream_t st);
+// weight-gradient jobs whose launches are grouped by tile shape (pn_gemm.hip: conv_wgrad_batch)
+struct WgradDesc {
+  pn_operand a, b;
+  int B, N, Ci, Cj, slab_rows;
+  float* slabs;
+  int prec, colsum;
+};
+int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st);
 int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, int Cj, int slab_rows, float* slabs, int prec,
                hipStream_t st, int colsum = 0);   // colsum: every slab is followed by Ci floats = sum over its rows of operand a
 

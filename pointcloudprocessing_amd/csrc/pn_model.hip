@@ -369,6 +369,7 @@ struct Run {
   // Deferred slab reductions (slab_reduce_batch): a job keeps its slabs in a region of its own until flush_jobs().  Not with an
   // auxiliary stream (its launches are already off the main chain), and PN_SLAB_DEFER=0 restores one reduction per layer.
   std::vector<SlabJob> jobs;
+  std::vector<WgradDesc> wg_jobs;                    // their weight-gradient GEMMs, launched together by tile shape (conv_wgrad_batch)
   std::vector<std::function<int()>> after_jobs;      // launches that consume a deferred reduction (and feed only the optimizer)
   std::vector<DwJob> dw_jobs;                        // ... and the dW kernels of the max-pooled layers behind those, one launch
   int dw_K = 0, dw_C = 0;
@@ -383,7 +384,9 @@ struct Run {
     return r;
   }
   int flush_jobs() {
-    int rc = jobs.empty() ? PN_OK : slab_reduce_batch(jobs.data(), (int)jobs.size(), st);
+    int rc = wg_jobs.empty() ? PN_OK : conv_wgrad_batch(wg_jobs.data(), (int)wg_jobs.size(), st);
+    wg_jobs.clear();
+    if (rc == PN_OK && !jobs.empty()) rc = slab_reduce_batch(jobs.data(), (int)jobs.size(), st);
     jobs.clear();
     for (auto& f : after_jobs) {
       if (rc != PN_OK) break;
@@ -619,7 +622,9 @@ struct Run {
     last_deferred = false;
     if (deferrable && !per_cloud) {
       if (float* ps = pool_take((size_t)Bq * spc * elems)) {
-        PN_TRY(conv_wgrad(&a, &b, Bq, Nq, Ci, Cj, rows, ps, pr, st, colsum ? 1 : 0));
+        static const bool batch_gemm = !(getenv("PN_WGRAD_BATCH") && atoi(getenv("PN_WGRAD_BATCH")) == 0);
+        if (batch_gemm) wg_jobs.push_back(WgradDesc{a, b, Bq, Nq, Ci, Cj, rows, ps, pr, colsum ? 1 : 0});
+        else PN_TRY(conv_wgrad(&a, &b, Bq, Nq, Ci, Cj, rows, ps, pr, st, colsum ? 1 : 0));
         jobs.push_back(SlabJob{ps, out, (long long)elems, Bq * spc});
         last_deferred = true;
         return PN_OK;
