@@ -41,6 +41,8 @@ struct SlabJob {
   int n_slabs;
 };
 int slab_reduce_batch(const SlabJob* jobs, int n_jobs, hipStream_t st);
+int slab_reduce_q(const float* slabs, int n_slabs, long long elems, float* out, const float* w, const float* f, int K, int C, float* q,
+                  hipStream_t st);
 int bn_finalize(const float* part, int n_tiles, int C, long long count, const float* gamma, const float* beta, float* mm,
                 float* mv, float momentum, float eps, int use_batch, int update, float* mean, float* invstd, float* scale,
                 float* shift, hipStream_t st);

@@ -692,8 +692,19 @@ struct Run {
     }
     // Pm[k'][k] = sum_c (-e_c) W[k'][c] W[k][c]: the contraction runs over the 1024 channels, so it is laid out as a
     // weight-gradient problem over "rows" c (16 slabs of 64 channels -> 16 workgroups) instead of one 128x128 tile
-    PN_TRY(wgrad_general(plain(m.We, K), plain(m.Wt, K), 1, C, K, K, m.Pm, false, PN_PREC_BF16X3));
-    PN_TRY(maxbwd_q(p(r.kernel), m.f, K, C, m.q, st));
+    // ... and q = W f (needs only maxbwd_prep's f) rides in the launch that reduces those slabs
+    {
+      int spc;
+      const int rows = (int)wgrad_slab_rows(1, C, K, K, &spc);
+      float* sl = cur_slabs();
+      if ((size_t)spc * K * K > (sl == w.slabs ? w.slab_floats : w.slab_main_floats)) {
+        set_error("wgrad: slab scratch too small");
+        return PN_ERR_WORKSPACE;
+      }
+      const pn_operand we = plain(m.We, K), wt = plain(m.Wt, K);
+      PN_TRY(conv_wgrad(&we, &wt, 1, C, K, K, rows, sl, PN_PREC_BF16X3, st, 0));
+      PN_TRY(slab_reduce_q(sl, spc, (long long)K * K, m.Pm, p(r.kernel), m.f, K, C, m.q, st));
+    }
     PN_TRY(maxbwd_scatter(m.arg, m.hs, m.Wt, m.q, B, N, K, C, m.D, st));
     return conv_bwd_data(&xop, m.Pm, 0, B, N, K, K, m.D, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st);
   }

@@ -218,6 +218,35 @@ __global__ __launch_bounds__(256) void slab_reduce_batch_kernel(const SlabBatch 
   slab_reduce_block(jb.slabs[j], jb.n_slabs[j], jb.elems[j], jb.out[j], bx - first, 0, red);
 }
 
+// slab reduction + an independent tiny job of the max-pool backward in one launch: q[k] = sum_c f[c] * W[k][c], one wave per k
+// (the blocks behind the reduction's; same lane stride and wave sum as a stand-alone launch would use)
+__global__ __launch_bounds__(256) void slab_reduce_q_kernel(const float* __restrict__ slabs, int n_slabs, long long elems, float* __restrict__ out,
+                                                            int nb_reduce, const float* __restrict__ w, const float* __restrict__ f, int K, int C,
+                                                            float* __restrict__ q) {
+  __shared__ float red[8][32];
+  if ((int)blockIdx.x < nb_reduce) {
+    slab_reduce_block(slabs, n_slabs, elems, out, blockIdx.x, 0, red);
+    return;
+  }
+  const int k = ((int)blockIdx.x - nb_reduce) * 4 + (threadIdx.x >> 6);
+  if (k >= K) return;
+  const int lane = threadIdx.x & 63;
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s = fmaf(f[c], w[(long long)k * C + c], s);
+  s = wave_sum(s);
+  if (lane == 0) q[k] = s;
+}
+
+int slab_reduce_q(const float* slabs, int n_slabs, long long elems, float* out, const float* w, const float* f, int K, int C, float* q,
+                  hipStream_t st) {
+  PN_CHECK_ARG(slabs && out && w && f && q, "slab_reduce_q: null pointer");
+  PN_CHECK_ARG(n_slabs > 0 && elems > 0 && K > 0 && C > 0, "slab_reduce_q: bad sizes");
+  const int nb = (int)cdivll(elems, 32);
+  hipLaunchKernelGGL(slab_reduce_q_kernel, dim3(nb + cdiv(K, 4)), dim3(256), 0, st, slabs, n_slabs, elems, out, nb, w, f, K, C, q);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
 int slab_reduce(const float* slabs, int n_slabs, int per_group, long long elems, float* out, hipStream_t st) {
   PN_CHECK_ARG(slabs && out, "pn_slab_reduce: null pointer");
   PN_CHECK_ARG(n_slabs > 0 && per_group > 0 && n_slabs % per_group == 0 && elems > 0, "pn_slab_reduce: bad sizes");
