@@ -370,6 +370,7 @@ struct Run {
   // auxiliary stream (its launches are already off the main chain), and PN_SLAB_DEFER=0 restores one reduction per layer.
   std::vector<SlabJob> jobs;
   std::vector<WgradDesc> wg_jobs;                    // their weight-gradient GEMMs, launched together by tile shape (conv_wgrad_batch)
+  std::vector<WgradDesc> gw_jobs;                    // the G W products of the max-pooled layers (consume the reduced Gram matrices)
   std::vector<std::function<int()>> after_jobs;      // launches that consume a deferred reduction (and feed only the optimizer)
   std::vector<DwJob> dw_jobs;                        // ... and the dW kernels of the max-pooled layers behind those, one launch
   int dw_K = 0, dw_C = 0;
@@ -388,6 +389,8 @@ struct Run {
     wg_jobs.clear();
     if (rc == PN_OK && !jobs.empty()) rc = slab_reduce_batch(jobs.data(), (int)jobs.size(), st);
     jobs.clear();
+    if (rc == PN_OK && !gw_jobs.empty()) rc = conv_wgrad_batch(gw_jobs.data(), (int)gw_jobs.size(), st);
+    gw_jobs.clear();
     for (auto& f : after_jobs) {
       if (rc != PN_OK) break;
       rc = f();
@@ -670,9 +673,12 @@ struct Run {
       // this whole branch feeds only dW: the Gram slabs are reduced with the other deferred jobs and the two consumers follow them
       PN_TRY(side([=] {
         PN_TRY(wgrad_general(xop, xop, B, N, K, K, mm.gram, false, prec, true, true));   // Gram matrix and a1 = column sums together
+        // G W in weight-gradient form: out[k][c] = sum_k' G[k'][k] W[k'][c] over ONE slab of K rows written straight into GW (G is
+        // symmetric up to the rounding of its cross terms); in that form the three layers can share a launch (conv_wgrad_batch)
+        const WgradDesc gwd{plain(mm.gram, K), plain(Wk, C), 1, K, K, C, K, mm.GW, PN_PREC_BF16X3, 0};
+        auto gw_alone = [=] { return conv_wgrad(&gwd.a, &gwd.b, 1, K, K, C, K, mm.GW, PN_PREC_BF16X3, st, 0); };
         auto rest = [=] {
-          const pn_operand gop = plain(mm.gram, K);
-          PN_TRY(conv_fwd(&gop, Wk, 0, 1, K, K, C, nullptr, mm.GW, nullptr, PN_PREC_BF16X3, st));
+          PN_TRY(gw_alone());
           return maxbwd_dw(&xop, mm.arg, mm.hs, B, N, K, C, mm.a1, mm.f, mm.e, mm.GW, dw, st);
         };
         if (!last_deferred) return rest();
@@ -680,10 +686,9 @@ struct Run {
           after_jobs.push_back(rest);
           return (int)PN_OK;
         }
-        after_jobs.push_back([=] {
-          const pn_operand gop = plain(mm.gram, K);
-          return conv_fwd(&gop, Wk, 0, 1, K, K, C, nullptr, mm.GW, nullptr, PN_PREC_BF16X3, st);
-        });
+        static const bool gw_batch = !(getenv("PN_GW_BATCH") && atoi(getenv("PN_GW_BATCH")) == 0);
+        if (gw_batch) gw_jobs.push_back(gwd);
+        else after_jobs.push_back(gw_alone);
         dw_K = K; dw_C = C;
         dw_jobs.push_back(DwJob{xop, mm.arg, mm.hs, mm.a1, mm.f, mm.e, mm.GW, dw});
         return (int)PN_OK;
