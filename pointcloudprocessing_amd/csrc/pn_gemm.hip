@@ -750,7 +750,7 @@ static int launch_wgrad_batch(const WgradBatch& wb, bool b2, int prec, int block
 int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st) {
   std::vector<char> done(n > 0 ? n : 0, 0);
   auto key = [&](const WgradDesc& q) {
-    const int shape = (q.Ci % 128 == 0 && q.Cj % 128 == 0) ? 0 : (q.Cj % 128 == 0 ? 1 : 2);
+    const int shape = q.small_tiles ? 2 : (q.Ci % 128 == 0 && q.Cj % 128 == 0) ? 0 : (q.Cj % 128 == 0 ? 1 : 2);
     return shape * 8 + (q.b.s2 ? 4 : 0) + (q.prec == PN_PREC_BF16X3 ? 1 : 0);
   };
   for (int i = 0; i < n; ++i) {

@@ -18,6 +18,7 @@ struct WgradDesc {
   int B, N, Ci, Cj, slab_rows;
   float* slabs;
   int prec, colsum;
+  int small_tiles;      // 64x64 output tiles whatever the channel counts: for jobs with so few slabs that 128-wide tiles leave the chip idle
 };
 int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st);
 int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, int Cj, int slab_rows, float* slabs, int prec,

@@ -626,7 +626,7 @@ struct Run {
     if (deferrable && !per_cloud) {
       if (float* ps = pool_take((size_t)Bq * spc * elems)) {
         static const bool batch_gemm = !(getenv("PN_WGRAD_BATCH") && atoi(getenv("PN_WGRAD_BATCH")) == 0);
-        if (batch_gemm) wg_jobs.push_back(WgradDesc{a, b, Bq, Nq, Ci, Cj, rows, ps, pr, colsum ? 1 : 0});
+        if (batch_gemm) wg_jobs.push_back(WgradDesc{a, b, Bq, Nq, Ci, Cj, rows, ps, pr, colsum ? 1 : 0, 0});
         else PN_TRY(conv_wgrad(&a, &b, Bq, Nq, Ci, Cj, rows, ps, pr, st, colsum ? 1 : 0));
         jobs.push_back(SlabJob{ps, out, (long long)elems, Bq * spc});
         last_deferred = true;
@@ -675,8 +675,8 @@ struct Run {
         PN_TRY(wgrad_general(xop, xop, B, N, K, K, mm.gram, false, prec, true, true));   // Gram matrix and a1 = column sums together
         // G W in weight-gradient form: out[k][c] = sum_k' G[k'][k] W[k'][c] over ONE slab of K rows written straight into GW (G is
         // symmetric up to the rounding of its cross terms); in that form the three layers can share a launch (conv_wgrad_batch)
-        const WgradDesc gwd{plain(mm.gram, K), plain(Wk, C), 1, K, K, C, K, mm.GW, PN_PREC_BF16X3, 0};
-        auto gw_alone = [=] { return conv_wgrad(&gwd.a, &gwd.b, 1, K, K, C, K, mm.GW, PN_PREC_BF16X3, st, 0); };
+        const WgradDesc gwd{plain(mm.gram, K), plain(Wk, C), 1, K, K, C, K, mm.GW, PN_PREC_BF16X3, 0, 1};   // 64x64 tiles: 32 workgroups per layer
+        auto gw_alone = [=] { return conv_wgrad_batch(&gwd, 1, st); };
         auto rest = [=] {
           PN_TRY(gw_alone());
           return maxbwd_dw(&xop, mm.arg, mm.hs, B, N, K, C, mm.a1, mm.f, mm.e, mm.GW, dw, st);
@@ -707,7 +707,9 @@ struct Run {
         return PN_ERR_WORKSPACE;
       }
       const pn_operand we = plain(m.We, K), wt = plain(m.Wt, K);
-      PN_TRY(conv_wgrad(&we, &wt, 1, C, K, K, rows, sl, PN_PREC_BF16X3, st, 0));
+      static const bool pm_small = !(getenv("PN_PM_SMALL") && atoi(getenv("PN_PM_SMALL")) == 0);
+      const WgradDesc pmd{we, wt, 1, C, K, K, rows, sl, PN_PREC_BF16X3, 0, pm_small ? 1 : 0};   // 64x64 tiles: 4x the workgroups of this 16-slab job
+      PN_TRY(conv_wgrad_batch(&pmd, 1, st));
       PN_TRY(slab_reduce_q(sl, spc, (long long)K * K, m.Pm, p(r.kernel), m.f, K, C, m.q, st));
     }
     PN_TRY(maxbwd_scatter(m.arg, m.hs, m.Wt, m.q, B, N, K, C, m.D, st));
