@@ -158,13 +158,13 @@ struct WS {
   unsigned* dcount;
 };
 
-static long long wgrad_slab_rows(int B, int N, int Ci, int Cj, int* spc_out) {
+static long long wgrad_slab_rows(int B, int N, int Ci, int Cj, int* spc_out, int target_override = 0) {
   const int bm = (Ci % 128 == 0 && Cj % 128 == 0) ? 128 : 64, bn = (Cj % 128 == 0) ? 128 : 64;
   const int n_out = (Ci / bm) * (Cj / bn);
   // about one workgroup per CU: 512 slabs of 64 rows made the weight-gradient kernels write (and slab_reduce re-read) twice the
   // bytes for no extra parallelism -- 1.40 -> 1.34 ms/step at B=32, N=1024 (sweep: 64: 1.47, 128: 1.38, 192: 1.36, 256-384: 1.34)
   static const int target_blocks = getenv("PN_WGRAD_TARGET") ? atoi(getenv("PN_WGRAD_TARGET")) : 256;
-  int target = target_blocks / n_out;
+  int target = (target_override > 0 ? target_override : target_blocks) / n_out;
   if (target < 1) target = 1;
   int spc = cdiv(target, B);
   const int max_spc = cdiv(N, 64);
@@ -619,8 +619,13 @@ struct Run {
   // colsum: `out` receives Ci*Cj products followed by Ci column sums of operand a (Gram matrix + a1 in one pass over the rows)
   int wgrad_general(const pn_operand& a, const pn_operand& b, int Bq, int Nq, int Ci, int Cj, float* out, bool per_cloud, int pr,
                     bool colsum = false, bool deferrable = false) {
+    // deferred jobs share their launch with others of the same tile shape, so each can do with fewer, longer slabs (never more than
+    // the plan sized the pool for: the default target is the upper bound)
+    // the three Gram matrices in one launch: 128 slabs each (1.063 -> 1.053 ms/step); the 64-wide jobs measured the same at 128 and 256
+    static const int t_gram = getenv("PN_WGRAD_TARGET_GRAM") ? atoi(getenv("PN_WGRAD_TARGET_GRAM")) : 128;
+    const int t_over = (deferrable && colsum) ? t_gram : 0;
     int spc;
-    const int rows = (int)wgrad_slab_rows(Bq, Nq, Ci, Cj, &spc);
+    const int rows = (int)wgrad_slab_rows(Bq, Nq, Ci, Cj, &spc, t_over);
     const size_t elems = (size_t)Ci * Cj + (colsum ? Ci : 0);
     last_deferred = false;
     if (deferrable && !per_cloud) {
