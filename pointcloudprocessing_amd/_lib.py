@@ -130,6 +130,10 @@ def lib():
             raise PointNetHipError(
                 f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                 f"(or `make -C {CSRC}`).  There is no CPU fallback for the PointNet hot path.")
+        # PyTorch first: its wheel bundles its own libamdhip64 and every stream / device pointer handed to the library comes from that
+        # runtime.  Loaded before torch, the library binds /opt/rocm's copy instead and the process ends up with two HIP runtimes
+        # (launches then fail with "no ROCm-capable device is detected").
+        import torch  # noqa: F401
         try:
             l = C.CDLL(LIB_PATH)
         except OSError as e:
