@@ -304,3 +304,15 @@ def test_graft_entry_build_hook_runs():
     """the driver's build check: compiles every native piece in-tree and imports the package (no GPU needed)"""
     import __graft_entry__ as g
     g.build()
+
+
+def test_library_load_pulls_in_pytorch_first():
+    """one HIP runtime per process: _lib.lib() imports torch (whose wheel bundles libamdhip64) before it dlopens the library, so
+    `build()` followed by `smoke()` in one interpreter works whatever was imported first"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); from pointcloudprocessing_amd import _lib; assert 'torch' not in sys.modules; "
+            "_lib.lib(); assert 'torch' in sys.modules; print('ok')" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-1500:]
