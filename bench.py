@@ -171,7 +171,7 @@ def main():
         e0.record(); e1.record()
     torch.cuda.synchronize()
     ev_overhead = sorted(e0.elapsed_time(e1) * 1e-3 for e0, e1 in cal)[len(cal) // 2]
-    k_mean = sum(kt) / len(kt) - ev_overhead
+    k_mean = sum(kt) / len(kt)
     flop_per_launch = 2.0 * 128 * 1024 * B * N
     # algorithmic bytes: pre-BN input rows read once (fp32) + the bf16 kernel copy + per-(cloud, channel) max/argmax/2 sums
     bytes_per_launch = 128 * 4 * B * N + 128 * 1024 * 2 * (2 if args.precision == "bf16x3" else 1) + B * 1024 * 16

@@ -218,6 +218,11 @@ int pn_seg_out_fwd(const pn_operand* x, const float* w, const float* bias, int64
  * K = 64 runs on the MFMA engine (pn_conv_fwd with a per-cloud weight stride); K = 3 is a three-FMA-per-output kernel. */
 int pn_bmm(const float* x, const float* R, int B, int N, int K, float* out, int prec, pn_stream stream);
 
+/* --- tf.debugging.check_numerics (PointNet.py:199,208,218,...,288; enabled by `debugging: true`, pointnet_train.py:112):
+ * *count (device int32) += the number of NaN / Inf elements among x[0..n).  The Python model calls it once per check site of the
+ * reference after a forward pass and raises with the reference's message for the first site whose count is non-zero. */
+int pn_count_nonfinite(const float* x, int64_t n, int32_t* count, pn_stream stream);
+
 /* --- farthest point sampling (no counterpart in the reference; build-defined spec):
  * per cloud, start at `start_idx`, repeatedly take the point with the largest squared distance (fp32,
  * d = dx*dx + dy*dy + dz*dz evaluated left to right without fma contraction) to the selected set, ties ->

@@ -91,6 +91,7 @@ SIGNATURES = {
     "pn_seg_out_fwd": (_I, [_OP, _P, _P, _I64, _I, _I, _P, _F, _P, _P, _P, _P]),
     "pn_bmm": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
     "pn_dropout_masks": (_I, [_P, _I64, _P, _I64, _F, C.c_uint64, _P, _P]),
+    "pn_count_nonfinite": (_I, [_P, _I64, _P, _P]),
     "pn_fps_workspace_bytes": (C.c_size_t, [_I, _I]),
     "pn_fps": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     "pn_voxel_workspace_bytes": (C.c_size_t, [_I]),

@@ -130,6 +130,7 @@ int fold3_fwd(const float* R, const float* W, int B, int C, float* Weff, hipStre
 int fold3_bwd(const float* dWeff, const float* R, const float* W, int B, int C, float* dR, float* dW, hipStream_t st);
 int fill_eye3(float* out, int B, hipStream_t st);
 int axpy(const float* x, float a, float* y, long long n, hipStream_t st);
+int count_nonfinite(const float* x, long long n, int* count, hipStream_t st);
 int zero_fill(float* p, long long n, hipStream_t st);
 int zero_fill2(float* p, long long n, float* p2, int n2, hipStream_t st);   // + a second, small region
 int add2(const float* a, const float* b, float* out, long long n, hipStream_t st);

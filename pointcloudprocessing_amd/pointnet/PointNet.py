@@ -675,11 +675,50 @@ class PointNet(torch.nn.Module):
         R = torch.empty(B, 3, 3, device=dev, dtype=torch.float32)
         io.out_cls, io.out_seg, io.out_R = cls.data_ptr(), seg.data_ptr(), R.data_ptr()
         check(lib().pn_model_forward(C.byref(self._desc), C.byref(io), current_stream()), "pn_model_forward")
+        if self._debugging:
+            self._check_numerics(pc, cls, seg, training)
         self._last = (cls, seg, R)
         self._last_call = dict(pc=pc, training=training, fused=fused, keep=keep, io=io)
         if not self._vanilla:
             self.input_transform._last_predicted = R
         return cls, seg, R
+
+    def _check_numerics(self, pc, cls, seg, training):
+        """``debugging: true`` (reference pointnet_train.py:112): PointNet.call wraps its input and every layer output in
+        tf.debugging.check_numerics (PointNet.py:199-288).  The plan stores each ConvLayer's pre-BN output and BN coefficients, the
+        pooled features and the head activations; they are scanned on the device (pn_count_nonfinite) in the reference's order and the
+        first site holding a NaN / Inf raises with the reference's own message.  One host read per call: debug mode only, never inside
+        a captured step."""
+        B, N, _ = pc.shape
+        def t(name):
+            return self.workspace_tensor(name, B, N, training)
+        conv = lambda wn: [t(wn + ".Z"), t(wn + ".scale"), t(wn + ".shift")]          # noqa: E731
+        sites = [("Input point cloud contains nan values", "pointnet_input", [pc])]
+        if not self._vanilla:
+            sites.append(("Input transform produced nan values.", self.input_transform.name, [t("iT.R"), t("Weff1")]))
+        sites += [("mlp_1_1 produced nan values.", self.mlp_1_1.name, conv("m11")),
+                  ("mlp_1_2 produced nan values.", self.mlp_1_2.name, conv("m12"))]
+        if not self._vanilla:
+            sites.append(("Feature transform produced nan values.", self.feature_transform.name, [t("fT.R"), t("X64")]))
+        sites += [("mlp_2_1 produced nan values.", self.mlp_2_1.name, conv("m21")),
+                  ("mlp_2_2 produced nan values.", self.mlp_2_2.name, conv("m22")),
+                  ("mlp_2_3 produced nan values.", self.mlp_2_3.name, [t("mm23.zstar"), t("mm23.g")]),
+                  ("mlp_cls_1 produced nan values.", self.mlp_cls_1.name, [t("c1.a")]),
+                  ("mlp_cls_2 produced nan values.", self.mlp_cls_2.name, [t("c2.a")]),
+                  ("mlp_cls_3 produced nan values.", self.mlp_cls_3.name, [cls]),
+                  ("mlp_3_1 produced nan values.", self.mlp_seg_1.name, conv("s1")),
+                  ("mlp_3_2 produced nan values.", self.mlp_seg_2.name, conv("s2")),
+                  ("mlp_3_3 produced nan values.", self.mlp_seg_3.name, conv("s3")),
+                  ("mlp_3_4 produced nan values.", self.mlp_seg_4.name, conv("s4")),
+                  ("mlp_3_5 produced nan values.", self.mlp_seg_5.name, [seg])]
+        counts = torch.zeros(len(sites), dtype=torch.int32, device=pc.device)
+        for i, (_, _, tensors) in enumerate(sites):
+            for x in tensors:
+                check(lib().pn_count_nonfinite(ptr(x), x.numel(), ptr(counts[i:i + 1]), current_stream()), "pn_count_nonfinite")
+        bad = counts.cpu().tolist()
+        for (msg, layer, _), n in zip(sites, bad):
+            if n:
+                raise PointNetHipError(f"check_numerics: {msg} ({n} non-finite values at layer '{layer}')")
 
     def _run_backward(self, d_cls, d_seg, d_R, phase: int = 0):
         """phase 0: the whole backward pass; 1 / 2: its two halves (pn_model_io.bwd_phase) for gradient-bucket overlap"""

@@ -136,13 +136,13 @@ class OracleEngine:
             torch.save({"config": {}, "weights": self.get_weights()}, path)
 
 
-def write_config(tmp, vanilla=None, epochs=2, patience=30, monitor=True):
+def write_config(tmp, vanilla=None, epochs=2, patience=30, monitor=True, input_width=128, batch_size=2, n_frames=12):
     d = str(tmp) + "/"
     os.makedirs(d + "models", exist_ok=True)
     os.makedirs(d + "data", exist_ok=True)
     os.makedirs(d + "in", exist_ok=True)
-    make_collect(d + "in", "collect_a", 12, seed=1)
-    make_collect(d + "in", "collect_b", 12, seed=2)
+    make_collect(d + "in", "collect_a", n_frames, seed=1)
+    make_collect(d + "in", "collect_b", n_frames, seed=2)
 
     def prof(tr, lw, mon):
         p = {"datasets": {"0": "collect_a", "1": "collect_b"}, "noise": {"x_stdev_m": 0.01, "y_stdev_m": 0.01, "z_stdev_m": 0.01},
@@ -161,7 +161,7 @@ def write_config(tmp, vanilla=None, epochs=2, patience=30, monitor=True):
                                        "segmentation_head": True}, {"classification": 0.0, "segmentation": 1.0, "rotation": 0.0},
                                       "val_segmentation_output_loss")},
                     "continue_training_model": ""},
-           "params": {"input_width": 128, "epochs": epochs, "patience": patience, "batch_size": 2,
+           "params": {"input_width": input_width, "epochs": epochs, "patience": patience, "batch_size": batch_size,
                       "learning": {"rate": 1e-3, "decay_steps": 7000, "decay_rate": 0.7}, "random_seed": 42, "debugging": False,
                       "regularize_input_transform": False, "regularize_feature_transform": False},
            "file_system": {"model_path": d + "models/", "input_path": d + "in/", "data_path": d + "data/"}}

@@ -1,0 +1,147 @@
+"""GPU parity on the configurations BASELINE.json names, at their named sizes, and of the pieces every timed step runs
+(Adam + ExponentialDecay, the orthogonality regularisers), against the CPU oracle.
+
+PARITY UNPINNED against the reference itself (see tests/parity_harness.py): the checker is oracle/pointnet_oracle.py.
+
+  C2  PointNet-cls  B=32, N=1024, bf16 MFMA operands, profile classification_pretrain  -- what bench.py times
+  C3  PointNet-seg  B=32, N=2048, profile final (segmentation head trained)             -- bf16x3 and bf16
+  C4  PointNet-cls  per-rank shape of the 8-GPU run: B=8, N=4096                        -- bf16x3 and bf16
+  C1  the trainer entry point at its named size (N=1024, batch 4) is in tests/test_gpu_train.py
+
+Tolerances.  bf16x3 (16 significant bits per operand) vs the fp64 oracle: gradients 5e-3 of each tensor's max (measured ~1e-4),
+training-mode outputs 3e-4.  bf16 vs the fp64 oracle with bf16-rounded matmul operands: the forward pass shares its rounding points
+with the oracle (outputs 5e-3); the backward pass of the GPU additionally rounds dz and the activations to bf16 (the oracle's
+autograd does not), so gradients are held to 4e-2 of each tensor's max, the bound bf16's 2^-9 relative operand rounding gives over
+K <= 1024-term contractions.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import pointnet_oracle as O   # noqa: E402  (checker only)
+from parity_harness import CCLS, CSEG, build_model, check_training_step, make_inputs, report   # noqa: E402
+
+BF16 = dict(tol_grad=4e-2, tol_fwd=5e-3, tol_loss=5e-3, tol_stats=5e-3, near_zero=3e-2, with_cond=False)
+X3 = dict(tol_grad=5e-3, tol_fwd=3e-4, with_cond=False)
+
+
+@pytest.mark.parametrize("name,B,N,profile,precision,tol", [
+    ("C2", 32, 1024, "classification_pretrain", "bf16", BF16),
+    ("C2-x3", 32, 1024, "classification_pretrain", "bf16x3", X3),
+    ("C3", 32, 2048, "final", "bf16x3", X3),
+    ("C3-bf16", 32, 2048, "final", "bf16", BF16),
+    ("C4-rank", 8, 4096, "classification_pretrain", "bf16x3", X3),
+    ("C4-rank-bf16", 8, 4096, "classification_pretrain", "bf16", BF16),
+])
+def test_training_step_at_baseline_config(dev, name, B, N, profile, precision, tol):
+    worst, _ = check_training_step(dev, B, N, profile, precision=precision, seed_params=21, seed_inputs=20260001, tag=f"{name}[{profile},{precision},B={B},N={N}]",
+                                   **tol)
+    report(f"{name}: worst relative gradient error {worst:.3e} (tolerance {tol['tol_grad']:.0e})")
+
+
+def test_both_regularisers_on(dev):
+    """regularize_input_transform / regularize_feature_transform (PointNet.py:92-93, 447-451): 1e-3 * l2_loss(I - R R^T) summed over the
+    batch enters the loss through add_loss; scalars[5], scalars[6] and every T-Net gradient against the oracle.  The T-Net tail `b` is
+    perturbed away from the identity (init_params randomize_bn) so that I - R R^T is not ~0."""
+    worst, m = check_training_step(dev, 16, 136, "all", precision="bf16x3", reg=True, seed_params=31, seed_inputs=32)
+    sc = m.scalars.cpu()
+    assert float(sc[5]) > 0 and float(sc[6]) > 0
+    # the regularisers alone must reach the T-Nets: zero loss weights, heads frozen -> only add_loss terms drive the gradients
+    worst2, m2 = check_training_step(dev, 16, 136, "reg_only", precision="bf16x3", reg=True, seed_params=31, seed_inputs=32)
+    assert float(m2.named_grads()["feature_transform.w"].abs().max()) > 0
+
+
+def test_adam_kernel_matches_keras_adam(dev):
+    """pn_adam_step (the one launch every timed step ends with: device-side ExponentialDecay schedule, last-ticket iteration advance,
+    grad_scale) against oracle.keras_adam_step + exponential_decay_lr (pointnet_train.py:310-319) over 5 steps, one of them with
+    grad_scale = 0.5 (the 1/world of a two-rank sum), then a restore of (m, v, iterations) into a fresh optimizer and 3 more steps."""
+    from pointcloudprocessing_amd.optim import KerasAdam
+    n = 4_210_476 + 13                                        # the model's parameter count, not a multiple of the block size
+    g = torch.Generator().manual_seed(3)
+    p0 = torch.randn(n, generator=g) * 0.1
+    lr0, ds, dr = 1e-3, 7.0, 0.7                             # a short decay period so that the schedule moves visibly within 8 steps
+    p_ref, m_ref, v_ref = p0.double().clone(), torch.zeros(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    p_gpu = p0.to(dev).clone()
+    opt = KerasAdam(p_gpu, lr0, ds, dr)
+    scales = [1.0, 1.0, 0.5, 1.0, 1.0, 1.0, 0.25, 1.0]
+    for step, gs in enumerate(scales):
+        grad = torch.randn(n, generator=g) * (10.0 ** (step % 3 - 2))      # magnitudes 1e-2 .. 1
+        if step == 5:                                          # checkpoint restore into a new optimizer object
+            state = {k: v.clone() for k, v in opt.state_dict().items()}
+            opt = KerasAdam(p_gpu, lr0, ds, dr)
+            assert int(opt.iterations) == 0
+            opt.load_state_dict(state)
+            assert int(opt.iterations) == 5
+        lr = O.exponential_decay_lr(lr0, step, ds, dr)
+        assert abs(opt.learning_rate - lr) < 1e-6 * lr, (step, opt.learning_rate, lr)
+        opt.step(grad.to(dev), gs)
+        O.keras_adam_step(p_ref, grad.double() * gs, m_ref, v_ref, step, lr)
+        torch.cuda.synchronize()
+        assert int(opt.iterations) == step + 1
+        ep = float((p_gpu.cpu().double() - p_ref).abs().max())
+        em = float((opt.m.cpu().double() - m_ref).abs().max() / m_ref.abs().max())
+        ev = float((opt.v.cpu().double() - v_ref).abs().max() / v_ref.abs().max())
+        report(f"adam step {step}: max abs param err {ep:.3e}, rel m err {em:.3e}, rel v err {ev:.3e}, lr {lr:.6e}")
+        # fp32 state against fp64: a step moves a parameter by at most ~lr, and its rounding error is a few ulp of the parameter
+        assert ep < 5e-7 and em < 1e-5 and ev < 1e-5, (step, ep, em, ev)
+    moved = float((p_gpu.cpu().double() - p0.double()).abs().max())
+    assert moved > 3 * lr0                                     # the comparison above is not vacuous
+    assert math.isclose(opt.learning_rate, O.exponential_decay_lr(lr0, len(scales), ds, dr), rel_tol=1e-6)
+
+
+def test_nan_and_inf_clouds_do_not_fault(dev):
+    """regression (round 1, gpurun call 20): a cloud holding NaN made every arg-max comparison false, the index sentinel 0x7fffffff
+    reached the scatter of the max-pool backward and the GPU faulted.  A NaN cloud and an Inf cloud through fused_loss_step: no fault,
+    every arg-max index inside the cloud, the loss sums flagged non-finite, and the healthy step afterwards is unaffected."""
+    B, N = 4, 300
+    params = O.init_params(CCLS, CSEG, seed=41, randomize_bn=True)
+    pc, y_cls, y_seg, se3, keep = make_inputs(B, N, 42)
+    kp = (keep["dropout_1"].to(torch.uint8).to(dev), keep["dropout_2"].to(torch.uint8).to(dev))
+    args = (y_cls.to(torch.int32).to(dev), y_seg.to(torch.int32).to(dev), se3.to(dev), (1.0, 1.0, 1.0))
+    m = build_model(dev, params, precision="bf16")
+    m.fused_loss_step(pc.to(dev), *args, keep=kp)
+    torch.cuda.synchronize()
+    healthy = m.grads_flat.clone()
+    assert bool(torch.isfinite(healthy).all())
+    for poison in (float("nan"), float("inf"), -float("inf")):
+        bad = pc.clone()
+        bad[1, 17, 2] = poison
+        bad[3, :, :] = poison                                   # a whole cloud
+        m.set_weights(params)                                   # moving statistics back to finite values
+        m.fused_loss_step(bad.to(dev), *args, keep=kp)
+        torch.cuda.synchronize()
+        for wn in ("iT.m3", "fT.m3", "mm23"):
+            arg = m.workspace_tensor(wn + ".arg", B, N, True, torch.int32)
+            assert int(arg.min()) >= 0 and int(arg.max()) < N, (poison, wn, int(arg.min()), int(arg.max()))
+        sc = m.scalars.cpu()
+        assert not bool(torch.isfinite(sc[[0, 2]]).all()), (poison, sc.tolist())
+    m.set_weights(params)
+    m.fused_loss_step(pc.to(dev), *args, keep=kp)
+    torch.cuda.synchronize()
+    assert torch.equal(m.grads_flat, healthy)
+
+
+def test_debugging_flag_checks_numerics(dev):
+    """`debugging: true` (pointnet_train.py:112) makes the reference wrap every layer output in tf.debugging.check_numerics
+    (PointNet.py:199-288): the first layer whose output holds a NaN / Inf raises, named.  Off: no check, no error."""
+    from pointcloudprocessing_amd._lib import PointNetHipError
+    B, N = 2, 200
+    params = O.init_params(CCLS, CSEG, seed=43, randomize_bn=True)
+    pc, *_ = make_inputs(B, N, 44)
+    m = build_model(dev, params, precision="bf16", debugging=True)
+    m(pc.to(dev), training=False)                               # healthy input passes
+    bad = pc.clone()
+    bad[0, 5, 1] = float("nan")
+    with pytest.raises(PointNetHipError, match="Input point cloud contains nan values"):
+        m(bad.to(dev), training=False)
+    # a poisoned weight deeper in the network is blamed on that layer, not on an earlier one
+    p2 = {k: v.clone() for k, v in params.items()}
+    p2["mlp_2_2.kernel"][3, 7] = float("inf")
+    m2 = build_model(dev, p2, precision="bf16", debugging=True)
+    with pytest.raises(PointNetHipError, match="mlp_2_2 produced nan values"):
+        m2(pc.to(dev), training=False)
+    m3 = build_model(dev, p2, precision="bf16", debugging=False)
+    m3(pc.to(dev), training=False)                              # no check without the flag (the reference behaves the same)

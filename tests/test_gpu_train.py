@@ -28,6 +28,20 @@ def test_trainer_end_to_end_on_gpu(dev, tmp_path):
     assert "Continuing training on model unit/classification_pretrain/unit_classification_pretrain.pt" in log
 
 
+def test_trainer_at_baseline_config_c1_size(dev, tmp_path):
+    """BASELINE config C1 (plumbing): PointNet-cls N=1024 points, batch 4, through the reference's entry point
+    (pointnet_train.py config -> datasets -> profiles -> artefacts); 3 steps per epoch.  The 490- / 313-point reference clouds are
+    padded to 1024 by _adjust_to_input_width (PointCloudSet.py:443-470)."""
+    from pointcloudprocessing_amd import pointnet_train as T
+    cfg, d = write_config(tmp_path, vanilla=False, epochs=1, input_width=1024, batch_size=4, n_frames=24)
+    assert T.train_pointnet([cfg], max_steps_per_epoch=3, precision="bf16")
+    h = json.load(open(d + "models/unit/classification_pretrain/unit_classification_pretrain_history.json"))
+    assert all(len(v) == 1 and np.isfinite(v[0]) for v in h.values())
+    assert 0.0 <= h["classification_output_sparse_categorical_accuracy"][0] <= 1.0 and h["loss"][0] > 0
+    ck = torch.load(d + "models/unit/final/unit_final.pt", weights_only=True)
+    assert ck["config"]["precision"] == "bf16" and tuple(ck["weights"]["mlp_2_3.kernel"].shape) == (128, 1024)
+
+
 def test_native_train_step_learns_and_graph_matches_eager(dev):
     """a few hundred Adam steps on one fixed batch must drive the classification loss down; the hipGraph replay of the
     step must produce exactly the same weights as eager launches (same kernels, same order)."""
