@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 2
+#define PN_ABI_VERSION 3
 
 typedef enum {
   PN_OK = 0,
@@ -340,11 +340,13 @@ int pn_dropout_masks(uint8_t* keep1, int64_t n1, uint8_t* keep2, int64_t n2, flo
  * grads are multiplied by grad_scale first (1/world_size after a sum all-reduce). */
 /* evaluate the schedule for the CURRENT *iterations into alpha_scratch and clear the ticket: once after allocating the
  * state, and again whenever *iterations is set from outside (checkpoint restore) */
-int pn_adam_prepare(const int32_t* iterations, float* alpha_scratch, float lr0, float decay_rate, float decay_steps, float beta1,
-                    float beta2, pn_stream stream);
+/* hyper-parameters travel as doubles: keras forms `1 - beta` from the Python float and only then casts to the variable's fp32
+ * (1 - 0.999 -> 0.001f), whereas 1.f - 0.999f is 1.3e-5 off */
+int pn_adam_prepare(const int32_t* iterations, float* alpha_scratch, double lr0, double decay_rate, double decay_steps, double beta1,
+                    double beta2, pn_stream stream);
 int pn_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int32_t* iterations,
-                 float* alpha_scratch, float lr0, float decay_rate, float decay_steps, float beta1, float beta2,
-                 float eps, float grad_scale, pn_stream stream);
+                 float* alpha_scratch, double lr0, double decay_rate, double decay_steps, double beta1, double beta2,
+                 double eps, float grad_scale, pn_stream stream);
 
 #ifdef __cplusplus
 }

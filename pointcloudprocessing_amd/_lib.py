@@ -15,7 +15,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 PN_PREC_BF16 = 1
 PN_PREC_BF16X3 = 3
-ABI_VERSION = 2            # PN_ABI_VERSION of include/pointnet_hip.h this binding was written against
+ABI_VERSION = 3            # PN_ABI_VERSION of include/pointnet_hip.h this binding was written against
 PN_NUM_BLOCKS = 15
 PREC = {"bf16": PN_PREC_BF16, "bf16x3": PN_PREC_BF16X3}
 
@@ -60,6 +60,7 @@ _P = C.c_void_p
 _I = C.c_int
 _I64 = C.c_int64
 _F = C.c_float
+_D = C.c_double
 _OP = C.POINTER(pn_operand)
 _DESC = C.POINTER(pn_model_desc)
 _IO = C.POINTER(pn_model_io)
@@ -105,8 +106,8 @@ SIGNATURES = {
     "pn_model_ws_entry": (_I, [_DESC, _I, _I, _I, _I, C.c_char_p, _I, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pn_model_forward": (_I, [_DESC, _IO, _P]),
     "pn_model_backward": (_I, [_DESC, _IO, _P, _P, _P, _P]),
-    "pn_adam_prepare": (_I, [_P, _P, _F, _F, _F, _F, _F, _P]),
-    "pn_adam_step": (_I, [_P, _P, _P, _P, _I64, _P, _P, _F, _F, _F, _F, _F, _F, _F, _P]),
+    "pn_adam_prepare": (_I, [_P, _P, _D, _D, _D, _D, _D, _P]),
+    "pn_adam_step": (_I, [_P, _P, _P, _P, _I64, _P, _P, _D, _D, _D, _D, _D, _D, _F, _P]),
 }
 
 _lib = None

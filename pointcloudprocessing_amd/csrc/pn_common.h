@@ -45,6 +45,10 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
   return v;
 }
+// Lower clamp (ReLU when lo = 0) and two-sided clip that keep a NaN a NaN, as tf.nn.relu / tf.clip_by_value do: v_max_f32 /
+// fmaxf return the OTHER operand for a NaN, which would turn a diverged (NaN) activation into a silent zero and leave the loss finite.
+__device__ __forceinline__ float clamp_lo(float v, float lo) { return v < lo ? lo : v; }
+__device__ __forceinline__ float clip_nan(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

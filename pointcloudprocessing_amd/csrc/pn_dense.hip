@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a) {
         const int r = ty + RP * i;
         if (r < R) {
           float y = fmaf(sc, zr[i], sh);
-          if (a.act == 1) y = fmaxf(y, 0.f);
+          if (a.act == 1) y = clamp_lo(y, 0.f);
           if (a.keep) y = a.keep[(long long)r * C + j] ? y * a.keep_scale : 0.f;
           a.a_out[(long long)r * C + j] = y;
         }
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a) {
     } else {
       for (int r = ty; r < R; r += RP) {
         float y = fmaf(sc, a.z_out[(long long)r * C + j], sh);
-        if (a.act == 1) y = fmaxf(y, 0.f);
+        if (a.act == 1) y = clamp_lo(y, 0.f);
         if (a.keep) y = a.keep[(long long)r * C + j] ? y * a.keep_scale : 0.f;
         a.a_out[(long long)r * C + j] = y;
       }
@@ -595,10 +595,10 @@ __global__ __launch_bounds__(1024) void softmax_xent_rows_kernel(const float* __
       const int y = labels[r];
       // keras: q = log(clip(p)), loss = -log_softmax(q)[y]
       float qs = 0.f;
-      for (int c = lane; c < C; c += 32) qs += fminf(fmaxf(expf(l[c] - mx) * inv, 1e-7f), 1.f - 1e-7f);
+      for (int c = lane; c < C; c += 32) qs += clip_nan(expf(l[c] - mx) * inv, 1e-7f, 1.f - 1e-7f);
       qs = grp_sum(qs);
       const float pyr = expf(l[y] - mx) * inv;
-      const float py = fminf(fmaxf(pyr, 1e-7f), 1.f - 1e-7f);
+      const float py = clip_nan(pyr, 1e-7f, 1.f - 1e-7f);
       if (lane == 0) {
         myloss += -(logf(py) - logf(qs));
         mycorr += (am == y) ? 1.f : 0.f;
@@ -608,7 +608,7 @@ __global__ __launch_bounds__(1024) void softmax_xent_rows_kernel(const float* __
         float dot = 0.f;
         for (int c = lane; c < C; c += 32) {
           const float pc0 = expf(l[c] - mx) * inv;
-          const float pc = fminf(fmaxf(pc0, 1e-7f), 1.f - 1e-7f);
+          const float pc = clip_nan(pc0, 1e-7f, 1.f - 1e-7f);
           const bool inr = (pc0 > 1e-7f) && (pc0 < 1.f - 1e-7f);
           const float dp = inr ? (pc / qs - (c == y ? 1.f : 0.f)) / pc0 : 0.f;
           dot = fmaf(pc0, dp, dot);
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(1024) void softmax_xent_rows_kernel(const float* __
         float* d = dlogits + (long long)r * C;
         for (int c = lane; c < C; c += 32) {
           const float pc0 = expf(l[c] - mx) * inv;
-          const float pc = fminf(fmaxf(pc0, 1e-7f), 1.f - 1e-7f);
+          const float pc = clip_nan(pc0, 1e-7f, 1.f - 1e-7f);
           const bool inr = (pc0 > 1e-7f) && (pc0 < 1.f - 1e-7f);
           const float dp = inr ? (pc / qs - (c == y ? 1.f : 0.f)) / pc0 : 0.f;
           d[c] = grad_scale * pc0 * (dp - dot);

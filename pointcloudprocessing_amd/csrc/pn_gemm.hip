@@ -151,7 +151,7 @@ struct NatStage {
       for (int e = 0; e < 8; ++e) {
         float t = fmaf(ca[e], v[e], cc[e]);
         if (HAS2) t = fmaf(cb[e], w[e], t);
-        v[e] = rv ? fmaxf(t, lo) : 0.f;
+        v[e] = rv ? clamp_lo(t, lo) : 0.f;
       }
       cvt_store8(Thi + r * PITCH + ch * 8, Tlo + r * PITCH + ch * 8, v, NS == 3);
     }
@@ -218,7 +218,7 @@ struct TrnStage {
         const int k = kg * 8 + e;
         float t = fmaf(ca, x[p][e], cc);
         if (HAS2) t = fmaf(cb, y[p][e], t);
-        v[e] = (rv && k < nvalid_k) ? fmaxf(t, lo) : 0.f;
+        v[e] = (rv && k < nvalid_k) ? clamp_lo(t, lo) : 0.f;
       }
       if (want_sum) csum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
       cvt_store8(Thi + r * PITCH + kg * 8, Tlo + r * PITCH + kg * 8, v, NS == 3);

@@ -134,10 +134,10 @@ int count_nonfinite(const float* x, long long n, int* count, hipStream_t st);
 int zero_fill(float* p, long long n, hipStream_t st);
 int zero_fill2(float* p, long long n, float* p2, int n2, hipStream_t st);   // + a second, small region
 int add2(const float* a, const float* b, float* out, long long n, hipStream_t st);
-int adam_prepare(const int* iterations, float lr0, float decay_rate, float decay_steps, float beta1, float beta2, float* scratch,
+int adam_prepare(const int* iterations, double lr0, double decay_rate, double decay_steps, double beta1, double beta2, float* scratch,
                  hipStream_t st);
-int adam_fused(float* p, const float* g, float* m, float* v, long long n, int* iterations, float lr0, float decay_rate, float decay_steps,
-               float beta1, float beta2, float eps, float grad_scale, float* scratch, hipStream_t st);
+int adam_fused(float* p, const float* g, float* m, float* v, long long n, int* iterations, double lr0, double decay_rate, double decay_steps,
+               double beta1, double beta2, double eps, float grad_scale, float* scratch, hipStream_t st);
 int dropout_masks(unsigned char* k1, long long n1, unsigned char* k2, long long n2, float rate, unsigned long long seed, unsigned* step,
                   hipStream_t st);
 int cloud_bias_grad(const float* bwd_part, const float* fwd_part, int B, int tpc, int N, int C, const float* ca, const float* cb,

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void colsum_lazy_kernel(const pn_operand x, in
 #pragma unroll
     for (int u = 0; u < 8; ++u) v[u] = x.s1[((long long)cloud * N + min(rb + u, r1 - 1)) * x.ld + c];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += (rb + u < r1) ? fmaxf(fmaf(ca, v[u], cc), x.lo) : 0.f;
+    for (int u = 0; u < 8; ++u) s += (rb + u < r1) ? clamp_lo(fmaf(ca, v[u], cc), x.lo) : 0.f;
   }
   red[wave][lane] = s;
   __syncthreads();
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(128) void maxbwd_dw_kernel(const DwBatch jb, int B,
           for (int u = 0; u < 8; ++u) v[u] = x.s1[srow[min(bb + u, nb - 1)] + k];
 #pragma unroll
           for (int u = 0; u < 8; ++u)
-            if (bb + u < nb) acc[kk] = fmaf(fmaxf(fmaf(ca, v[u], cc), x.lo), sw[bb + u], acc[kk]);
+            if (bb + u < nb) acc[kk] = fmaf(clamp_lo(fmaf(ca, v[u], cc), x.lo), sw[bb + u], acc[kk]);
         }
       }
     }

@@ -1033,12 +1033,12 @@ int pn_model_backward(const pn_model_desc* d, const pn_model_io* io, const float
   delete r;
   return rc;
 }
-int pn_adam_prepare(const int32_t* iterations, float* alpha_scratch, float lr0, float decay_rate, float decay_steps, float beta1, float beta2,
+int pn_adam_prepare(const int32_t* iterations, float* alpha_scratch, double lr0, double decay_rate, double decay_steps, double beta1, double beta2,
                     pn_stream stream) {
   return adam_prepare(iterations, lr0, decay_rate, decay_steps, beta1, beta2, alpha_scratch, reinterpret_cast<hipStream_t>(stream));
 }
-int pn_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int32_t* iterations, float* alpha_scratch, float lr0,
-                 float decay_rate, float decay_steps, float beta1, float beta2, float eps, float grad_scale, pn_stream stream) {
+int pn_adam_step(float* params, const float* grads, float* m, float* v, int64_t n, int32_t* iterations, float* alpha_scratch, double lr0,
+                 double decay_rate, double decay_steps, double beta1, double beta2, double eps, float grad_scale, pn_stream stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   PN_CHECK_ARG(iterations && alpha_scratch, "pn_adam_step: null pointer");
   return adam_fused(params, grads, m, v, n, iterations, lr0, decay_rate, decay_steps, beta1, beta2, eps, grad_scale, alpha_scratch, st);

@@ -23,27 +23,28 @@ __global__ void adam_schedule_kernel(int* __restrict__ iterations, float lr0, fl
 // adam_prepare at construction / after a restore, then kept current by this kernel), [2] ticket counter (uint32, zero).
 // The block that draws the last ticket -- every block has used scratch[0] by then -- advances the counter and evaluates the
 // schedule for the next step, so the fp64 pow()s are paid by one thread per step, off everyone else's path.
-__device__ __forceinline__ void adam_schedule_eval(int it, float lr0, float decay_rate, float decay_steps, float beta1, float beta2,
+__device__ __forceinline__ void adam_schedule_eval(int it, double lr0, double decay_rate, double decay_steps, double beta1, double beta2,
                                                    float* __restrict__ scratch) {
-  const double lr = (double)lr0 * pow((double)decay_rate, (double)it / (double)decay_steps);
+  const double lr = lr0 * pow(decay_rate, (double)it / decay_steps);
   const double t = (double)(it + 1);
-  scratch[0] = (float)(lr * sqrt(1.0 - pow((double)beta2, t)) / (1.0 - pow((double)beta1, t)));
+  scratch[0] = (float)(lr * sqrt(1.0 - pow(beta2, t)) / (1.0 - pow(beta1, t)));
   scratch[1] = (float)lr;
 }
-__global__ void adam_prepare_kernel(const int* __restrict__ iterations, float lr0, float decay_rate, float decay_steps, float beta1,
-                                    float beta2, float* __restrict__ scratch) {
+__global__ void adam_prepare_kernel(const int* __restrict__ iterations, double lr0, double decay_rate, double decay_steps, double beta1,
+                                    double beta2, float* __restrict__ scratch) {
   adam_schedule_eval(*iterations, lr0, decay_rate, decay_steps, beta1, beta2, scratch);
   reinterpret_cast<unsigned*>(scratch)[2] = 0u;
 }
 __global__ __launch_bounds__(1024) void adam_fused_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                         float* __restrict__ v, long long n, int* __restrict__ iterations, float lr0,
-                                                         float decay_rate, float decay_steps, float beta1, float beta2, float eps,
+                                                         float* __restrict__ v, long long n, int* __restrict__ iterations, double lr0,
+                                                         double decay_rate, double decay_steps, double beta1, double beta2, float eps,
                                                          float grad_scale, float* __restrict__ scratch) {
   const float alpha = scratch[0];
+  const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);      // keras: the Python float 1 - beta, cast to fp32
   for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < n; i += (long long)gridDim.x * 1024) {
     const float gi = g[i] * grad_scale;
-    const float mi = m[i] + (gi - m[i]) * (1.f - beta1);
-    const float vi = v[i] + (gi * gi - v[i]) * (1.f - beta2);
+    const float mi = m[i] + (gi - m[i]) * omb1;
+    const float vi = v[i] + (gi * gi - v[i]) * omb2;
     m[i] = mi;
     v[i] = vi;
     p[i] -= mi * alpha / (sqrtf(vi) + eps);
@@ -217,21 +218,21 @@ int adam(float* p, const float* g, float* m, float* v, long long n, const float*
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
-int adam_prepare(const int* iterations, float lr0, float decay_rate, float decay_steps, float beta1, float beta2, float* scratch,
+int adam_prepare(const int* iterations, double lr0, double decay_rate, double decay_steps, double beta1, double beta2, float* scratch,
                  hipStream_t st) {
   PN_CHECK_ARG(iterations && scratch, "pn_adam_prepare: null pointer");
   hipLaunchKernelGGL(adam_prepare_kernel, dim3(1), dim3(1), 0, st, iterations, lr0, decay_rate, decay_steps, beta1, beta2, scratch);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
-int adam_fused(float* p, const float* g, float* m, float* v, long long n, int* iterations, float lr0, float decay_rate, float decay_steps,
-               float beta1, float beta2, float eps, float grad_scale, float* scratch, hipStream_t st) {
+int adam_fused(float* p, const float* g, float* m, float* v, long long n, int* iterations, double lr0, double decay_rate, double decay_steps,
+               double beta1, double beta2, double eps, float grad_scale, float* scratch, hipStream_t st) {
   PN_CHECK_ARG(p && g && m && v && iterations && scratch && n > 0, "pn_adam_step: bad arguments");
   // 256 blocks of 1024 threads: one per CU at full occupancy, and only 256 tickets on the counter (a same-address atomic costs
   // ~11 ns: 2048 blocks spent 22 us of a 43 us launch queueing on it)
   const long long blocks = cdivll(n, 1024);
   hipLaunchKernelGGL(adam_fused_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(1024), 0, st, p, g, m, v, n, iterations, lr0,
-                     decay_rate, decay_steps, beta1, beta2, eps, grad_scale, scratch);
+                     decay_rate, decay_steps, beta1, beta2, (float)eps, grad_scale, scratch);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

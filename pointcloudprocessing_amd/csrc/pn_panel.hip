@@ -205,7 +205,7 @@ __global__ __launch_bounds__(128 * RG) void panel_max_kernel(const PanelArgs g) 
       bf16x8 hv, lv;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const float t = rv ? fmaxf(fmaf(ca[e], v[e], cc[e]), lo) : 0.f;
+        const float t = rv ? clamp_lo(fmaf(ca[e], v[e], cc[e]), lo) : 0.f;
         hv[e] = (__bf16)t;
         if (NS == 3) lv[e] = (__bf16)(t - (float)hv[e]);
       }

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restric
     for (int u = 0; u < 8; ++u) {
       float d = fmaf(ca, y[u], cc);
       d = fmaf(cb, zz[u], d);
-      d = (rb + u < r1) ? fmaxf(d, dz.lo) : 0.f;
+      d = (rb + u < r1) ? clamp_lo(d, dz.lo) : 0.f;
       g0 = fmaf(xa[u], d, g0);
       g1 = fmaf(xb[u], d, g1);
       g2 = fmaf(xc[u], d, g2);
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void max_finalize_kernel(const float* __restri
   }
   const float zs = (sgn[c] < 0.f ? -1.f : 1.f) * best;   // sgn may be gamma itself
   const long long o = (long long)b * C + c;
-  g[o] = fmaxf(fmaf(scale[c], zs, shift[c]), 0.f);
+  g[o] = clamp_lo(fmaf(scale[c], zs, shift[c]), 0.f);
   if (zstar) zstar[o] = zs;
   if (arg) arg[o] = (bi >= 0 && bi < n_rows) ? bi : 0;   // NaN inputs leave no winner: keep the index in range
 }

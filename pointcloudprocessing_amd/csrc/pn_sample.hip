@@ -1,10 +1,9 @@
-// Point-cloud downsampling for dense scans: farthest point sampling and voxel-grid centroids (gfx950).
+// Point-cloud downsampling for dense scans: farthest point sampling (gfx950); the voxel grid is in pn_voxel.hip.
 // The reference has neither (its only resize is truncate / random duplicate,
 // pointcloud/PointCloudSet.py:443-470); the specification is build-defined and stated in pointnet_hip.h,
 // with NumPy oracles in oracle/sampling_oracle.py.
 #include <cstring>
 #include "pn_common.h"
-#include <rocprim/device/device_radix_sort.hpp>
 
 namespace pn {
 int zero_fill(float* p, long long n, hipStream_t st);   // pn_optim.hip
@@ -256,151 +255,5 @@ int fps(const float* xyz, int B, int N, int M, int start_idx, int* idx_out, floa
   }
   return PN_OK;
 }
-
-// ------------------------------------------------------------------------------------------------------
-// voxel grid
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void voxel_keys_kernel(const float* __restrict__ xyz, int N, float lx, float ly, float lz, float ox,
-                                                         float oy, float oz, unsigned long long* __restrict__ keys,
-                                                         int* __restrict__ vals, int* __restrict__ err) {
-#pragma clang fp contract(off)
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= N) return;
-  const float fx = floorf((xyz[3 * i] - ox) / lx);
-  const float fy = floorf((xyz[3 * i + 1] - oy) / ly);
-  const float fz = floorf((xyz[3 * i + 2] - oz) / lz);
-  const float lim = 2097152.f;  // 2^21
-  if (!(fx >= 0.f && fx < lim && fy >= 0.f && fy < lim && fz >= 0.f && fz < lim)) atomicExch(err, 1);
-  const unsigned long long kx = (unsigned long long)fminf(fmaxf(fx, 0.f), lim - 1.f);
-  const unsigned long long ky = (unsigned long long)fminf(fmaxf(fy, 0.f), lim - 1.f);
-  const unsigned long long kz = (unsigned long long)fminf(fmaxf(fz, 0.f), lim - 1.f);
-  keys[i] = (kz << 42) | (ky << 21) | kx;
-  vals[i] = i;
-}
-
-// single block: segment heads of the sorted keys -> seg_start[], n_out
-__global__ __launch_bounds__(1024) void voxel_heads_kernel(const unsigned long long* __restrict__ keys, int N, int* __restrict__ seg_start,
-                                                           int* __restrict__ n_out) {
-  __shared__ int wsum[16];
-  __shared__ int carry;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) carry = 0;
-  __syncthreads();
-  for (int c0 = 0; c0 < N; c0 += 1024) {
-    const int i = c0 + tid;
-    const int flag = (i < N) && (i == 0 || keys[i] != keys[i - 1]);
-    int v = flag;   // inclusive scan inside the wave
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int t = __shfl_up(v, o, 64);
-      if (lane >= o) v += t;
-    }
-    if (lane == 63) wsum[wave] = v;
-    __syncthreads();
-    int off = carry;
-    for (int w = 0; w < wave; ++w) off += wsum[w];
-    if (flag) seg_start[off + v - 1] = i;
-    __syncthreads();
-    if (tid == 1023) carry = off + v;
-    __syncthreads();
-  }
-  if (tid == 0) {
-    seg_start[carry] = N;
-    *n_out = carry;
-  }
-}
-
-__global__ __launch_bounds__(256) void voxel_reduce_kernel(const float* __restrict__ xyz, const int* __restrict__ labels,
-                                                           const int* __restrict__ sorted_idx, const int* __restrict__ seg_start,
-                                                           const int* __restrict__ n_out, int n_labels, float* __restrict__ centroids,
-                                                           int* __restrict__ counts, int* __restrict__ majority) {
-  const int v = blockIdx.x * 256 + threadIdx.x;
-  if (v >= *n_out) return;
-  const int s = seg_start[v], e = seg_start[v + 1];
-  double sx = 0.0, sy = 0.0, sz = 0.0;
-  int hist[32];
-#pragma unroll
-  for (int l = 0; l < 32; ++l) hist[l] = 0;
-  for (int t = s; t < e; ++t) {
-    const int i = sorted_idx[t];
-    sx += (double)xyz[3 * i]; sy += (double)xyz[3 * i + 1]; sz += (double)xyz[3 * i + 2];
-    if (labels) {
-      const int l = labels[i];
-      if (l >= 0 && l < n_labels) hist[l]++;
-    }
-  }
-  const double inv = 1.0 / (double)(e - s);
-  centroids[3 * v] = (float)(sx * inv);
-  centroids[3 * v + 1] = (float)(sy * inv);
-  centroids[3 * v + 2] = (float)(sz * inv);
-  if (counts) counts[v] = e - s;
-  if (majority) {
-    int best = 0, bl = labels ? 0 : -1;
-    if (labels)
-      for (int l = 0; l < n_labels; ++l)
-        if (hist[l] > best) { best = hist[l]; bl = l; }
-    majority[v] = bl;
-  }
-}
-
-static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
-
-struct VoxelLayout {
-  size_t keys_in, keys_out, idx_in, idx_out, seg, err, tmp, tmp_bytes, total;
-};
-
-static VoxelLayout voxel_layout(int N) {
-  VoxelLayout L;
-  size_t off = 0;
-  L.err = off; off += 256;
-  L.keys_in = off; off += align256((size_t)N * 8);
-  L.keys_out = off; off += align256((size_t)N * 8);
-  L.idx_in = off; off += align256((size_t)N * 4);
-  L.idx_out = off; off += align256((size_t)N * 4);
-  L.seg = off; off += align256((size_t)(N + 1) * 4);
-  size_t tb = 0;
-  unsigned long long* k = nullptr;
-  int* v = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, tb, k, k, v, v, (size_t)N, 0, 63, (hipStream_t)0);
-  L.tmp = off; L.tmp_bytes = tb; off += align256(tb);
-  L.total = off;
-  return L;
-}
-
-size_t voxel_workspace_bytes(int N) { return N > 0 ? voxel_layout(N).total : 0; }
-
-int voxel_downsample(const float* xyz, const int* labels, int N, const float* leaf, const float* origin, int n_labels,
-                     float* centroids, int* counts, int* majority, int* n_out, void* ws, size_t ws_bytes, hipStream_t st) {
-  PN_CHECK_ARG(xyz && leaf && origin && centroids && n_out, "pn_voxel_downsample: null pointer");
-  PN_CHECK_ARG(N > 0, "pn_voxel_downsample: N must be positive (N=%d)", N);
-  PN_CHECK_ARG(leaf[0] > 0.f && leaf[1] > 0.f && leaf[2] > 0.f, "pn_voxel_downsample: leaf sizes must be positive");
-  PN_CHECK_ARG(n_labels >= 0 && n_labels <= 32, "pn_voxel_downsample: n_labels %d outside [0,32]", n_labels);
-  const VoxelLayout L = voxel_layout(N);
-  PN_CHECK_ARG(ws && ws_bytes >= L.total, "pn_voxel_downsample: workspace too small (%zu < %zu)", ws_bytes, L.total);
-  char* w = reinterpret_cast<char*>(ws);
-  int* err = reinterpret_cast<int*>(w + L.err);
-  unsigned long long* kin = reinterpret_cast<unsigned long long*>(w + L.keys_in);
-  unsigned long long* kout = reinterpret_cast<unsigned long long*>(w + L.keys_out);
-  int* iin = reinterpret_cast<int*>(w + L.idx_in);
-  int* iout = reinterpret_cast<int*>(w + L.idx_out);
-  int* seg = reinterpret_cast<int*>(w + L.seg);
-  PN_TRY(zero_fill(reinterpret_cast<float*>(err), 1, st));
-  hipLaunchKernelGGL(voxel_keys_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, xyz, N, leaf[0], leaf[1], leaf[2], origin[0],
-                     origin[1], origin[2], kin, iin, err);
-  PN_CHECK_LAUNCH();
-  size_t tb = L.tmp_bytes;
-  if (rocprim::radix_sort_pairs(w + L.tmp, tb, kin, kout, iin, iout, (size_t)N, 0, 63, st) != hipSuccess) {
-    set_error("pn_voxel_downsample: radix sort failed");
-    return PN_ERR_LAUNCH;
-  }
-  hipLaunchKernelGGL(voxel_heads_kernel, dim3(1), dim3(1024), 0, st, kout, N, seg, n_out);
-  PN_CHECK_LAUNCH();
-  hipLaunchKernelGGL(voxel_reduce_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, xyz, labels, iout, seg, n_out, n_labels, centroids,
-                     counts, majority);
-  PN_CHECK_LAUNCH();
-  return PN_OK;
-}
-
-int voxel_error_flag_offset() { return 0; }
 
 }  // namespace pn

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(SEG_RPB) void seg_out_fwd_kernel(const pn_operand x
         seg_bf16x8 ah, al;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const float a = fmaxf(fmaf(ca[k0 + e], v[e], cc[k0 + e]), x.lo);
+          const float a = clamp_lo(fmaf(ca[k0 + e], v[e], cc[k0 + e]), x.lo);
           ah[e] = (__bf16)a;
           al[e] = (__bf16)(a - (float)ah[e]);
         }
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(SEG_RPB) void seg_out_fwd_kernel(const pn_operand x
 #pragma unroll 4
       for (int k = 0; k < K; k += 4) {
         const float4 v = *reinterpret_cast<const float4*>(src + k);
-        const float a0 = fmaxf(fmaf(ca[k], v.x, cc[k]), x.lo), a1 = fmaxf(fmaf(ca[k + 1], v.y, cc[k + 1]), x.lo);
-        const float a2 = fmaxf(fmaf(ca[k + 2], v.z, cc[k + 2]), x.lo), a3 = fmaxf(fmaf(ca[k + 3], v.w, cc[k + 3]), x.lo);
+        const float a0 = clamp_lo(fmaf(ca[k], v.x, cc[k]), x.lo), a1 = clamp_lo(fmaf(ca[k + 1], v.y, cc[k + 1]), x.lo);
+        const float a2 = clamp_lo(fmaf(ca[k + 2], v.z, cc[k + 2]), x.lo), a3 = clamp_lo(fmaf(ca[k + 3], v.w, cc[k + 3]), x.lo);
 #pragma unroll
         for (int c = 0; c < SEG_CM; ++c) {
           acc[c] = fmaf(a0, ws[k * SEG_CM + c], acc[c]);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(SEG_RPB) void seg_out_fwd_kernel(const pn_operand x
 #pragma unroll
       for (int c = 0; c < SEG_CM; ++c)
         if (c < C) {
-          const float pc = fminf(fmaxf(p[c], 1e-7f), 1.f - 1e-7f);
+          const float pc = clip_nan(p[c], 1e-7f, 1.f - 1e-7f);
           qs += pc;
           if (c == y) py = pc;
         }
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(SEG_RPB) void seg_out_fwd_kernel(const pn_operand x
       for (int c = 0; c < SEG_CM; ++c) {
         dp[c] = 0.f;
         if (c < C) {
-          const float pc = fminf(fmaxf(p[c], 1e-7f), 1.f - 1e-7f);
+          const float pc = clip_nan(p[c], 1e-7f, 1.f - 1e-7f);
           const bool inr = (p[c] > 1e-7f) && (p[c] < 1.f - 1e-7f);
           dp[c] = inr ? (pc / qs - (c == y ? 1.f : 0.f)) / p[c] : 0.f;
           dot = fmaf(p[c], dp[c], dot);
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, co
     const long long row = (long long)cloud * N + r;
     const float z = x.s1[row * x.ld + k];
     const float pre = fmaf(ca, z, cc);
-    const float a = fmaxf(pre, lo);
+    const float a = clamp_lo(pre, lo);
     // the row is the same for every lane of a wave (stream = threadIdx.x >> 7), but only readfirstlane lets the compiler see it:
     // the 12 gradient values then come through scalar loads instead of 12 vector loads of one address per row
     const float* dl = dlogits + ((long long)cloud * N + __builtin_amdgcn_readfirstlane(r)) * C;

@@ -61,20 +61,27 @@ class TrainStep:
         self._mask_step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.mode = "eager"
         self._g1 = self._g1b = self._g2 = None
-        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
-        # capture needs a created stream; a caller-supplied null stream only replays
-        self._capture_stream = self.stream if self.stream.cuda_stream != 0 else torch.cuda.Stream(device=dev)
-        # optional second stream for the parameter-gradient kernels of the backward pass (pn_model_io.aux_stream).
-        # Bit-identical results; measured at B=32, N=1024 it does not pay on ROCm 7.2 (graph cross-branch edges cost more
-        # than the overlap wins: 1.52-1.68 ms vs 1.54 ms/step), so it is off by default.
-        self.aux_stream = torch.cuda.Stream(device=dev) if aux else None
+        # A host-memory model has no streams or graphs: only the step SEQUENCE runs (forward/backward phases, the bucketed
+        # all-reduce schedule, the optimizer).  The product never builds one -- PointNet refuses to compute without a HIP device --
+        # but it lets tests/test_cpu_train.py drive this very schedule over gloo with world_size 2.
+        self.on_gpu = dev.type == "cuda"
+        self.stream = self._capture_stream = self.aux_stream = None
+        if self.on_gpu:
+            self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
+            # capture needs a created stream; a caller-supplied null stream only replays
+            self._capture_stream = self.stream if self.stream.cuda_stream != 0 else torch.cuda.Stream(device=dev)
+            # optional second stream for the parameter-gradient kernels of the backward pass (pn_model_io.aux_stream).
+            # Bit-identical results; measured at B=32, N=1024 it does not pay on ROCm 7.2 (graph cross-branch edges cost more
+            # than the overlap wins: 1.52-1.68 ms vs 1.54 ms/step), so it is off by default.
+            self.aux_stream = torch.cuda.Stream(device=dev) if aux else None
+        use_graph = use_graph and self.on_gpu
         self._use_graph = use_graph
         self._calls = 0           # the first two steps run eagerly (they warm up allocator / lazy init), then the step is captured
 
     # -- pieces ---------------------------------------------------------------------------------------------
     def _fwd_bwd(self, phase: int = 0):
         rate = self.model._dropout_rate
-        if rate > 0:        # one native launch; the step counter lives on the device, so graph replays draw fresh masks
+        if rate > 0 and self.on_gpu:        # one native launch; the step counter lives on the device, so graph replays draw fresh masks
             check(lib().pn_dropout_masks(ptr(self.keep[0]), self.keep[0].numel(), ptr(self.keep[1]), self.keep[1].numel(), rate,
                                          self._mask_seed, ptr(self._mask_step), current_stream()), "pn_dropout_masks")
         self.model._aux_stream = self.aux_stream
@@ -93,23 +100,30 @@ class TrainStep:
 
     def _reduce_async(self, lo, hi):
         """RCCL sum over xGMI of one gradient bucket; runs on RCCL's stream behind everything enqueued so far"""
-        if not self.reduce or hi <= lo:
+        if not self.reduce:
             return None
         if not self.overlap:
             if lo != 0:
-                return None                                   # single collective: issued with the second bucket
+                return None                                   # single collective: issued with the second bucket (lo == 0), even an empty one
             # a synchronous collective: recent PyTorch runs it on the CURRENT stream (no cross-stream fence at all)
             self.dist.all_reduce(self.model.grads_flat)
             return None
+        if hi <= lo:
+            return None
         return self.dist.all_reduce(self.model.grads_flat[lo:hi], async_op=True)
 
-    @staticmethod
-    def _wait_last(*handles):
+    def _wait_last(self, *handles):
         """the collectives of one process group run in order on one RCCL stream: waiting for the last issued one is enough, and
-        every cross-stream wait costs ~50-100 us on this stack"""
+        every cross-stream wait costs ~50-100 us on this stack.  Other backends (gloo, in the CPU tests) complete their asynchronous
+        collectives in any order: there every handle is waited for."""
         live = [h for h in handles if h is not None]
-        if live:
+        if not live:
+            return
+        if self.dist.get_backend() == "nccl":
             live[-1].wait()
+        else:
+            for h in live:
+                h.wait()
 
     def _eager(self):
         if not self.split:
@@ -156,24 +170,32 @@ class TrainStep:
     # fences exist only for callers on another stream; the trainer and bench.py run their loops under
     # ``torch.cuda.stream(step.stream)`` and pay nothing.
     def _enter(self):
+        if not self.on_gpu:
+            return
         cur = torch.cuda.current_stream(self.dev)
         if cur.cuda_stream != self.stream.cuda_stream:
             self.stream.wait_stream(cur)                                 # whatever produced the batch / read the last results
 
     def _exit(self):
+        if not self.on_gpu:
+            return
         cur = torch.cuda.current_stream(self.dev)
         if cur.cuda_stream != self.stream.cuda_stream:
             cur.wait_stream(self.stream)                                 # the caller may read scalars / weights on its stream
 
+    def _on_stream(self):
+        import contextlib
+        return torch.cuda.stream(self.stream) if self.on_gpu else contextlib.nullcontext()
+
     def load(self, pc, y_cls, y_seg, se3):
         self._enter()
-        with torch.cuda.stream(self.stream):
+        with self._on_stream():
             self.pc.copy_(pc, non_blocking=True)
             self.y_cls.copy_(y_cls, non_blocking=True)
             self.y_seg.copy_(y_seg.reshape(self.B, self.N), non_blocking=True)
             self.se3.copy_(se3, non_blocking=True)
         for t in (pc, y_cls, y_seg, se3):
-            if t.is_cuda:
+            if t.is_cuda and self.on_gpu:
                 t.record_stream(self.stream)
 
     def run(self):
@@ -183,7 +205,7 @@ class TrainStep:
             self._capture()                                     # capture only records; the replay below executes step 3
             self._use_graph = self._g1 is not None
         self._enter()
-        with torch.cuda.stream(self.stream):
+        with self._on_stream():
             if self._g1 is None:
                 self._eager()
             else:
@@ -200,7 +222,7 @@ class TrainStep:
     def run_eager(self):
         """the same step launched kernel by kernel (bench.py times the dominant kernel with HIP events this way)"""
         self._enter()
-        with torch.cuda.stream(self.stream):
+        with self._on_stream():
             self._eager()
         self._exit()
 

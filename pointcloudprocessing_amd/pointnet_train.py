@@ -22,8 +22,9 @@ rank (standard DDP practice); the moving statistics are averaged across ranks at
 Reference defects tolerated, not replicated: missing ``vanilla`` / ``monitor`` keys default
 to False / ``val_loss``; an invalid path raises ``ValueError`` instead of returning a half-built object; the log
 file name has no ':'; no stdin prompt when no GPU is present -- without a HIP device training refuses to start,
-because there is no CPU compute path.  ONNX export (pointnet_train.py:238-248) needs onnx/tf2onnx, absent here: skipped
-with a log line.
+because there is no CPU compute path.  The ONNX export of every profile (pointnet_train.py:238-248) is written by
+onnx_export.py (hand-encoded protobuf, opset 13); `continue_training_model` accepts such a file as well as a .pt checkpoint.
+The .keras container (zip of config.json + HDF5 weights) is not written: it needs an HDF5 writer (h5py), absent here.
 """
 from __future__ import annotations
 
@@ -96,7 +97,18 @@ class HipEngine:
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.device = torch.device("cuda", torch.cuda.current_device())
         p = cfg['params']
-        if checkpoint:
+        if checkpoint and checkpoint.endswith(".onnx"):
+            # an exported inference graph (onnx_export.py) keeps every raw parameter under its canonical name
+            from .onnx_export import read_onnx_weights
+            w = read_onnx_weights(checkpoint)
+            self.model = PN.PointNet(classification_output_width=int(w["mlp_cls_3.kernel"].shape[1]),
+                                     segmentation_output_width=int(w["mlp_seg_5.kernel"].shape[1]), dropout_rate=0.3,
+                                     random_seed=p['random_seed'], debugging=p.get('debugging', False),
+                                     vanilla="input_transform.w" not in w,
+                                     regularize_input_transform=p.get('regularize_input_transform', False),
+                                     regularize_feature_transform=p.get('regularize_feature_transform', False), precision=precision)
+            self.model.set_weights({k: torch.from_numpy(v) for k, v in w.items()})
+        elif checkpoint:
             payload = torch.load(checkpoint, map_location="cpu", weights_only=True)
             mc = dict(payload["config"])
             mc["precision"] = precision
@@ -382,7 +394,9 @@ class TrainProfile:
                             self._log.info(f"Epoch {epoch + 1}: early stopping")
                             break
                     keyboard_interrupt.on_epoch_end(epoch, logs)
-                    if keyboard_interrupt.stop_training:
+                    # a Ctrl-C reaches the ranks at different times: every rank must take the same branch here, or one leaves for the
+                    # barrier below while the others enter the next epoch's all-reduce and the job hangs
+                    if self._any_rank(keyboard_interrupt.stop_training, engine):
                         break
                 if best_weights is not None:
                     engine.set_weights(best_weights)    # EarlyStopping(restore_best_weights=True)
@@ -390,12 +404,34 @@ class TrainProfile:
             if self._rank == 0:
                 with open(f"{self._model_path}{pd['path']}{self._name}_{prof}_history.json", 'w') as j:
                     json.dump(history, j)
-                self._log.info("ONNX export skipped: onnx / tf2onnx are not available in this environment")
+                # reference :238-248: tf2onnx.convert.from_keras(model, input_signature=[(None, input_width, 3)], opset=13) of the restored
+                # best weights -> <name>_<prof>.onnx.  Written by onnx_export.py (hand-encoded protobuf; numeric parity unpinned).
+                if best_weights is not None:
+                    try:
+                        from .onnx_export import export_onnx
+                        onnx_path = f"{self._model_path}{pd['path']}{self._name}_{prof}.onnx"
+                        export_onnx({k: np.asarray(v, dtype=np.float32) for k, v in best_weights.items()}, self._input_width, onnx_path,
+                                    vanilla=not any(k.startswith("input_transform.") for k in best_weights))
+                        self._log.info(f"ONNX model (opset 13) written to {onnx_path}")
+                    except Exception as e:            # the reference logs and carries on as well (:246-248)
+                        self._log.info(f"ONNX export failed: {e}")
                 shutil.copy(self._config_file, f"{self._model_path}{pd['path']}")
             self._pretrained_model = f"{pd['path']}{self._name}_{prof}.pt"
             if distributed:
                 dist.barrier()
         return True
+
+    @staticmethod
+    def _any_rank(flag: bool, engine) -> bool:
+        """logical OR of a per-rank flag over the process group (MAX all-reduce); the flag itself without one"""
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return bool(flag)
+        dev = getattr(engine, "device", None)
+        t = torch.tensor([1.0 if flag else 0.0], device=dev if dev is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return bool(t.item() > 0)
 
     def _profile_datasets(self, profile) -> None:
         pd = self._training_profiles[profile]

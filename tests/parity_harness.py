@@ -10,10 +10,15 @@ rounding of 0 or two points tie within rounding.  (1) The GPU's decisions must e
 pre-activation is below `near_zero`; (2) the GPU's decisions are imposed on the oracle and every loss, output, moving statistic,
 stored activation gradient and parameter gradient is compared.
 
-Arithmetic modes: 'bf16x3' (16 significant bits per MFMA operand) is compared with the fp64 oracle; 'bf16' (BASELINE config C2)
-with the fp64 oracle whose per-point matmul operands are rounded to bf16 (`quant=O.bf16_round`: the same rounding points as the
-MFMA operands of the forward pass; the backward pass of the GPU also rounds its dz / activation operands, which the oracle's
-autograd does not -- hence the wider gradient tolerance stated by the caller).
+Arithmetic modes and tolerances.  The GPU is compared with oracle B = the fp64 oracle whose per-point matmul operands (K >= 64) are
+rounded the way the GPU's mode rounds its MFMA operands (`quant=O.bf16_round` for 'bf16', BASELINE config C2; `O.bf16x3_round` for
+'bf16x3').  B cannot be met exactly: an activation that differs by one fp32 rounding between GPU and oracle can land on the other
+side of a bf16 rounding boundary, the backward pass of the GPU also rounds dz / activations (the oracle's autograd does not), and the
+batch-statistics BatchNormalization of the T-Net dense layers (rows = B clouds, eps 1e-3) amplifies any difference by up to
+1/sqrt(var + eps) per layer.  How much those roundings matter for a given case is MEASURED, not guessed: oracle A = the same fp64
+oracle without operand rounding, and `spread` = |A - B| per quantity is the sensitivity of that quantity to the mode's operand
+rounding.  A quantity passes when  |gpu - B| <= max(absolute tolerance, spread_factor * spread).  A wrong formula, index or scale
+shows up as an error far above the spread; the ratio err / spread is written to gpurun_out/model_report.txt for every quantity.
 """
 import os
 
@@ -97,7 +102,7 @@ def apply_profile(m, spec):
 
 
 def check_training_step(dev, B, N, profile, vanilla=False, precision="bf16x3", reg=False, seed_params=12, seed_inputs=6,
-                        tol_grad=5e-3, tol_fwd=3e-4, tol_loss=2e-3, tol_stats=2e-3, near_zero=1e-2, with_cond=True, tag=None):
+                        tol_grad=5e-3, tol_fwd=3e-4, tol_loss=2e-3, tol_stats=2e-3, near_zero=1e-2, spread_factor=1.0, tag=None):
     """runs one fused_loss_step on the GPU and the oracle, returns (worst relative gradient error, model); raises AssertionError
     with the list of failed quantities."""
     tag = tag or f"train[{profile},vanilla={vanilla},{precision},B={B},N={N},reg={reg}]"
@@ -109,9 +114,9 @@ def check_training_step(dev, B, N, profile, vanilla=False, precision="bf16x3", r
     tr = oracle_trainable(spec)
     if "it" not in spec and not spec.get("shared", True):
         tr["input_transform"] = False
-    quant = O.bf16_round if precision == "bf16" else None
+    quant_b = O.bf16_round if precision == "bf16" else O.bf16x3_round
     okw = dict(training=True, trainable=tr, vanilla=vanilla, dropout_masks=keep, regularize_input_transform=reg and not vanilla,
-               regularize_feature_transform=reg and not vanilla, quant=quant)
+               regularize_feature_transform=reg and not vanilla)
     m = build_model(dev, params, vanilla, precision=precision, reg=reg)
     apply_profile(m, spec)
     kp = (keep["dropout_1"].to(torch.uint8).to(dev), keep["dropout_2"].to(torch.uint8).to(dev))
@@ -148,52 +153,60 @@ def check_training_step(dev, B, N, profile, vanilla=False, precision="bf16x3", r
         mask.scatter_(1, arg.long().unsqueeze(1), (ws(wn + ".g").view(B, 1024) > 0).unsqueeze(1))
         decisions[(on if on.startswith("mlp") else on + ".conv3") + ".relu"] = mask
 
-    p64 = {k: v.double().requires_grad_(O.is_trainable_name(k) and tr.get(O.block_of(k), True)) for k, v in params.items()}
-    # (1) the oracle's own decisions, to see where they differ from the GPU's
-    _, ctx_free = O.forward({k: v.double() for k, v in params.items()}, pc.double(), return_ctx=True, **okw)
+    targets = {"classification_output": y_cls, "segmentation_output": y_seg, "se3": se3.double()}
+
+    def oracle(quant):
+        """the fp64 oracle with the GPU's decisions imposed: outputs, losses, moving statistics, every gradient"""
+        p64 = {k: v.double().requires_grad_(O.is_trainable_name(k) and tr.get(O.block_of(k), True)) for k, v in params.items()}
+        outs, ctx = O.forward(p64, pc.double(), return_ctx=True, decisions=decisions, quant=quant, **okw)
+        loss, parts = O.total_loss(outs, targets, dict(classification=lw[0], segmentation=lw[1], rotation=lw[2]), ctx.reg_losses)
+        names = [k for k, t in p64.items() if t.requires_grad]
+        tapn = [k for k, t in ctx.taps.items() if (k.endswith(".y") or k.endswith(".z")) and t.requires_grad]
+        allg = torch.autograd.grad(loss, [p64[k] for k in names] + [ctx.taps[k] for k in tapn], allow_unused=True)
+        return dict(outs=[o.detach() for o in outs], ctx=ctx, parts={k: float(v) for k, v in parts.items()}, grads=dict(zip(names, allg[:len(names)])),
+                    tapg=dict(zip(tapn, allg[len(names):])), reg=[float(r) for r in ctx.reg_losses],
+                    stats={k: v.detach() for k, v in ctx.new_stats.items()})
+
+    Bq = oracle(quant_b)             # the GPU mode's operand rounding: what the GPU is compared with
+    ctx = Bq["ctx"]
+    A = oracle(None)                 # exact operands: the sensitivity reference; only small results are kept
+    y_spread = {}
+    for on in list(conv_map) + [(o if o.startswith("mlp") else o + ".conv3") for o in max_map]:
+        y_spread[on] = float((A["ctx"].taps[on + ".y"].detach() - ctx.taps[on + ".y"].detach()).abs().max())
+    A.pop("ctx"); A.pop("tapg")
     fails = []
+
+    def judge(name, err, spread, tol_abs, scale=1.0):
+        """err, spread absolute; tol_abs relative to `scale`"""
+        lim = max(tol_abs * scale, spread_factor * spread)
+        report(f"{tag} {name:44s} err {err:.3e}  spread(A,B) {spread:.3e}  limit {lim:.3e}  err/limit {err / (lim + 1e-300):.2f}")
+        if not err <= lim:
+            fails.append((name, err, lim))
+
+    # (1) the GPU's decisions are valid ones: against the pre-activations of oracle B (earlier decisions imposed, so nothing cascades)
+    #     a ReLU sign may differ only where |y| is within `near_zero`, and the arg-max row's value must reach the true maximum within it
     for on in conv_map:
-        y = ctx_free.taps[on + ".y"]
+        y = ctx.taps[on + ".y"].detach()
         diff = (y > 0) != decisions[on + ".relu"]
-        if diff.any():
-            worst_flip = float(y[diff].abs().max())
-            if not worst_flip < near_zero:                      # only near-zero pre-activations may flip
-                fails.append((on + ".relu decision", worst_flip))
-        report(f"{tag} relu decisions differing from the free oracle in {on}: {int(diff.sum())}")
-    # the arg-max rows: wherever the GPU's row is not the free oracle's, the two rows' values must tie within rounding
+        worst_flip = float(y[diff].abs().max()) if diff.any() else 0.0
+        lim = max(near_zero, spread_factor * y_spread[on])
+        report(f"{tag} relu decisions of {on}: {int(diff.sum())} of {diff.numel()} differ from oracle B, largest |y| among them {worst_flip:.3e} (limit {lim:.3e})")
+        if not worst_flip < lim:
+            fails.append((on + ".relu decision", worst_flip))
     for on, wn in max_map.items():
         pref = on if on.startswith("mlp") else on + ".conv3"
-        yfree = ctx_free.taps[pref + ".y"]                          # (B, N, 1024) BN output in front of the ReLU
+        yb = torch.relu(ctx.taps[pref + ".y"].detach())              # (B, N, 1024)
         arg = decisions[on + ".argmax"].long()
-        v_gpu = torch.relu(yfree).gather(1, arg.unsqueeze(1)).squeeze(1)
-        v_max = torch.relu(yfree).amax(1)
-        gap = float((v_max - v_gpu).abs().max())
-        report(f"{tag} arg-max rows of {on}: {int((torch.relu(yfree).argmax(1) != arg).sum())} differ from the free oracle, worst value gap {gap:.3e}")
-        if not gap < near_zero:
+        gap = float((yb.amax(1) - yb.gather(1, arg.unsqueeze(1)).squeeze(1)).abs().max())
+        lim = max(near_zero, spread_factor * y_spread[pref])
+        report(f"{tag} arg-max rows of {on}: {int((yb.argmax(1) != arg).sum())} of {arg.numel()} differ from oracle B, worst value gap {gap:.3e} (limit {lim:.3e})")
+        if not gap < lim:
             fails.append((on + ".argmax decision", gap))
-    del ctx_free
-    # (2) the oracle with the GPU's decisions imposed
-    outs, ctx = O.forward(p64, pc.double(), return_ctx=True, decisions=decisions, **okw)
-    targets = {"classification_output": y_cls, "segmentation_output": y_seg, "se3": se3.double()}
-    loss, parts = O.total_loss(outs, targets, dict(classification=lw[0], segmentation=lw[1], rotation=lw[2]), ctx.reg_losses)
-    names = [k for k, t in p64.items() if t.requires_grad]
-    tapn = [k for k, t in ctx.taps.items() if (k.endswith(".y") or k.endswith(".z")) and t.requires_grad]
-    allg = torch.autograd.grad(loss, [p64[k] for k in names] + [ctx.taps[k] for k in tapn], allow_unused=True)
-    grads = dict(zip(names, allg[:len(names)]))
-    tapg = dict(zip(tapn, allg[len(names):]))
-    cond = 0.0
-    if with_cond:   # how ill-conditioned is this case?  fp32 oracle vs fp64 oracle on the same step
-        p32 = {k: v.float() for k, v in params.items()}
-        outs32 = O.forward(p32, pc, **okw)
-        cond = max(float((outs32[i].double() - outs[i].detach()).abs().max()) for i in range(3))
-        report(f"{tag} fp32-oracle vs fp64-oracle forward spread {cond:.3e}")
-        del outs32
-    # forward in training mode
+        del yb
+    # (2) continuous quantities against oracle B, tolerance widened by the measured sensitivity |A - B|
     for i, nm in enumerate(["cls", "seg", "R"]):
-        e = float((outs_g[i].cpu().double() - outs[i].detach()).abs().max())
-        report(f"{tag} forward {nm} max abs err {e:.3e}")
-        if not e < max(tol_fwd, 30 * cond):
-            fails.append((nm, e))
+        judge(f"forward {nm}", float((outs_g[i].cpu().double() - Bq["outs"][i]).abs().max()),
+              float((A["outs"][i] - Bq["outs"][i]).abs().max()), tol_fwd)
     taps = {"pcn": "pcn", "global": "mm23.g"}
     if not vanilla:
         taps.update({"input_transform.global": "iT.m3.g", "feature_transform.global": "fT.m3.g", "x64": "X64", "R64": "fT.R"})
@@ -208,6 +221,7 @@ def check_training_step(dev, B, N, profile, vanilla=False, precision="bf16x3", r
     if not vanilla:
         lay.update({"feature_transform.conv2": "fT.c2", "feature_transform.conv1": "fT.c1", "input_transform.conv2": "iT.c2",
                     "input_transform.conv1": "iT.c1"})
+    tapg = Bq["tapg"]
     for oname, wname in lay.items():
         gy, gz = tapg.get(oname + ".y"), tapg.get(oname + ".z")
         if gy is None or gz is None:
@@ -221,24 +235,20 @@ def check_training_step(dev, B, N, profile, vanilla=False, precision="bf16x3", r
         ez = float((dz - gz.reshape(-1, C_)).abs().max() / (gz.abs().max() + 1e-30))
         report(f"{tag} act-grad {oname:28s} dyhat rel err {ey:.3e}   dz rel err {ez:.3e}")
     sc = m.scalars.cpu().double()
-    if abs(sc[0] / B - float(parts["classification_output_loss"])) > tol_loss: fails.append(("cls loss", float(sc[0] / B)))
-    if abs(sc[2] / (B * N) - float(parts["segmentation_output_loss"])) > tol_loss: fails.append(("seg loss", float(sc[2] / (B * N))))
-    if abs(sc[4] / (B * 9) - float(parts["se3_loss"])) > tol_loss: fails.append(("se3 loss", float(sc[4] / (B * 9)), float(parts["se3_loss"])))
+    pa, pb = A["parts"], Bq["parts"]
+    judge("cls loss", abs(float(sc[0] / B) - pb["classification_output_loss"]), abs(pa["classification_output_loss"] - pb["classification_output_loss"]), tol_loss)
+    judge("seg loss", abs(float(sc[2] / (B * N)) - pb["segmentation_output_loss"]), abs(pa["segmentation_output_loss"] - pb["segmentation_output_loss"]), tol_loss)
+    judge("se3 loss", abs(float(sc[4] / (B * 9)) - pb["se3_loss"]), abs(pa["se3_loss"] - pb["se3_loss"]), tol_loss)
     if reg and not vanilla:          # the two orthogonality regularisers, PointNet.py:447-451 (add_loss terms)
         for i, nm in ((0, "input_transform reg"), (1, "feature_transform reg")):
-            ref = float(ctx.reg_losses[i])
-            got = float(sc[5 + i])
-            report(f"{tag} {nm}: gpu {got:.6e} oracle {ref:.6e}")
-            if not abs(got - ref) < 2e-3 * max(abs(ref), 1e-6) + 1e-7:
-                fails.append((nm, got, ref))
+            judge(nm, abs(float(sc[5 + i]) - Bq["reg"][i]), abs(A["reg"][i] - Bq["reg"][i]), 2e-3, scale=max(abs(Bq["reg"][i]), 1e-6))
     # moving statistics
     nw = m.named_weights()
-    for k, v in ctx.new_stats.items():
-        e = rel_err(nw[k], v)
-        if not e < tol_stats:
-            fails.append((k, e))
+    for k, v in Bq["stats"].items():
+        sc_ = float(v.abs().max()) + 1e-12
+        judge(k, float((nw[k].double().cpu() - v).abs().max()), float((A["stats"][k] - v).abs().max()), tol_stats, scale=sc_)
     for k in params:
-        if ("moving" in k) and k not in ctx.new_stats:
+        if ("moving" in k) and k not in Bq["stats"]:
             assert torch.equal(nw[k].cpu(), params[k]), f"frozen statistic {k} changed"
     # gradients
     ng = m.named_grads()
@@ -247,19 +257,17 @@ def check_training_step(dev, B, N, profile, vanilla=False, precision="bf16x3", r
         if not O.is_trainable_name(k):
             continue
         g = ng[k].cpu().double()
-        if k in grads and grads[k] is not None:
-            pieces = [(k, g, grads[k])]
+        if k in Bq["grads"] and Bq["grads"][k] is not None:
+            ga = A["grads"][k]
+            pieces = [(k, g, Bq["grads"][k], ga)]
             if k == "mlp_seg_1.kernel":
-                pieces = [(k + "[:64]", g[:64], grads[k][:64]), (k + "[64:]", g[64:], grads[k][64:])]
-            for nm, gg, r in pieces:
+                pieces = [(k + "[:64]", g[:64], Bq["grads"][k][:64], ga[:64]), (k + "[64:]", g[64:], Bq["grads"][k][64:], ga[64:])]
+            for nm, gg, r, ra in pieces:
                 scale = float(r.abs().max())
                 e = float((gg - r).abs().max())
-                rel = e / (scale + 1e-9)
-                report(f"{tag} grad {nm:40s} ref_max={scale:.3e} abs_err={e:.3e} rel={rel:.3e}")
                 if scale > 1e-6:
-                    worst = max(worst, rel)
-                    if not rel < tol_grad:
-                        fails.append((nm, rel, scale))
+                    worst = max(worst, e / scale)
+                    judge("grad " + nm, e, float((ra - r).abs().max()), tol_grad, scale=scale)
                 elif not e < 1e-5:
                     fails.append((nm, e))
         else:

@@ -1,0 +1,187 @@
+"""Model artefact interop: the ONNX export of the inference graph (reference pointnet_train.py:238-248) and what the
+reference itself still holds about its exported model -- the tf2onnx graph dump its training run logged.
+
+* the oracle's layer table and the HIP library's parameter slots against that dump (tests/golden/ref_tf2onnx_graph_f15.json, made
+  by tests/golden/make_graph_fixture.py from models/f15_scale_lidar/log_20260126_16*0916.log:220-2227): op histogram, every Conv2D /
+  MatMul / BatchMatMulV2 kernel shape in graph order, placeholder and output shapes.  This pins the STRUCTURE of oracle and product
+  to the reference; numeric parity stays unpinned (no reference-held numbers exist).
+* the file written by pointcloudprocessing_amd.onnx_export: parsed back with an independent reader, same op histogram as the dump,
+  evaluated with a NumPy interpreter of the dozen ONNX ops it uses and compared with the oracle's inference outputs; its
+  initializers restore every parameter bit for bit.  NUMERIC PARITY UNPINNED: no onnxruntime in this image."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import pointnet_oracle as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+FIX = json.load(open(os.path.join(HERE, "golden", "ref_tf2onnx_graph_f15.json")))
+CCLS, CSEG, NREF = 23, 12, 8192
+
+
+def _nodes(op):
+    return [n for n in FIX["nodes"] if n["op"] == op]
+
+
+def test_reference_graph_dump_histogram():
+    h = FIX["op_histogram_of_dumped_nodes"]
+    assert h == FIX["tensorflow_ops_counter"]                      # the parser saw every node the converter counted
+    # the figures SURVEY.md 2.2 quotes
+    assert (h["Conv2D"], h["MatMul"], h["BatchMatMulV2"], h["Max"], h["Relu"], h["Softmax"]) == (16, 7, 4, 4, 21, 2)
+    assert (h["Tile"], h["ConcatV2"], h["Mean"], h["Sub"], h["Square"], h["Sum"], h["Sqrt"], h["Maximum"], h["RealDiv"]) == (1,) * 9
+    ph = _nodes("Placeholder")
+    assert len(ph) == 1 and ph[0]["outputs"][0]["shape"] == [-1, NREF, 3]
+    outs = sorted(n["inputs"][0]["shape"] for n in _nodes("Identity") if n["name"] in ("Identity", "Identity_1", "Identity_2"))
+    assert outs == sorted([[-1, CCLS], [-1, 3, 3], [-1, NREF, CSEG]])
+
+
+def test_oracle_layer_table_matches_reference_graph():
+    table = O.layer_table(CCLS, CSEG)
+    convs = [(cin, cout) for _, kind, cin, cout, _ in table if kind == "conv"]
+    denses = [(cin, cout) for _, kind, cin, cout, _ in table if kind == "dense"]
+    ref_convs = [tuple(n["inputs"][1]["shape"][2:]) for n in _nodes("Conv2D")]
+    assert all(n["inputs"][1]["shape"][:2] == [1, 1] for n in _nodes("Conv2D"))      # 1x1 kernels (PointNet.py:535)
+    assert ref_convs == convs                                                          # same layers, same order as PointNet.call
+    ref_dense = [tuple(n["inputs"][1]["shape"]) for n in _nodes("MatMul")]
+    assert ref_dense == denses
+    # the four batched products: T-Net tails x @ w (256, K^2) and the two transform applications (PointNet.py:207,228,437)
+    bm = [(n["inputs"][0]["shape"], n["inputs"][1]["shape"]) for n in _nodes("BatchMatMulV2")]
+    assert bm == [([-1, 1, 256], [256, 9]), ([-1, NREF, 3], [-1, 3, 3]), ([-1, 1, 256], [256, 4096]), ([-1, NREF, 64], [-1, 64, 64])]
+    # the reduce_max inputs: the normalisation radius and three (B, N, 1024) tensors
+    assert [n["inputs"][0]["shape"] for n in _nodes("Max")] == [[-1, NREF]] + [[-1, NREF, 1024]] * 3
+    # the 21 ReLUs = every BN'd conv / dense layer (15 + 6)
+    assert sum(1 for _, _, _, _, bn in table if bn) == len(_nodes("Relu")) == 21
+
+
+def test_hip_parameter_slots_match_reference_graph():
+    """pn_model_slot_info (host-only code of libpointnet_hip.so: no GPU needed) describes the same kernels as the reference graph"""
+    from pointcloudprocessing_amd import _lib
+    l = _lib.lib()
+    d = _lib.pn_model_desc(ccls=CCLS, cseg=CSEG, vanilla=0, reg_in=0, reg_feat=0, prec=_lib.PN_PREC_BF16, dropout_rate=0.3,
+                           bn_momentum=0.99, bn_eps=1e-3)
+    slots = []
+    for i in range(l.pn_model_num_slots(C.byref(d))):
+        s = _lib.pn_slot_info()
+        assert l.pn_model_slot_info(C.byref(d), i, C.byref(s)) == 0
+        slots.append((s.name.decode(), s.rows, s.cols, s.kind))
+    kernels = [(n, r, c) for n, r, c, k in slots if k == 0]
+    per_point = [(r, c) for n, r, c in kernels if ("conv" in n or n.startswith(("mlp_1", "mlp_2", "mlp_seg")))]
+    per_cloud = [(r, c) for n, r, c in kernels if ("dense" in n or n.startswith("mlp_cls"))]
+    assert per_point == [tuple(n["inputs"][1]["shape"][2:]) for n in _nodes("Conv2D")]
+    assert per_cloud == [tuple(n["inputs"][1]["shape"]) for n in _nodes("MatMul")]
+    tw = [(r, c) for n, r, c, k in slots if k == 6]
+    assert tw == [(256, 9), (256, 4096)]
+    n_bn = sum(1 for n, r, c, k in slots if k == 1)
+    assert n_bn == 21
+
+
+# ---- a NumPy interpreter for the ops the export uses (independent of the writer: works from the parsed file only) --------------
+def _run_onnx(model, feed):
+    env = dict(model["initializers"])
+    env.update(feed)
+    for nd in model["nodes"]:
+        i = [env[x] for x in nd["inputs"]]
+        a, op = nd["attrs"], nd["op"]
+        if op == "ReduceMean":
+            o = i[0].mean(axis=tuple(a["axes"]), keepdims=bool(a["keepdims"]))
+        elif op == "ReduceMax":
+            o = i[0].max(axis=tuple(a["axes"]), keepdims=bool(a["keepdims"]))
+        elif op == "ReduceSum":
+            o = i[0].sum(axis=tuple(int(v) for v in i[1]), keepdims=bool(a["keepdims"]))
+        elif op == "Sub":
+            o = i[0] - i[1]
+        elif op == "Add":
+            o = i[0] + i[1]
+        elif op == "Mul":
+            o = i[0] * i[1]
+        elif op == "Div":
+            o = i[0] / i[1]
+        elif op == "Max":
+            o = np.maximum(i[0], i[1])
+        elif op == "Sqrt":
+            o = np.sqrt(i[0])
+        elif op == "Relu":
+            o = np.maximum(i[0], 0)
+        elif op == "Identity":
+            o = i[0]
+        elif op == "MatMul":
+            o = np.matmul(i[0], i[1])
+        elif op == "Transpose":
+            o = np.transpose(i[0], a["perm"])
+        elif op == "Reshape":
+            shp = [i[0].shape[k] if int(v) == 0 else int(v) for k, v in enumerate(i[1])]
+            o = i[0].reshape(shp)
+        elif op == "Expand":
+            o = i[0] * np.ones([int(v) for v in i[1]], dtype=i[0].dtype)
+        elif op == "Concat":
+            o = np.concatenate(i, axis=a["axis"])
+        elif op == "Conv":
+            assert a["kernel_shape"] == [1, 1]
+            w = i[1].reshape(i[1].shape[0], i[1].shape[1])
+            o = np.einsum("bcnw,oc->bonw", i[0], w)
+            if len(i) > 2:
+                o = o + i[2].reshape(1, -1, 1, 1)
+        elif op == "BatchNormalization":
+            shp = [1, -1] + [1] * (i[0].ndim - 2)
+            sc, b, mu, var = (t.reshape(shp) for t in i[1:5])
+            o = (i[0] - mu) / np.sqrt(var + a["epsilon"]) * sc + b
+        elif op == "Softmax":
+            z = i[0] - i[0].max(axis=a["axis"], keepdims=True)
+            e = np.exp(z)
+            o = e / e.sum(axis=a["axis"], keepdims=True)
+        else:
+            raise AssertionError(f"op {op} is not in the export's vocabulary")
+        env[nd["outputs"][0]] = o
+    return [env[n] for n, _ in model["outputs"]]
+
+
+def _export(tmp_path, vanilla, N):
+    from pointcloudprocessing_amd import onnx_export as X
+    params = O.init_params(CCLS, CSEG, seed=7, vanilla=vanilla, randomize_bn=True)
+    path = str(tmp_path / "m.onnx")
+    X.export_onnx({k: v.numpy() for k, v in params.items()}, N, path, vanilla=vanilla)
+    return X, params, path
+
+
+def test_onnx_export_structure_and_weights_round_trip(tmp_path):
+    X, params, path = _export(tmp_path, False, NREF)
+    m = X.parse_model(open(path, "rb").read())
+    assert m["ir_version"] == 7 and m["opset"] == 13              # opset=13, pointnet_train.py:242
+    assert m["inputs"] == [("pointnet_input", ["unk__batch", NREF, 3])]               # PointNet.py:113, input_signature :241
+    assert m["outputs"] == [("classification_output", ["unk__batch", CCLS]), ("segmentation_output", ["unk__batch", NREF, CSEG]),
+                            ("se3", ["unk__batch", 3, 3])]                           # PointNet.py:114
+    h = {}
+    for nd in m["nodes"]:
+        h[nd["op"]] = h.get(nd["op"], 0) + 1
+    ref = FIX["tensorflow_ops_counter"]
+    assert h["Conv"] == ref["Conv2D"] == 16
+    assert h["MatMul"] == ref["MatMul"] + ref["BatchMatMulV2"] == 11
+    assert h["ReduceMax"] == ref["Max"] == 4
+    assert h["Relu"] == ref["Relu"] == 21 and h["Softmax"] == ref["Softmax"] == 2
+    assert h["Concat"] == ref["ConcatV2"] == 1 and h["Expand"] == ref["Tile"] == 1
+    assert h["BatchNormalization"] == 21 and h["Identity"] == 3
+    # Conv kernels in graph order carry the reference's kernel shapes, transposed to ONNX's (Cout, Cin, 1, 1)
+    convs = [m["initializers"][nd["inputs"][1]].shape for nd in m["nodes"] if nd["op"] == "Conv"]
+    assert [(s[1], s[0]) for s in convs] == [tuple(n["inputs"][1]["shape"][2:]) for n in _nodes("Conv2D")]
+    # every parameter comes back bit for bit
+    w = X.read_onnx_weights(path)
+    assert set(w) == set(params)
+    for k, v in params.items():
+        assert w[k].shape == tuple(v.shape) and np.array_equal(w[k], v.numpy()), k
+
+
+def test_onnx_export_evaluates_to_the_oracle(tmp_path):
+    for vanilla in (False, True):
+        N, B = 96, 3
+        X, params, path = _export(tmp_path, vanilla, N)
+        m = X.parse_model(open(path, "rb").read())
+        g = torch.Generator().manual_seed(3)
+        pc = (torch.rand(B, N, 3, generator=g) * 30 - 10).float()
+        ref = O.forward({k: v.double() for k, v in params.items()}, pc.double(), training=False, vanilla=vanilla)
+        out = _run_onnx(m, {"pointnet_input": pc.numpy().astype(np.float64)})
+        for got, want in zip(out, ref):
+            assert got.shape == tuple(want.shape)
+            assert np.abs(got - want.numpy()).max() < 1e-6

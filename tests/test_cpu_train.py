@@ -182,6 +182,11 @@ def test_trainer_end_to_end_artifacts_and_stage_chaining(tmp_path):
     for prof in ("classification_pretrain", "final"):
         pd = d + f"models/unit/{prof}/"
         assert os.path.isfile(pd + f"unit_{prof}.pt") and os.path.isfile(pd + "unit_config.json")
+        # the ONNX export of the profile's best weights (pointnet_train.py:238-248): same parameters as the checkpoint
+        from pointcloudprocessing_amd.onnx_export import read_onnx_weights
+        ow = read_onnx_weights(pd + f"unit_{prof}.onnx")
+        ck = torch.load(pd + f"unit_{prof}.pt", weights_only=True)["weights"]
+        assert set(ow) == set(ck) and all(np.array_equal(ow[k], ck[k].numpy()) for k in ck)
         h = json.load(open(pd + f"unit_{prof}_history.json"))
         assert set(h.keys()) == set(T.HISTORY_KEYS) | {"val_" + k for k in T.HISTORY_KEYS}
         assert all(len(v) == 2 and all(np.isfinite(v)) for v in h.values())
@@ -269,3 +274,80 @@ def test_data_parallel_world_size_2_gloo(tmp_path):
     res = json.load(open(out))
     assert res == {"ok": True, "identical": True, "world": 2}
     assert len(glob.glob(d + "models/unit/final/unit_final_history.json")) == 1
+
+
+SCHEDULE_SCRIPT = textwrap.dedent("""
+    import json, os, sys
+    sys.path.insert(0, {root!r})
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    from pointcloudprocessing_amd.engine import TrainStep
+
+    N_PARAMS, CUT = 4099, 1031                      # odd sizes: the buckets are not multiples of anything
+    base = torch.arange(N_PARAMS, dtype=torch.float64).add(1).sqrt().float()
+
+    class StubModel:
+        '''stands in for PointNet on host memory: the backward phases fill known, rank-dependent gradients into the flat buffer,
+        exactly where pn_model_backward's phases leave theirs (phase 1: [cut, end), phase 2: [0, cut))'''
+        def __init__(self):
+            self.params_flat = torch.zeros(N_PARAMS)
+            self.grads_flat = torch.zeros(N_PARAMS)
+            self._dropout_rate = 0.0
+            self._aux_stream = None
+            self.calls = []
+        def grad_bucket_boundary(self):
+            return CUT
+        def fused_loss_step(self, pc, y_cls, y_seg, se3, lw, keep=None, backward_phase=0):
+            self.calls.append(("fwd+bwd", backward_phase))
+            self.grads_flat.fill_(float("nan"))            # anything the schedule forgets to produce or reduce stays visible
+            self.grads_flat[CUT:] = base[CUT:] * (rank + 1)
+            if backward_phase == 0:
+                self.grads_flat[:CUT] = base[:CUT] * (rank + 1)
+        def _run_backward(self, a, b, c, phase):
+            self.calls.append(("bwd", phase))
+            self.grads_flat[:CUT] = base[:CUT] * (rank + 1)
+
+    class StubAdam:
+        def __init__(self):
+            self.seen = []
+        def step(self, grads, scale=1.0):
+            self.seen.append((grads * scale).clone())
+
+    out = {{}}
+    for overlap in ("1", "0"):
+        os.environ["PN_DDP_OVERLAP"] = overlap
+        m, opt = StubModel(), StubAdam()
+        ts = TrainStep(m, opt, 2, 8, (1.0, 0.0, 0.0), use_graph=True)        # graphs are a GPU matter: a host model runs the bare sequence
+        assert ts.split and ts.reduce and ts.world == world and ts.mode == "eager"
+        for _ in range(3):
+            ts.run()
+        want = base * sum(r + 1 for r in range(world)) / world               # the mean over ranks: sum all-reduce, then 1/world in Adam
+        ok_value = all(torch.allclose(g, want, rtol=1e-6, atol=0) for g in opt.seen) and len(opt.seen) == 3
+        both = [torch.zeros(N_PARAMS) for _ in range(world)]
+        dist.all_gather(both, opt.seen[-1])
+        out[overlap] = dict(value=bool(ok_value), identical=bool(torch.equal(both[0], both[1])),
+                            order=m.calls[:2] == [("fwd+bwd", 1), ("bwd", 2)], n_calls=len(m.calls))
+    if rank == 0:
+        json.dump(out, open({out!r}, "w"))
+    dist.barrier()
+    dist.destroy_process_group()
+""")
+
+
+def test_product_bucket_schedule_world_size_2_gloo(tmp_path):
+    """engine.TrainStep's own step sequence -- backward phase 1, all-reduce of the bucket [cut, end) issued asynchronously, backward
+    phase 2, all-reduce of [0, cut), wait, Adam with grad_scale = 1/world (and the single synchronous collective of PN_DDP_OVERLAP=0)
+    -- run by two gloo ranks on a host-memory stand-in model whose phases fill known per-rank gradients: every element of what Adam
+    receives is the mean over ranks and is bit-identical on both ranks."""
+    out = str(tmp_path / "sched.json")
+    script = str(tmp_path / "sched.py")
+    open(script, "w").write(SCHEDULE_SCRIPT.format(root=ROOT, out=out))
+    env = dict(os.environ, OMP_NUM_THREADS="2", CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", script], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    res = json.load(open(out))
+    for overlap in ("1", "0"):
+        assert res[overlap] == {"value": True, "identical": True, "order": True, "n_calls": 6}, (overlap, res)

@@ -8,11 +8,12 @@ PARITY UNPINNED against the reference itself (see tests/parity_harness.py): the 
   C4  PointNet-cls  per-rank shape of the 8-GPU run: B=8, N=4096                        -- bf16x3 and bf16
   C1  the trainer entry point at its named size (N=1024, batch 4) is in tests/test_gpu_train.py
 
-Tolerances.  bf16x3 (16 significant bits per operand) vs the fp64 oracle: gradients 5e-3 of each tensor's max (measured ~1e-4),
-training-mode outputs 3e-4.  bf16 vs the fp64 oracle with bf16-rounded matmul operands: the forward pass shares its rounding points
-with the oracle (outputs 5e-3); the backward pass of the GPU additionally rounds dz and the activations to bf16 (the oracle's
-autograd does not), so gradients are held to 4e-2 of each tensor's max, the bound bf16's 2^-9 relative operand rounding gives over
-K <= 1024-term contractions.
+Tolerances (tests/parity_harness.py has the reasoning): every quantity is compared with the fp64 oracle run with the GPU mode's
+operand rounding (oracle B) and passes when its error is below max(absolute tolerance, measured sensitivity), the sensitivity being
+|oracle without operand rounding - oracle B| for that very quantity.  Absolute tolerances: bf16x3 gradients 5e-3 of each tensor's
+max and training-mode outputs 3e-4; bf16 gradients 2e-2, outputs 5e-3.  At these batch shapes the T-Net dense layers' batch
+statistics (rows = B) make the feature transform sensitive to bf16 rounding (R_64 moves by ~1e-2 between oracle A and B at B = 32),
+which is a property of the reference model in reduced precision, not of the kernels: the sensitivity term covers exactly that.
 """
 import math
 
@@ -24,8 +25,8 @@ pytestmark = pytest.mark.gpu
 from oracle import pointnet_oracle as O   # noqa: E402  (checker only)
 from parity_harness import CCLS, CSEG, build_model, check_training_step, make_inputs, report   # noqa: E402
 
-BF16 = dict(tol_grad=4e-2, tol_fwd=5e-3, tol_loss=5e-3, tol_stats=5e-3, near_zero=3e-2, with_cond=False)
-X3 = dict(tol_grad=5e-3, tol_fwd=3e-4, with_cond=False)
+BF16 = dict(tol_grad=2e-2, tol_fwd=5e-3, tol_loss=5e-3, tol_stats=5e-3, near_zero=3e-2)
+X3 = dict(tol_grad=5e-3, tol_fwd=3e-4)
 
 
 @pytest.mark.parametrize("name,B,N,profile,precision,tol", [

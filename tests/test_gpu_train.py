@@ -163,3 +163,59 @@ def test_batched_backward_launches_do_not_change_a_bit(dev):
     assert differing(digest(), base) == []                       # the step itself is reproducible from process to process
     for switch in ("PN_WGRAD_BATCH", "PN_SLAB_DEFER", "PN_GW_BATCH", "PN_PM_SMALL"):
         assert differing(digest(**{switch: 0}), base) == [], switch
+
+
+_RCCL_SCRIPT = r"""
+import json, os, sys, torch
+sys.path.insert(0, {root!r})
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+import torch.distributed as dist
+dev = torch.device("cuda:0")
+torch.cuda.set_device(dev)
+dist.init_process_group(backend="nccl", device_id=dev, rank=0, world_size=1)
+from pointcloudprocessing_amd.engine import TrainStep
+from pointcloudprocessing_amd.optim import KerasAdam
+from pointcloudprocessing_amd.pointnet.PointNet import PointNet
+B, N = 8, 256
+g = torch.Generator().manual_seed(0)
+pc = (torch.rand(B, N, 3, generator=g) * 10).to(dev)
+y_cls = torch.randint(0, 23, (B,), generator=g, dtype=torch.int32).to(dev)
+y_seg = torch.randint(0, 12, (B, N), generator=g, dtype=torch.int32).to(dev)
+se3 = torch.eye(3).expand(B, 3, 3).contiguous().to(dev)
+finals, modes, w0 = [], [], None
+for split in (False, True, True):
+    os.environ["PN_DDP_OVERLAP"] = "1" if len(finals) < 2 else "0"
+    m = PointNet(23, 12, 0.0, 42, precision="bf16", device=dev)
+    if w0 is None:
+        w0 = m.params_flat.data.clone()
+    else:
+        m.params_flat.data.copy_(w0)
+    opt = KerasAdam(m.params_flat.data, 1e-3, 7000, 0.7)
+    ts = TrainStep(m, opt, B, N, (1.0, 1.0, 1.0), use_graph=True, split_optimizer=split)
+    assert ts.reduce == split
+    for i in range(12):
+        ts(pc, y_cls, y_seg, se3)
+    torch.cuda.synchronize()
+    finals.append(m.params_flat.data.clone()); modes.append(ts.mode)
+print("RESULT", json.dumps(dict(modes=modes, same_overlapped=bool(torch.equal(finals[0], finals[1])),
+                                same_single=bool(torch.equal(finals[0], finals[2])), finite=bool(torch.isfinite(finals[1]).all()),
+                                moved=float((finals[0] - w0).abs().max()))))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_world_size_1_split_graph_step_equals_fused_step(dev):
+    """the data-parallel layout of a step with a REAL RCCL process group (world_size 1, one fresh child process): graph 1 (forward +
+    backward phase 1) -> asynchronous all-reduce of the bucket [cut, end) -> graph 1b (backward phase 2) -> all-reduce of [0, cut) ->
+    wait -> graph 2 (Adam), captured with RCCL's watchdog thread alive (capture_error_mode="thread_local", engine.py), against the
+    fused single-graph step: the weights after 12 steps must be bit-identical, for the overlapped and the single-collective form."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", _RCCL_SCRIPT.format(root=root)], capture_output=True, text=True, timeout=420,
+                         env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][0][len("RESULT "):])
+    assert res["modes"] == ["hipgraph"] * 3 and res["finite"] and res["moved"] > 0
+    assert res["same_overlapped"] and res["same_single"], res

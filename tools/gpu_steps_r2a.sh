@@ -1,0 +1,5 @@
+out=$1
+timeout -k 10 900 python -m pytest tests/test_gpu_parity_configs.py tests/test_gpu_train.py -q -m gpu --durations=15 > $out/tests_new.log 2>&1; echo "new tests rc=$?" | tee -a $out/summary.txt
+timeout -k 10 600 python -m pytest tests -q -m gpu -x --deselect tests/test_gpu_parity_configs.py --deselect tests/test_gpu_train.py > $out/tests_old.log 2>&1; echo "old tests rc=$?" | tee -a $out/summary.txt
+timeout -k 10 300 python bench.py > $out/bench.json 2> $out/bench.err; echo "bench rc=$?" | tee -a $out/summary.txt
+cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$out/prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $GRAFT_REPO_ROOT/$out/prof_bench.json 2> $GRAFT_REPO_ROOT/$out/prof.err; echo "prof rc=$?" | tee -a $GRAFT_REPO_ROOT/$out/summary.txt
