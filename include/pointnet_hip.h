@@ -111,19 +111,30 @@ int pn_conv_fwd(const pn_operand* x, const float* w, int64_t w_cloud_stride, int
 int pn_conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C, const float* sgn,
                     float* pmax, int32_t* pidx, float* stat_partials, int prec, pn_stream stream);
 
-/* --- the same layer as a ROW-PANEL kernel (the one the model plan uses): a workgroup owns 64 point rows for ALL C channels,
- * the activation panel is staged into LDS once and the kernel is streamed from a bf16 channel-major copy made by
- * pn_weights_prep (wb_hi[c][k] = bf16(W[k][c]); wb_lo = bf16(W - hi), needed for PN_PREC_BF16X3 only).
- * K in {64, 128}; tiles are 64 rows: n_tiles = B*ceil(N/64) for pmax / pidx / stat_partials. */
-int pn_weights_prep(const float* w, int K, int C, void* wb_hi, void* wb_lo, pn_stream stream);
-int pn_conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C,
-                          const float* sgn, float* pmax, int32_t* pidx, float* stat_partials, int prec, pn_stream stream);
-/* the same with taller panels (panel_rows = 64, 128 or 256; tiles = B * ceil(N / panel_rows)): every panel streams the whole bf16
- * kernel from L2, so a taller panel cuts that traffic.  The model plan uses 128, and 256 (bf16 operands only) once B * ceil(N/256)
- * still gives a workgroup per CU. */
-int pn_conv_fwd_max_panel_rows(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C,
-                               const float* sgn, float* pmax, int32_t* pidx, float* stat_partials, int prec, int panel_rows,
-                               pn_stream stream);
+/* --- the same layer as a ROW-PANEL kernel (the one the model plan uses; pn_panel.hip): a workgroup owns a panel of panel_rows
+ * (64 or 128) point rows for ALL C channels; the activation panel is staged into LDS once and every wave streams the kernel columns it
+ * owns from a fragment-ordered bf16 copy made by pn_weights_prep:
+ *     wf_hi[((cb * K/16 + ks) * 64 + lane) * 8 + j] = bf16(s_c * W[k][c]),  c = cb*32 + (lane & 31),  k = ks*16 + (lane >> 5)*8 + j
+ *     wf_lo = bf16(s_c * W - hi) (needed for PN_PREC_BF16X3 only);  s_c = -1 where sgn[c] < 0 (sgn may be gamma itself; NULL = +1).
+ * K in {64, 128}, C a multiple of 128; tiles = B * ceil(N / panel_rows).  Per tile and channel the kernel emits
+ *     pmax   = max over the tile's rows of s_c * z,      pblock = index inside the cloud of the 32-row block holding it (lowest on ties),
+ *     sumsq  = sum over the rows of z^2 and, per tile, a1 = column sums of the staged bf16 panel (K values; hi then lo image for
+ *     PN_PREC_BF16X3) from which the finaliser forms sum z = a1 . W[:, c]   (sumsq and a1: both or neither; NULL for inference). */
+int pn_weights_prep(const float* w, const float* sgn, int K, int C, void* wf_hi, void* wf_lo, pn_stream stream);
+int pn_conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo, int B, int N, int K, int C, float* pmax,
+                          int32_t* pblock, float* sumsq, float* a1, int prec, int panel_rows, pn_stream stream);
+/* finaliser of the panel kernel: BatchNormalization coefficients of the layer (as pn_bn_finalize; batch statistics from sumsq / a1 and
+ * the weight copy, or the moving statistics) AND tf.reduce_max over each cloud's tiles:  zstar[b][c] = s_c * max,
+ * g[b][c] = relu(scale*zstar + shift), arg_block[b][c] = the 32-row block of cloud b holding the row of the maximum. */
+int pn_panel_finalize(const float* pmax, const int32_t* pblock, const float* sumsq, const float* a1, const void* wf_hi, const void* wf_lo,
+                      int B, int N, int K, int C, int panel_rows, int prec, const float* gamma, const float* beta, float* moving_mean,
+                      float* moving_var, float momentum, float eps, int use_batch_stats, int update_moving, float* mean, float* invstd,
+                      float* scale, float* shift, float* g, float* zstar, int32_t* arg_block, pn_stream stream);
+/* the row of the maximum itself (needed by the backward pass only, where the model plan resolves it inside its scatter kernel):
+ * arg[b][c] = the row of cloud b, inside block arg_block[b][c], with the largest s_c * z -- the 32 candidates re-evaluated in fp32 from
+ * the same bf16-rounded operands, lowest row on ties (exact ties = duplicated points, as the reference's padding produces). */
+int pn_max_resolve(const pn_operand* x, const void* wf_hi, const void* wf_lo, const int32_t* arg_block, int B, int N, int K, int C,
+                   int32_t* arg, int prec, pn_stream stream);
 
 /* --- data gradient of a ConvLayer: out = [relu-mask] (dz . W^T + addend), plus the two partial sums
  * BatchNormalization's backward needs (sum dy_hat, sum dy_hat*z) per channel.

@@ -25,9 +25,13 @@ int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, i
                hipStream_t st, int colsum = 0);   // colsum: every slab is followed by Ci floats = sum over its rows of operand a
 
 // pn_panel.hip
-int weights_prep(const float* w, int K, int C, void* hi, void* lo, hipStream_t st);
-int conv_fwd_max_panel(const pn_operand* x, const void* wb_hi, const void* wb_lo, int B, int N, int K, int C, const float* sgn,
-                       float* pmax, int* pidx, float* stat_partials, int prec, hipStream_t st, int presigned = 0, int panel_rows = 64);
+int weights_prep(const float* w, const float* sgn, int K, int C, void* hi, void* lo, hipStream_t st);
+int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo, int B, int N, int K, int C, float* pmax, int* pq,
+                       float* sumsq, float* a1, int prec, int panel_rows, hipStream_t st);
+int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const float* a1, const void* wf_hi, const void* wf_lo, int B, int N,
+                   int K, int C, int panel_rows, int prec, const float* gamma, const float* beta, float* mm, float* mv, float momentum,
+                   float eps, int use_batch, int update, float* mean, float* invstd, float* scale, float* shift, float* g, float* zstar,
+                   int* argq, hipStream_t st);
 
 // pn_pointwise.hip
 int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st);
@@ -108,8 +112,10 @@ int maxbwd_dw_batch(const DwJob* jobs, int n_jobs, int B, int N, int K, int C, h
 int maxbwd_dw(const pn_operand* x, const int* arg, const float* hs, int B, int N, int K, int C, const float* a1, const float* f,
               const float* e, const float* GW, float* dW, hipStream_t st);
 int maxbwd_q(const float* w, const float* f, int K, int C, float* q, hipStream_t st);
-int maxbwd_scatter(const int* arg, const float* hs, const float* wt, const float* q, int B, int N, int K, int C, float* D,
-                   hipStream_t st);
+int maxbwd_scatter(const pn_operand* x, const void* wf_hi, const void* wf_lo, int prec, const int* argq, int* arg, const float* hs,
+                   const float* wt, const float* q, int B, int N, int K, int C, float* D, hipStream_t st);
+int max_resolve(const pn_operand* x, const void* wf_hi, const void* wf_lo, int prec, const int* argq, int B, int N, int K, int C, int* arg,
+                hipStream_t st);
 
 // pn_sample.hip
 size_t fps_workspace_bytes(int B, int N);

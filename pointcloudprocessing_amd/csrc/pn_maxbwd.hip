@@ -181,47 +181,170 @@ __global__ __launch_bounds__(64) void maxbwd_q_kernel(const float* __restrict__ 
   if (threadIdx.x == 0) q[k] = s;
 }
 
+// ---- the row of the maximum, found among the 32 candidates the forward pass left (pn_panel.hip) --------------------------------
+// The panel kernel records, per (cloud, channel), only WHICH 32-row block of the cloud held max_n sgn*z (argq).  The row itself is
+// needed by the backward pass alone and is found here: the block's 32 rows of the layer input (BN + ReLU applied, rounded to the
+// MFMA operand precision exactly as the panel kernel stages them) are put in LDS once per workgroup, and for every channel whose
+// maximum lies in this block a wave evaluates the 32 candidate pre-activations sgn*z = a . Wf[c] in fp32 and takes the largest,
+// lowest row on ties.  Duplicated points (the reference pads clouds with duplicates, PointCloudSet.py:459-463) give bit-identical
+// candidates, so the lowest index wins exactly as in the oracle; two DIFFERENT rows whose values agree to the last fp32 rounding
+// may resolve to either, which leaves zstar untouched (it is the panel kernel's exact maximum) and moves the gradient between two
+// rows of equal activation.
+typedef __attribute__((ext_vector_type(8))) __bf16 mb_bf16x8;
+constexpr int RS_PITCH = 129;                 // fp32 row pitch of the staged block (K <= 128): lanes <-> rows hit distinct banks
+
+// stage rows [rbase, rbase + nr) of cloud `cloud` (K columns): As_hi = the bf16-rounded activation as fp32, As_lo = its bf16 remainder
+template <int NT>
+__device__ __forceinline__ void resolve_stage(const pn_operand& x, int cloud, int N, int K, int rbase, int nr, float* __restrict__ As_hi,
+                                              float* __restrict__ As_lo, int tid, int nthreads) {
+  for (int i = tid; i < 32 * (K / 4); i += nthreads) {
+    const int row = i / (K / 4), k = (i % (K / 4)) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < nr) v = *reinterpret_cast<const float4*>(x.s1 + ((long long)cloud * N + rbase + row) * x.ld + k);
+    const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float ca = x.ca ? x.ca[k + e] : 1.f, cc = x.cc ? x.cc[k + e] : 0.f;
+      const float t = row < nr ? clamp_lo(fmaf(ca, vv[e], cc), x.lo) : 0.f;
+      const float hi = (float)(__bf16)t;
+      As_hi[row * RS_PITCH + k + e] = hi;
+      if (NT == 2) As_lo[row * RS_PITCH + k + e] = (float)(__bf16)(t - hi);
+    }
+  }
+}
+// one wave: the row (0..nr-1) of the largest candidate of channel c, lowest row on ties (0 if every candidate is NaN)
+template <int NT>
+__device__ __forceinline__ int resolve_row(const float* __restrict__ As_hi, const float* __restrict__ As_lo, const __bf16* __restrict__ wf_hi,
+                                           const __bf16* __restrict__ wf_lo, int c, int K, int nr, int lane) {
+  const int row = lane & 31, kh = lane >> 5, KS = K / 16;
+  const int cb = c >> 5, cl = c & 31;
+  float dot = 0.f;
+  for (int q = 0; q < K / 16; ++q) {              // this half-wave's K/2 values of k, eight at a time
+    const int k0 = kh * (K / 2) + q * 8;
+    const int ks = k0 >> 4, hh = (k0 >> 3) & 1;
+    const long long chunk = ((long long)cb * KS + ks) * 64 + hh * 32 + cl;
+    const mb_bf16x8 wh = *reinterpret_cast<const mb_bf16x8*>(wf_hi + chunk * 8);
+    mb_bf16x8 wl;
+    if (NT == 2) wl = *reinterpret_cast<const mb_bf16x8*>(wf_lo + chunk * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float ah = As_hi[row * RS_PITCH + k0 + j];
+      const float bh = (float)wh[j];
+      if (NT == 2) {
+        const float al = As_lo[row * RS_PITCH + k0 + j];
+        dot = fmaf(al, bh, dot);
+        dot = fmaf(ah, (float)wl[j], dot);
+      }
+      dot = fmaf(ah, bh, dot);
+    }
+  }
+  dot += __shfl_xor(dot, 32, 64);
+  const float mine = row < nr ? dot : -INFINITY;
+  float vmax = mine;
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
+  const unsigned long long hit = __ballot(mine == vmax && row < nr) & 0xffffffffull;
+  return hit ? (__ffsll((long long)hit) - 1) : 0;
+}
+
+// standalone form (op-level API pn_max_resolve; the model plan resolves inside maxbwd_scatter_kernel): one workgroup per 32-row block
+template <int NT>
+__global__ __launch_bounds__(256) void max_resolve_kernel(const pn_operand x, const __bf16* __restrict__ wf_hi, const __bf16* __restrict__ wf_lo,
+                                                          const int* __restrict__ argq, int N, int K, int C, int quarters_per_cloud,
+                                                          int* __restrict__ arg) {
+  __shared__ float As_hi[32 * RS_PITCH];
+  __shared__ float As_lo[NT == 2 ? 32 * RS_PITCH : 1];
+  __shared__ int hit_c[1024];
+  __shared__ int nhit;
+  const int bx = blockIdx.x, cloud = bx / quarters_per_cloud, qin = bx - cloud * quarters_per_cloud;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int rbase = qin * 32, nr = min(32, N - rbase);
+  bool staged = false;
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    if (t == 0) nhit = 0;
+    __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + 4 * t + i;
+      if (c < C && argq[(long long)cloud * C + c] == qin) hit_c[atomicAdd(&nhit, 1)] = c;
+    }
+    __syncthreads();
+    const int total = nhit;
+    if (total > 0 && !staged) {
+      resolve_stage<NT>(x, cloud, N, K, rbase, nr, As_hi, As_lo, t, 256);
+      staged = true;
+      __syncthreads();
+    }
+    for (int i = wave; i < total; i += 4) {
+      const int c = hit_c[i];
+      const int row = resolve_row<NT>(As_hi, As_lo, wf_hi, wf_lo, c, K, nr, lane);
+      if (lane == 0) arg[(long long)cloud * C + c] = rbase + row;
+    }
+    __syncthreads();
+  }
+}
+
 // D[m][k] = q[k] + sum_{c : arg[b][c] == m} hs[b][c] * Wt[c][k]        one block per 32-row quarter tile.
 // Critical points are few: the 1024 arg-max rows of a cloud concentrate on a handful of points, so a tile can
 // receive anything from 0 to C contributions, many of them on the same row.  Contributions are therefore accumulated
 // with LDS atomics in 2^-40 FIXED POINT (int64): integer addition is associative, so the result does not depend on
 // the order in which the four waves process the hits -> full parallelism AND bitwise reproducibility.
 // |hs*W| < 2^22 is assumed (the products are gradient-sized).  K <= 128, K % 4 == 0.
-__global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restrict__ arg, const float* __restrict__ hs,
+// The channels of this tile are those whose maximum the forward pass located in this 32-row block (argq); their exact rows are
+// resolved here first (resolve_row) and written to `arg` for the weight-gradient kernel and the tests.
+template <int NT>
+__global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const pn_operand x, const __bf16* __restrict__ wf_hi, const __bf16* __restrict__ wf_lo,
+                                                             const int* __restrict__ argq, int* __restrict__ arg, const float* __restrict__ hs,
                                                              const float* __restrict__ wt, const float* __restrict__ q, int N,
                                                              int K, int C, int quarters_per_cloud, float* __restrict__ D) {
   constexpr int CHUNK = 1024;                  // channels examined per round (4 per thread)
   constexpr double FX = 1099511627776.0;       // 2^40
   __shared__ unsigned long long tile[32][128]; // 32 KB
+  __shared__ float As_hi[32 * RS_PITCH];
+  __shared__ float As_lo[NT == 2 ? 32 * RS_PITCH : 1];
   __shared__ int hit_pk[CHUNK];                // (row << 16) | channel-in-chunk, unordered
   __shared__ int nhit;
   const int bx = blockIdx.x, cloud = bx / quarters_per_cloud, qin = bx - cloud * quarters_per_cloud;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int rbase = qin * 32, nr = min(32, N - rbase);
-  const int* ab = arg + (long long)cloud * C;
+  const int* qb = argq + (long long)cloud * C;
   const float* hb = hs + (long long)cloud * C;
   for (int i = t; i < 32 * 128; i += 256) (&tile[0][0])[i] = 0ull;
   if (t == 0) nhit = 0;
   __syncthreads();
+  bool staged = false;
   for (int c0 = 0; c0 < C; c0 += CHUNK) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = c0 + 4 * t + i;
-      const int m = (c < C) ? (ab[c] - rbase) : -1;
-      if (m >= 0 && m < nr) hit_pk[atomicAdd(&nhit, 1)] = (m << 16) | (4 * t + i);
+      if (c < C && qb[c] == qin) hit_pk[atomicAdd(&nhit, 1)] = 4 * t + i;
     }
     __syncthreads();
     const int total = nhit;
-    // wave w takes hits w, w+4, ...; eight of them (16 row loads per lane) are in flight at a time: the arg-max rows of a cloud
-    // concentrate on a few points, so some tiles carry hundreds of hits and the launch lasts as long as its heaviest tile
+    if (total > 0 && !staged) {                // block-uniform
+      resolve_stage<NT>(x, cloud, N, K, rbase, nr, As_hi, As_lo, t, 256);
+      staged = true;
+      __syncthreads();
+    }
+    // wave w owns hits w, w+4, ...: it resolves their rows, then scatters them (no other wave touches those entries)
+    for (int i = wave; i < total; i += 4) {
+      const int cc = hit_pk[i];
+      const int row = resolve_row<NT>(As_hi, As_lo, wf_hi, wf_lo, c0 + cc, K, nr, lane);
+      if (lane == 0) {
+        hit_pk[i] = (row << 16) | cc;
+        arg[(long long)cloud * C + c0 + cc] = rbase + row;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // eight hits (16 row loads per lane) are in flight at a time: the arg-max rows of a cloud concentrate on a few points, so some
+    // tiles carry hundreds of hits and the launch lasts as long as its heaviest tile
     constexpr int UF = 8;                      // 16 in flight measured no better
     for (int i0 = wave; i0 < total; i0 += 4 * UF) {
       int pk[UF];
       float h[UF], w0[UF], w1[UF];
 #pragma unroll
       for (int u = 0; u < UF; ++u) {
-        const int i = min(i0 + 4 * u, total - 1);
-        pk[u] = hit_pk[i];
+        const int i = min(i0 + 4 * u, total - 1 - ((total - 1 - wave) & 3));      // clamp inside this wave's own hits
+        pk[u] = reinterpret_cast<volatile int*>(hit_pk)[i];
         const int c = c0 + (pk[u] & 0xffff);
         h[u] = hb[c];
         w0[u] = wt[(long long)c * K + min(lane, K - 1)];
@@ -299,12 +422,35 @@ int maxbwd_q(const float* w, const float* f, int K, int C, float* q, hipStream_t
   return PN_OK;
 }
 
-int maxbwd_scatter(const int* arg, const float* hs, const float* wt, const float* q, int B, int N, int K, int C, float* D,
-                   hipStream_t st) {
-  PN_CHECK_ARG(arg && hs && wt && q && D, "maxbwd_scatter: null pointer");
-  PN_CHECK_ARG(K <= 128, "maxbwd_scatter: K must be <= 128 (K=%d)", K);
+int maxbwd_scatter(const pn_operand* x, const void* wf_hi, const void* wf_lo, int prec, const int* argq, int* arg, const float* hs,
+                   const float* wt, const float* q, int B, int N, int K, int C, float* D, hipStream_t st) {
+  PN_CHECK_ARG(x && x->s1 && !x->s2 && wf_hi && argq && arg && hs && wt && q && D, "maxbwd_scatter: null pointer");
+  PN_CHECK_ARG(K <= 128 && K % 16 == 0 && C % 32 == 0, "maxbwd_scatter: K must be a multiple of 16, at most 128, C a multiple of 32 (K=%d C=%d)", K, C);
+  PN_CHECK_ARG(C <= 65536, "maxbwd_scatter: C must be at most 65536");
+  PN_CHECK_ARG((reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && x->ld % 4 == 0, "maxbwd_scatter: operand alignment");
+  PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && wf_lo), "maxbwd_scatter: bad prec / missing lo weights");
   const int qpc = cdiv(N, 32);
-  hipLaunchKernelGGL(maxbwd_scatter_kernel, dim3(B * qpc), dim3(256), 0, st, arg, hs, wt, q, N, K, C, qpc, D);
+  const __bf16* wh = reinterpret_cast<const __bf16*>(wf_hi);
+  const __bf16* wl = reinterpret_cast<const __bf16*>(wf_lo);
+  if (prec == PN_PREC_BF16X3)
+    hipLaunchKernelGGL((maxbwd_scatter_kernel<2>), dim3(B * qpc), dim3(256), 0, st, *x, wh, wl, argq, arg, hs, wt, q, N, K, C, qpc, D);
+  else
+    hipLaunchKernelGGL((maxbwd_scatter_kernel<1>), dim3(B * qpc), dim3(256), 0, st, *x, wh, wl, argq, arg, hs, wt, q, N, K, C, qpc, D);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+int max_resolve(const pn_operand* x, const void* wf_hi, const void* wf_lo, int prec, const int* argq, int B, int N, int K, int C, int* arg,
+                hipStream_t st) {
+  PN_CHECK_ARG(x && x->s1 && !x->s2 && wf_hi && argq && arg, "pn_max_resolve: null pointer");
+  PN_CHECK_ARG(K <= 128 && K % 16 == 0 && C % 32 == 0, "pn_max_resolve: K must be a multiple of 16, at most 128, C a multiple of 32 (K=%d C=%d)", K, C);
+  PN_CHECK_ARG((reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && x->ld % 4 == 0, "pn_max_resolve: operand alignment");
+  PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && wf_lo), "pn_max_resolve: bad prec / missing lo weights");
+  const int qpc = cdiv(N, 32);
+  const __bf16* wh = reinterpret_cast<const __bf16*>(wf_hi);
+  const __bf16* wl = reinterpret_cast<const __bf16*>(wf_lo);
+  if (prec == PN_PREC_BF16X3) hipLaunchKernelGGL((max_resolve_kernel<2>), dim3(B * qpc), dim3(256), 0, st, *x, wh, wl, argq, N, K, C, qpc, arg);
+  else hipLaunchKernelGGL((max_resolve_kernel<1>), dim3(B * qpc), dim3(256), 0, st, *x, wh, wl, argq, N, K, C, qpc, arg);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -128,9 +128,9 @@ struct CL {   // per-point conv layer state
   int C = 0;
 };
 struct ML {   // extra state of a max-pooled layer
-  float *sgn, *pmax, *g, *zstar, *hs, *e, *nege, *f, *a1part, *a1, *gram, *GW, *Pm, *q, *D, *Wt, *We, *dG;
-  int *pidx, *arg;
-  unsigned short *wb_hi, *wb_lo;   // bf16 channel-major copies of the kernel for the panel kernel
+  float *pmax, *sumsq, *pa1, *g, *zstar, *hs, *e, *nege, *f, *a1part, *a1, *gram, *GW, *Pm, *q, *D, *Wt, *We, *dG;
+  int *pq, *argq, *arg;            // per tile: 32-row block of the maximum; per cloud: the same after the reduction; the row (backward)
+  unsigned short *wb_hi, *wb_lo;   // fragment-ordered bf16 copies of the kernel for the panel kernel (pn_panel.hip)
   int T64, tpc64, rows;   // panel tiles (all clouds / per cloud) and rows per panel
 };
 struct DLs {  // dense layer state (rows = B)
@@ -197,24 +197,23 @@ static void plan_cl(Arena& A, CL& l, const char* nm, long long M, int T, int C, 
     l.dy = store_z ? A.get<float>((n + ".dy").c_str(), (size_t)M * C) : nullptr;
   }
 }
-// rows per panel of the fused 128->1024 + max kernel (pn_panel.hip): 128 halves the L2 traffic of the weight stream
-// 128 rows.  PN_PANEL_ROWS = 64 / 256 for experiments (256: bf16 operands only, the lo images do not fit beside a 256-row panel);
-// measured at B = 32: N = 1024: 22.5 / 19.9 us for 64 / 128 rows; N = 4096: 81 / 59 / 64 us for 64 / 128 / 256 rows.
+// rows per panel of the fused 128->1024 + max kernel (pn_panel.hip): every panel streams the whole bf16 kernel from L2, so 128-row
+// panels halve that traffic; PN_PANEL_ROWS = 64 for experiments.
 static int panel_rows(int B, int N, int prec) {
   static const int forced = getenv("PN_PANEL_ROWS") ? atoi(getenv("PN_PANEL_ROWS")) : 0;
-  (void)B; (void)N;
-  if (forced == 64) return 64;
-  if (forced == 256 && prec != PN_PREC_BF16X3) return 256;
-  return 128;
+  (void)B; (void)N; (void)prec;
+  return forced == 64 ? 64 : 128;
 }
 static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, int T, int K, int C, bool training, int prec) {
   std::string n(nm);
   m.rows = panel_rows(B, N, prec);
   m.tpc64 = cdiv(N, m.rows);          // panel tiles per cloud (the buffers below are sized for 64-row panels, the finer case)
   m.T64 = B * m.tpc64;
-  m.sgn = A.get<float>((n + ".sgn").c_str(), C);
   m.pmax = A.get<float>((n + ".pmax").c_str(), (size_t)B * cdiv(N, 64) * C);
-  m.pidx = A.get<int>((n + ".pidx").c_str(), (size_t)B * cdiv(N, 64) * C);
+  m.pq = A.get<int>((n + ".pq").c_str(), (size_t)B * cdiv(N, 64) * C);
+  m.sumsq = A.get<float>((n + ".sumsq").c_str(), (size_t)B * cdiv(N, 64) * C);
+  m.pa1 = A.get<float>((n + ".pa1").c_str(), (size_t)B * cdiv(N, 64) * 2 * K);
+  m.argq = A.get<int>((n + ".argq").c_str(), (size_t)B * C);
   m.wb_hi = A.get<unsigned short>((n + ".wb_hi").c_str(), (size_t)K * C);
   m.wb_lo = A.get<unsigned short>((n + ".wb_lo").c_str(), (size_t)K * C);
   m.g = A.get<float>((n + ".g").c_str(), (size_t)B * C);
@@ -253,7 +252,7 @@ static void plan_tn(Arena& A, TN& t, const char* nm, int B, int N, long long M, 
   std::string n(nm);
   plan_cl(A, t.c1, (n + ".c1").c_str(), M, T, 64, true, training);
   plan_cl(A, t.c2, (n + ".c2").c_str(), M, T, 128, true, training);
-  plan_cl(A, t.c3, (n + ".c3").c_str(), M, B * cdiv(N, 64), 1024, false, training);   // 64-row panel tiles
+  plan_cl(A, t.c3, (n + ".c3").c_str(), M, 1, 1024, false, training);                 // statistics live in the panel buffers (plan_ml)
   plan_ml(A, t.m3, (n + ".m3").c_str(), B, N, M, T, 128, 1024, training, prec);
   plan_dl(A, t.d1, (n + ".d1").c_str(), B, 1024, 512, training);
   plan_dl(A, t.d2, (n + ".d2").c_str(), B, 512, 256, training);
@@ -278,7 +277,7 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
   plan_cl(A, w.m12, "m12", M, T, 64, true, training);
   plan_cl(A, w.m21, "m21", M, T, 64, true, training);
   plan_cl(A, w.m22, "m22", M, T, 128, true, training);
-  plan_cl(A, w.m23, "m23", M, B * cdiv(N, 64), 1024, false, training);                // 64-row panel tiles
+  plan_cl(A, w.m23, "m23", M, 1, 1024, false, training);                              // statistics live in the panel buffers (plan_ml)
   plan_ml(A, w.mm23, "mm23", B, N, M, T, 128, 1024, training, d.prec);
   plan_cl(A, w.s1, "s1", M, T, 512, true, training);
   plan_cl(A, w.s2, "s2", M, T, 256, true, training);
@@ -485,15 +484,15 @@ struct Run {
     return bn_fin(l, r);
   }
   int fwd_max(CL& l, ML& m, const LRef& r, const pn_operand& x, int prof_slot) {
-    m.sgn = p(r.gamma);   // only the sign is used (sgn(gamma) = sgn(BN scale))
+    const int ub = bn_batch(r.block) ? 1 : 0;
     void** ev = io.prof_events;
     if (ev && ev[2 * prof_slot]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot]), st);
-    PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.sgn, m.pmax, m.pidx, bn_batch(r.block) ? l.part : nullptr,
-                              prec, st, 1, m.rows));
+    PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.pmax, m.pq, ub ? m.sumsq : nullptr, ub ? m.pa1 : nullptr, prec,
+                              m.rows, st));
     if (ev && ev[2 * prof_slot + 1]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot + 1]), st);
-    // (a fused statistics + reduce_max finaliser was measured slower than the pair: 17.5 vs 5.0 + 7.6 us)
-    PN_TRY(bn_fin(l, r, m.T64));
-    return max_finalize(m.pmax, m.pidx, B, m.tpc64, r.cout, N, m.sgn, l.scale, l.shift, m.g, m.zstar, m.arg, st);
+    // one finaliser: the layer's BatchNormalization coefficients (+ moving statistics) and the reduce_max over each cloud's panels
+    return panel_finalize(m.pmax, m.pq, m.sumsq, m.pa1, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.rows, prec, p(r.gamma), p(r.beta), p(r.mm),
+                          p(r.mv), d.bn_momentum, d.bn_eps, ub, ub, l.mean, l.invstd, l.scale, l.shift, m.g, m.zstar, m.argq, st);
   }
   // out (B, C) = x (B, K) . W (+ bias): one launch (pn_dense.hip); trans reads W^T from the same (C, K)-major... kernel
   int dense_plain(const float* x, int ldx, const float* W, int ldw, bool trans, int K, int C, const float* bias, float* out) {
@@ -671,6 +670,27 @@ struct Run {
     // + the channel-major copies Wt, We = -e (.) Wt used below, written by the same launch
     PN_TRY(maxbwd_prep(dG, dG2, m.g, m.zstar, B, C, l.mean, l.invstd, l.scale, bs, M, m.hs, m.e, m.nege, m.f, wg ? gr(r.gamma) : nullptr,
                        wg ? gr(r.beta) : nullptr, p(r.kernel), K, m.Wt, m.We, st));
+    // Pm[k'][k] = sum_c (-e_c) W[k'][c] W[k][c]: the contraction runs over the 1024 channels, so it is laid out as a
+    // weight-gradient problem over "rows" c (16 slabs of 64 channels -> 16 workgroups) instead of one 128x128 tile
+    // ... and q = W f (needs only maxbwd_prep's f) rides in the launch that reduces those slabs
+    {
+      int spc;
+      const int rows = (int)wgrad_slab_rows(1, C, K, K, &spc);
+      float* sl = cur_slabs();
+      if ((size_t)spc * K * K > (sl == w.slabs ? w.slab_floats : w.slab_main_floats)) {
+        set_error("wgrad: slab scratch too small");
+        return PN_ERR_WORKSPACE;
+      }
+      const pn_operand we = plain(m.We, K), wt = plain(m.Wt, K);
+      static const bool pm_small = !(getenv("PN_PM_SMALL") && atoi(getenv("PN_PM_SMALL")) == 0);
+      const WgradDesc pmd{we, wt, 1, C, K, K, rows, sl, PN_PREC_BF16X3, 0, pm_small ? 1 : 0};   // 64x64 tiles: 4x the workgroups of this 16-slab job
+      PN_TRY(conv_wgrad_batch(&pmd, 1, st));
+      PN_TRY(slab_reduce_q(sl, spc, (long long)K * K, m.Pm, p(r.kernel), m.f, K, C, m.q, st));
+    }
+    // the rows of the maxima are resolved inside the scatter (m.argq -> m.arg); the weight-gradient kernel reads m.arg afterwards
+    PN_TRY(maxbwd_scatter(&xop, m.wb_hi, m.wb_lo, prec, m.argq, m.arg, m.hs, m.Wt, m.q, B, N, K, C, m.D, st));
+    PN_TRY(conv_bwd_data(&xop, m.Pm, 0, B, N, K, K, m.D, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st));
+    // the parameter-gradient branch comes last: it reads m.arg, which the scatter above has just resolved
     if (wg) {
       const ML mm = m;
       float* dw = gr(r.kernel);
@@ -700,25 +720,7 @@ struct Run {
       }));
       PN_TRY(flush());
     }
-    // Pm[k'][k] = sum_c (-e_c) W[k'][c] W[k][c]: the contraction runs over the 1024 channels, so it is laid out as a
-    // weight-gradient problem over "rows" c (16 slabs of 64 channels -> 16 workgroups) instead of one 128x128 tile
-    // ... and q = W f (needs only maxbwd_prep's f) rides in the launch that reduces those slabs
-    {
-      int spc;
-      const int rows = (int)wgrad_slab_rows(1, C, K, K, &spc);
-      float* sl = cur_slabs();
-      if ((size_t)spc * K * K > (sl == w.slabs ? w.slab_floats : w.slab_main_floats)) {
-        set_error("wgrad: slab scratch too small");
-        return PN_ERR_WORKSPACE;
-      }
-      const pn_operand we = plain(m.We, K), wt = plain(m.Wt, K);
-      static const bool pm_small = !(getenv("PN_PM_SMALL") && atoi(getenv("PN_PM_SMALL")) == 0);
-      const WgradDesc pmd{we, wt, 1, C, K, K, rows, sl, PN_PREC_BF16X3, 0, pm_small ? 1 : 0};   // 64x64 tiles: 4x the workgroups of this 16-slab job
-      PN_TRY(conv_wgrad_batch(&pmd, 1, st));
-      PN_TRY(slab_reduce_q(sl, spc, (long long)K * K, m.Pm, p(r.kernel), m.f, K, C, m.q, st));
-    }
-    PN_TRY(maxbwd_scatter(m.arg, m.hs, m.Wt, m.q, B, N, K, C, m.D, st));
-    return conv_bwd_data(&xop, m.Pm, 0, B, N, K, K, m.D, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st);
+    return PN_OK;
   }
   // dense layer backward: da (B,C) -> dx (B,K) written to dx_out; parameter gradients
   int bwd_dense(DLs& dl, const LRef& r, const float* xin, const float* da, int act, const unsigned char* keep, float* dx_out) {

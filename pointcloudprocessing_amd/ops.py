@@ -66,19 +66,52 @@ def conv_fwd_max(x_op, w, B, N, K, C_, sgn, prec):
     return pmax, pidx, part
 
 
-def conv_fwd_max_panel(x_op, w, B, N, K, C_, sgn, prec, want_stats=True, panel_rows=64):
-    """row-panel variant: bf16 channel-major weight copy + 64- or 128-row panels (want_stats=False: inference, no BN sums)"""
-    dev = w.device
+def weights_prep(w, sgn=None):
+    """fragment-ordered bf16 copies (hi, lo) of a Keras kernel (K, C), columns pre-multiplied by sign(sgn) (include/pointnet_hip.h)"""
+    K, C_ = w.shape
+    hi = torch.empty(C_ * K, device=w.device, dtype=torch.bfloat16)
+    lo = torch.empty(C_ * K, device=w.device, dtype=torch.bfloat16)
+    check(lib().pn_weights_prep(ptr(w), ptr(sgn), K, C_, ptr(hi), ptr(lo), current_stream()), "pn_weights_prep")
+    return hi, lo
+
+
+def conv_fwd_max_panel(x_op, wf, B, N, K, C_, prec, want_stats=True, panel_rows=128):
+    """the row-panel kernel: per tile and channel max of sgn*z, the 32-row block holding it and (want_stats) sum z^2; per tile the
+    column sums a1 of the staged panel.  wf = weights_prep(w, gamma)."""
+    dev = wf[0].device
     T = B * ((N + panel_rows - 1) // panel_rows)
-    hi = torch.empty(C_ * K, device=dev, dtype=torch.bfloat16)
-    lo = torch.empty(C_ * K, device=dev, dtype=torch.bfloat16)
-    check(lib().pn_weights_prep(ptr(w), K, C_, ptr(hi), ptr(lo), current_stream()), "pn_weights_prep")
+    nt = 2 if prec == 3 else 1
     pmax = torch.empty(T, C_, device=dev, dtype=F32)
-    pidx = torch.empty(T, C_, device=dev, dtype=torch.int32)
-    part = torch.empty(T, 2, C_, device=dev, dtype=F32) if want_stats else None
-    check(lib().pn_conv_fwd_max_panel_rows(C.byref(x_op), ptr(hi), ptr(lo), B, N, K, C_, ptr(sgn), ptr(pmax), ptr(pidx), ptr(part), prec,
-                                           panel_rows, current_stream()), "pn_conv_fwd_max_panel_rows")
-    return pmax, pidx, part
+    pblk = torch.empty(T, C_, device=dev, dtype=torch.int32)
+    sumsq = torch.empty(T, C_, device=dev, dtype=F32) if want_stats else None
+    a1 = torch.empty(T, nt * K, device=dev, dtype=F32) if want_stats else None
+    check(lib().pn_conv_fwd_max_panel(C.byref(x_op), ptr(wf[0]), ptr(wf[1]), B, N, K, C_, ptr(pmax), ptr(pblk), ptr(sumsq), ptr(a1), prec,
+                                      panel_rows, current_stream()), "pn_conv_fwd_max_panel")
+    return pmax, pblk, sumsq, a1
+
+
+def panel_finalize(pmax, pblk, sumsq, a1, wf, B, N, K, prec, gamma, beta, moving_mean, moving_var, training=True, panel_rows=128,
+                   momentum=0.99, eps=1e-3):
+    """BN coefficients of the layer + reduce_max over each cloud's tiles -> (mean, invstd, scale, shift, g, zstar, arg_block)"""
+    C_ = pmax.shape[1]
+    dev = pmax.device
+    mean, invstd, scale, shift = (torch.empty(C_, device=dev, dtype=F32) for _ in range(4))
+    g = torch.empty(B, C_, device=dev, dtype=F32)
+    zstar = torch.empty(B, C_, device=dev, dtype=F32)
+    argb = torch.empty(B, C_, device=dev, dtype=torch.int32)
+    check(lib().pn_panel_finalize(ptr(pmax), ptr(pblk), ptr(sumsq), ptr(a1), ptr(wf[0]), ptr(wf[1]), B, N, K, C_, panel_rows, prec,
+                                  ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), momentum, eps, int(training), int(training),
+                                  ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(g), ptr(zstar), ptr(argb), current_stream()),
+          "pn_panel_finalize")
+    return mean, invstd, scale, shift, g, zstar, argb
+
+
+def max_resolve(x_op, wf, argb, B, N, K, C_, prec):
+    """the row of each (cloud, channel) maximum inside its 32-row block"""
+    arg = torch.empty(B, C_, device=argb.device, dtype=torch.int32)
+    check(lib().pn_max_resolve(C.byref(x_op), ptr(wf[0]), ptr(wf[1]), ptr(argb), B, N, K, C_, ptr(arg), prec, current_stream()),
+          "pn_max_resolve")
+    return arg
 
 
 def conv_bwd_data(dz_op, w, B, N, K, C_, prec, w_cloud_stride=0, addend=None, zmask=None, msc=None, msh=None,

