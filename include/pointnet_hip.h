@@ -111,23 +111,25 @@ int pn_conv_fwd(const pn_operand* x, const float* w, int64_t w_cloud_stride, int
 int pn_conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C, const float* sgn,
                     float* pmax, int32_t* pidx, float* stat_partials, int prec, pn_stream stream);
 
-/* --- the same layer as a ROW-PANEL kernel (the one the model plan uses; pn_panel.hip): a workgroup owns a panel of panel_rows
- * (64 or 128) point rows for ALL C channels; the activation panel is staged into LDS once and every wave streams the kernel columns it
- * owns from a fragment-ordered bf16 copy made by pn_weights_prep:
+/* --- the same layer as a KERNEL-STATIONARY ROW-PANEL kernel (the one the model plan uses; pn_panel.hip): every cloud is cut into
+ * pn_panel_slots_per_cloud(B, N) contiguous runs of 64-row panels, one workgroup per run; its eight waves keep the kernel columns
+ * they own in registers for the whole launch and the run's panels stream through a double-buffered LDS image.  The kernel is read
+ * from a fragment-ordered bf16 copy made by pn_weights_prep:
  *     wf_hi[((cb * K/16 + ks) * 64 + lane) * 8 + j] = bf16(s_c * W[k][c]),  c = cb*32 + (lane & 31),  k = ks*16 + (lane >> 5)*8 + j
  *     wf_lo = bf16(s_c * W - hi) (needed for PN_PREC_BF16X3 only);  s_c = -1 where sgn[c] < 0 (sgn may be gamma itself; NULL = +1).
- * K in {64, 128}, C a multiple of 128; tiles = B * ceil(N / panel_rows).  Per tile and channel the kernel emits
- *     pmax   = max over the tile's rows of s_c * z,      pblock = index inside the cloud of the 32-row block holding it (lowest on ties),
- *     sumsq  = sum over the rows of z^2 and, per tile, a1 = column sums of the staged bf16 panel (K values; hi then lo image for
+ * K in {64, 128}; C = 256, 512 or a multiple of 1024; slots = B * pn_panel_slots_per_cloud(B, N).  Per slot and channel the kernel emits
+ *     pmax   = max over the run's rows of s_c * z,      pblock = index inside the cloud of the 32-row block holding it (lowest on ties),
+ *     sumsq  = sum over the rows of z^2 and, per slot, a1 = column sums of the staged bf16 rows (K values; hi then lo image for
  *     PN_PREC_BF16X3) from which the finaliser forms sum z = a1 . W[:, c]   (sumsq and a1: both or neither; NULL for inference). */
 int pn_weights_prep(const float* w, const float* sgn, int K, int C, void* wf_hi, void* wf_lo, pn_stream stream);
+int pn_panel_slots_per_cloud(int B, int N);
 int pn_conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo, int B, int N, int K, int C, float* pmax,
-                          int32_t* pblock, float* sumsq, float* a1, int prec, int panel_rows, pn_stream stream);
+                          int32_t* pblock, float* sumsq, float* a1, int prec, pn_stream stream);
 /* finaliser of the panel kernel: BatchNormalization coefficients of the layer (as pn_bn_finalize; batch statistics from sumsq / a1 and
- * the weight copy, or the moving statistics) AND tf.reduce_max over each cloud's tiles:  zstar[b][c] = s_c * max,
+ * the weight copy, or the moving statistics) AND tf.reduce_max over each cloud's slots:  zstar[b][c] = s_c * max,
  * g[b][c] = relu(scale*zstar + shift), arg_block[b][c] = the 32-row block of cloud b holding the row of the maximum. */
 int pn_panel_finalize(const float* pmax, const int32_t* pblock, const float* sumsq, const float* a1, const void* wf_hi, const void* wf_lo,
-                      int B, int N, int K, int C, int panel_rows, int prec, const float* gamma, const float* beta, float* moving_mean,
+                      int B, int N, int K, int C, int prec, const float* gamma, const float* beta, float* moving_mean,
                       float* moving_var, float momentum, float eps, int use_batch_stats, int update_moving, float* mean, float* invstd,
                       float* scale, float* shift, float* g, float* zstar, int32_t* arg_block, pn_stream stream);
 /* the row of the maximum itself (needed by the backward pass only, where the model plan resolves it inside its scatter kernel):

@@ -191,60 +191,80 @@ __global__ __launch_bounds__(64) void maxbwd_q_kernel(const float* __restrict__ 
 // may resolve to either, which leaves zstar untouched (it is the panel kernel's exact maximum) and moves the gradient between two
 // rows of equal activation.
 typedef __attribute__((ext_vector_type(8))) __bf16 mb_bf16x8;
-constexpr int RS_PITCH = 129;                 // fp32 row pitch of the staged block (K <= 128): lanes <-> rows hit distinct banks
+typedef __attribute__((ext_vector_type(16))) float mb_f32x16;
+constexpr int RS_KMAX = 128;
+constexpr int RS_PITCH = RS_KMAX + 8;         // bf16 row pitch of the staged block: conflict-free 16-byte fragment reads (as pn_panel.hip)
 
-// stage rows [rbase, rbase + nr) of cloud `cloud` (K columns): As_hi = the bf16-rounded activation as fp32, As_lo = its bf16 remainder
+// stage rows [rbase, rbase + nr) of cloud `cloud` (K columns) the way the panel kernel stages its panel: BN + ReLU on load, rounded
+// once to bf16 (hi image) and, for bf16x3 operands, the bf16 remainder (lo image); rows outside the cloud are zero rows
 template <int NT>
-__device__ __forceinline__ void resolve_stage(const pn_operand& x, int cloud, int N, int K, int rbase, int nr, float* __restrict__ As_hi,
-                                              float* __restrict__ As_lo, int tid, int nthreads) {
-  for (int i = tid; i < 32 * (K / 4); i += nthreads) {
-    const int row = i / (K / 4), k = (i % (K / 4)) * 4;
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (row < nr) v = *reinterpret_cast<const float4*>(x.s1 + ((long long)cloud * N + rbase + row) * x.ld + k);
-    const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float ca = x.ca ? x.ca[k + e] : 1.f, cc = x.cc ? x.cc[k + e] : 0.f;
-      const float t = row < nr ? clamp_lo(fmaf(ca, vv[e], cc), x.lo) : 0.f;
-      const float hi = (float)(__bf16)t;
-      As_hi[row * RS_PITCH + k + e] = hi;
-      if (NT == 2) As_lo[row * RS_PITCH + k + e] = (float)(__bf16)(t - hi);
+__device__ __forceinline__ void resolve_stage(const pn_operand& x, int cloud, int N, int K, int rbase, int nr, __bf16* __restrict__ Ab_hi,
+                                              __bf16* __restrict__ Ab_lo, int tid, int nthreads) {
+  for (int i = tid; i < 32 * (K / 8); i += nthreads) {
+    const int row = i / (K / 8), k = (i % (K / 8)) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (row < nr) {
+      const float* s = x.s1 + ((long long)cloud * N + rbase + row) * x.ld + k;
+      const float4 v0 = *reinterpret_cast<const float4*>(s), v1 = *reinterpret_cast<const float4*>(s + 4);
+      v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
     }
+    mb_bf16x8 hv, lv;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float ca = x.ca ? x.ca[k + e] : 1.f, cc = x.cc ? x.cc[k + e] : 0.f;
+      const float t = row < nr ? clamp_lo(fmaf(ca, v[e], cc), x.lo) : 0.f;
+      hv[e] = (__bf16)t;
+      if (NT == 2) lv[e] = (__bf16)(t - (float)hv[e]);
+    }
+    *reinterpret_cast<mb_bf16x8*>(Ab_hi + row * RS_PITCH + k) = hv;
+    if (NT == 2) *reinterpret_cast<mb_bf16x8*>(Ab_lo + row * RS_PITCH + k) = lv;
   }
 }
-// one wave: the row (0..nr-1) of the largest candidate of channel c, lowest row on ties (0 if every candidate is NaN)
+// One wave, up to 32 channels at once (lane & 31 <-> channel c, both half-waves): the 32 x 32 block of pre-activations
+// sgn*z[row][c] on the matrix cores, from the same bf16 operands, in the same instruction order as the panel kernel accumulates them
+// (so the values are the panel kernel's own), then per channel the largest over the valid rows, lowest row on ties.  Returns the
+// row (0 .. nr-1; 0 if every candidate is NaN).
 template <int NT>
-__device__ __forceinline__ int resolve_row(const float* __restrict__ As_hi, const float* __restrict__ As_lo, const __bf16* __restrict__ wf_hi,
-                                           const __bf16* __restrict__ wf_lo, int c, int K, int nr, int lane) {
-  const int row = lane & 31, kh = lane >> 5, KS = K / 16;
+__device__ __forceinline__ int resolve_group(const __bf16* __restrict__ Ab_hi, const __bf16* __restrict__ Ab_lo, const __bf16* __restrict__ wf_hi,
+                                             const __bf16* __restrict__ wf_lo, int c, int K, int nr, int lane) {
+  const int r = lane & 31, h = lane >> 5, KS = K / 16;
   const int cb = c >> 5, cl = c & 31;
-  float dot = 0.f;
-  for (int q = 0; q < K / 16; ++q) {              // this half-wave's K/2 values of k, eight at a time
-    const int k0 = kh * (K / 2) + q * 8;
-    const int ks = k0 >> 4, hh = (k0 >> 3) & 1;
-    const long long chunk = ((long long)cb * KS + ks) * 64 + hh * 32 + cl;
-    const mb_bf16x8 wh = *reinterpret_cast<const mb_bf16x8*>(wf_hi + chunk * 8);
-    mb_bf16x8 wl;
-    if (NT == 2) wl = *reinterpret_cast<const mb_bf16x8*>(wf_lo + chunk * 8);
+  mb_f32x16 acc;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float ah = As_hi[row * RS_PITCH + k0 + j];
-      const float bh = (float)wh[j];
-      if (NT == 2) {
-        const float al = As_lo[row * RS_PITCH + k0 + j];
-        dot = fmaf(al, bh, dot);
-        dot = fmaf(ah, (float)wl[j], dot);
-      }
-      dot = fmaf(ah, bh, dot);
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int ks = 0; ks < KS; ++ks) {
+    const long long chunk = ((long long)cb * KS + ks) * 64 + h * 32 + cl;
+    const mb_bf16x8 bh = *reinterpret_cast<const mb_bf16x8*>(wf_hi + chunk * 8);
+    const mb_bf16x8 ah = *reinterpret_cast<const mb_bf16x8*>(Ab_hi + r * RS_PITCH + ks * 16 + h * 8);
+    if (NT == 2) {
+      const mb_bf16x8 al = *reinterpret_cast<const mb_bf16x8*>(Ab_lo + r * RS_PITCH + ks * 16 + h * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+  }
+  if (NT == 2) {
+    for (int ks = 0; ks < KS; ++ks) {
+      const long long chunk = ((long long)cb * KS + ks) * 64 + h * 32 + cl;
+      const mb_bf16x8 bl = *reinterpret_cast<const mb_bf16x8*>(wf_lo + chunk * 8);
+      const mb_bf16x8 ah = *reinterpret_cast<const mb_bf16x8*>(Ab_hi + r * RS_PITCH + ks * 16 + h * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
     }
   }
-  dot += __shfl_xor(dot, 32, 64);
-  const float mine = row < nr ? dot : -INFINITY;
-  float vmax = mine;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o, 64));
-  const unsigned long long hit = __ballot(mine == vmax && row < nr) & 0xffffffffull;
-  return hit ? (__ffsll((long long)hit) - 1) : 0;
+  for (int e = 0; e < 16; ++e) {              // rows ascend with e: the first maximum wins
+    const int il = (e & 3) + 8 * (e >> 2) + 4 * h;
+    const float v = il < nr ? acc[e] : -INFINITY;
+    const bool better = v > best;
+    best = better ? v : best;
+    bi = better ? il : bi;
+  }
+  const float ob = __shfl_xor(best, 32, 64);
+  const int oi = __shfl_xor(bi, 32, 64);
+  const bool take = ob > best || (ob == best && oi < bi);
+  const int row = take ? oi : bi;
+  return (row >= 0 && row < nr) ? row : 0;
 }
 
 // standalone form (op-level API pn_max_resolve; the model plan resolves inside maxbwd_scatter_kernel): one workgroup per 32-row block
@@ -252,8 +272,8 @@ template <int NT>
 __global__ __launch_bounds__(256) void max_resolve_kernel(const pn_operand x, const __bf16* __restrict__ wf_hi, const __bf16* __restrict__ wf_lo,
                                                           const int* __restrict__ argq, int N, int K, int C, int quarters_per_cloud,
                                                           int* __restrict__ arg) {
-  __shared__ float As_hi[32 * RS_PITCH];
-  __shared__ float As_lo[NT == 2 ? 32 * RS_PITCH : 1];
+  __shared__ __attribute__((aligned(16))) __bf16 Ab_hi[32 * RS_PITCH];
+  __shared__ __attribute__((aligned(16))) __bf16 Ab_lo[NT == 2 ? 32 * RS_PITCH : 8];
   __shared__ int hit_c[1024];
   __shared__ int nhit;
   const int bx = blockIdx.x, cloud = bx / quarters_per_cloud, qin = bx - cloud * quarters_per_cloud;
@@ -270,14 +290,15 @@ __global__ __launch_bounds__(256) void max_resolve_kernel(const pn_operand x, co
     __syncthreads();
     const int total = nhit;
     if (total > 0 && !staged) {
-      resolve_stage<NT>(x, cloud, N, K, rbase, nr, As_hi, As_lo, t, 256);
+      resolve_stage<NT>(x, cloud, N, K, rbase, nr, Ab_hi, Ab_lo, t, 256);
       staged = true;
       __syncthreads();
     }
-    for (int i = wave; i < total; i += 4) {
-      const int c = hit_c[i];
-      const int row = resolve_row<NT>(As_hi, As_lo, wf_hi, wf_lo, c, K, nr, lane);
-      if (lane == 0) arg[(long long)cloud * C + c] = rbase + row;
+    for (int g0 = wave * 32; g0 < total; g0 += 4 * 32) {          // wave-uniform
+      const int i = g0 + (lane & 31);
+      const int c = hit_c[min(i, total - 1)];
+      const int row = resolve_group<NT>(Ab_hi, Ab_lo, wf_hi, wf_lo, c, K, nr, lane);
+      if (lane < 32 && i < total) arg[(long long)cloud * C + c] = rbase + row;
     }
     __syncthreads();
   }
@@ -299,8 +320,8 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const pn_operand x,
   constexpr int CHUNK = 1024;                  // channels examined per round (4 per thread)
   constexpr double FX = 1099511627776.0;       // 2^40
   __shared__ unsigned long long tile[32][128]; // 32 KB
-  __shared__ float As_hi[32 * RS_PITCH];
-  __shared__ float As_lo[NT == 2 ? 32 * RS_PITCH : 1];
+  __shared__ __attribute__((aligned(16))) __bf16 Ab_hi[32 * RS_PITCH];
+  __shared__ __attribute__((aligned(16))) __bf16 Ab_lo[NT == 2 ? 32 * RS_PITCH : 8];
   __shared__ int hit_pk[CHUNK];                // (row << 16) | channel-in-chunk, unordered
   __shared__ int nhit;
   const int bx = blockIdx.x, cloud = bx / quarters_per_cloud, qin = bx - cloud * quarters_per_cloud;
@@ -321,20 +342,21 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const pn_operand x,
     __syncthreads();
     const int total = nhit;
     if (total > 0 && !staged) {                // block-uniform
-      resolve_stage<NT>(x, cloud, N, K, rbase, nr, As_hi, As_lo, t, 256);
+      resolve_stage<NT>(x, cloud, N, K, rbase, nr, Ab_hi, Ab_lo, t, 256);
       staged = true;
       __syncthreads();
     }
-    // wave w owns hits w, w+4, ...: it resolves their rows, then scatters them (no other wave touches those entries)
-    for (int i = wave; i < total; i += 4) {
-      const int cc = hit_pk[i];
-      const int row = resolve_row<NT>(As_hi, As_lo, wf_hi, wf_lo, c0 + cc, K, nr, lane);
-      if (lane == 0) {
+    // the rows: 32 hits per wave at a time on the matrix cores (resolve_group); every hit's entry gets its row packed in
+    for (int g0 = wave * 32; g0 < total; g0 += 4 * 32) {          // wave-uniform
+      const int i = g0 + (lane & 31);
+      const int cc = hit_pk[min(i, total - 1)];
+      const int row = resolve_group<NT>(Ab_hi, Ab_lo, wf_hi, wf_lo, c0 + cc, K, nr, lane);
+      if (lane < 32 && i < total) {
         hit_pk[i] = (row << 16) | cc;
         arg[(long long)cloud * C + c0 + cc] = rbase + row;
       }
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();                           // the scatter below walks the list with another wave <-> hit assignment
     // eight hits (16 row loads per lane) are in flight at a time: the arg-max rows of a cloud concentrate on a few points, so some
     // tiles carry hundreds of hits and the launch lasts as long as its heaviest tile
     constexpr int UF = 8;                      // 16 in flight measured no better
@@ -343,8 +365,8 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const pn_operand x,
       float h[UF], w0[UF], w1[UF];
 #pragma unroll
       for (int u = 0; u < UF; ++u) {
-        const int i = min(i0 + 4 * u, total - 1 - ((total - 1 - wave) & 3));      // clamp inside this wave's own hits
-        pk[u] = reinterpret_cast<volatile int*>(hit_pk)[i];
+        const int i = min(i0 + 4 * u, total - 1);
+        pk[u] = hit_pk[i];
         const int c = c0 + (pk[u] & 0xffff);
         h[u] = hb[c];
         w0[u] = wt[(long long)c * K + min(lane, K - 1)];
@@ -425,7 +447,7 @@ int maxbwd_q(const float* w, const float* f, int K, int C, float* q, hipStream_t
 int maxbwd_scatter(const pn_operand* x, const void* wf_hi, const void* wf_lo, int prec, const int* argq, int* arg, const float* hs,
                    const float* wt, const float* q, int B, int N, int K, int C, float* D, hipStream_t st) {
   PN_CHECK_ARG(x && x->s1 && !x->s2 && wf_hi && argq && arg && hs && wt && q && D, "maxbwd_scatter: null pointer");
-  PN_CHECK_ARG(K <= 128 && K % 16 == 0 && C % 32 == 0, "maxbwd_scatter: K must be a multiple of 16, at most 128, C a multiple of 32 (K=%d C=%d)", K, C);
+  PN_CHECK_ARG(K <= RS_KMAX && K % 16 == 0 && C % 32 == 0, "maxbwd_scatter: K must be a multiple of 16, at most 128, C a multiple of 32 (K=%d C=%d)", K, C);
   PN_CHECK_ARG(C <= 65536, "maxbwd_scatter: C must be at most 65536");
   PN_CHECK_ARG((reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && x->ld % 4 == 0, "maxbwd_scatter: operand alignment");
   PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && wf_lo), "maxbwd_scatter: bad prec / missing lo weights");

@@ -197,17 +197,12 @@ static void plan_cl(Arena& A, CL& l, const char* nm, long long M, int T, int C, 
     l.dy = store_z ? A.get<float>((n + ".dy").c_str(), (size_t)M * C) : nullptr;
   }
 }
-// rows per panel of the fused 128->1024 + max kernel (pn_panel.hip): every panel streams the whole bf16 kernel from L2, so 128-row
-// panels halve that traffic; PN_PANEL_ROWS = 64 for experiments.
-static int panel_rows(int B, int N, int prec) {
-  static const int forced = getenv("PN_PANEL_ROWS") ? atoi(getenv("PN_PANEL_ROWS")) : 0;
-  (void)B; (void)N; (void)prec;
-  return forced == 64 ? 64 : 128;
-}
+
 static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, int T, int K, int C, bool training, int prec) {
   std::string n(nm);
-  m.rows = panel_rows(B, N, prec);
-  m.tpc64 = cdiv(N, m.rows);          // panel tiles per cloud (the buffers below are sized for 64-row panels, the finer case)
+  (void)prec;
+  m.rows = 64;
+  m.tpc64 = panel_slots_per_cloud(B, N);   // slots (workgroups) per cloud of the panel kernel; never more than ceil(N / 64)
   m.T64 = B * m.tpc64;
   m.pmax = A.get<float>((n + ".pmax").c_str(), (size_t)B * cdiv(N, 64) * C);
   m.pq = A.get<int>((n + ".pq").c_str(), (size_t)B * cdiv(N, 64) * C);
@@ -487,11 +482,10 @@ struct Run {
     const int ub = bn_batch(r.block) ? 1 : 0;
     void** ev = io.prof_events;
     if (ev && ev[2 * prof_slot]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot]), st);
-    PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.pmax, m.pq, ub ? m.sumsq : nullptr, ub ? m.pa1 : nullptr, prec,
-                              m.rows, st));
+    PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.pmax, m.pq, ub ? m.sumsq : nullptr, ub ? m.pa1 : nullptr, prec, st));
     if (ev && ev[2 * prof_slot + 1]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot + 1]), st);
     // one finaliser: the layer's BatchNormalization coefficients (+ moving statistics) and the reduce_max over each cloud's panels
-    return panel_finalize(m.pmax, m.pq, m.sumsq, m.pa1, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.rows, prec, p(r.gamma), p(r.beta), p(r.mm),
+    return panel_finalize(m.pmax, m.pq, m.sumsq, m.pa1, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, prec, p(r.gamma), p(r.beta), p(r.mm),
                           p(r.mv), d.bn_momentum, d.bn_eps, ub, ub, l.mean, l.invstd, l.scale, l.shift, m.g, m.zstar, m.argq, st);
   }
   // out (B, C) = x (B, K) . W (+ bias): one launch (pn_dense.hip); trans reads W^T from the same (C, K)-major... kernel

@@ -16,6 +16,7 @@
 //     records which 32-row block of the panel held the maximum and the backward pass, which is the only consumer of the row, finds
 //     it among those 32 candidates (pn_maxbwd.hip: max_resolve).
 // Per point: 2 * K * C FLOP against 4 * K bytes of input: MFMA-bound by the roofline.
+#include <cstdlib>
 #include "pn_common.h"
 #include "pn_internal.h"
 
@@ -89,59 +90,107 @@ int weights_prep(const float* w, const float* sgn, int K, int C, void* hi, void*
 }
 
 // ---- the panel kernel --------------------------------------------------------------------------------------------------------
+// Work split: every cloud is cut into `spc` (slots per cloud, panel_slots_per_cloud) contiguous runs of 64-row panels, one workgroup
+// per run, about one workgroup per CU in all.  A workgroup = 8 waves (two per SIMD, up to 256 VGPRs each).
 struct PanelArgs {
   pn_operand a;                 // lazy activation operand over (B*N, K)
   const __bf16* wf_hi;          // fragment-ordered copies (weights_prep)
   const __bf16* wf_lo;          // (NS == 3)
   int B, N, C;
-  int tiles_per_cloud;          // ceil(N / panel rows)
-  float* pmax;                  // [tiles][C]  max over the panel's rows of the accumulator (= sgn * z with presigned weights)
-  int* pq;                      // [tiles][C]  index inside the cloud of the 32-row block that held it (lowest on ties)
-  float* sumsq;                 // [tiles][C]  sum over the panel's rows of z^2, or NULL
-  float* a1;                    // [tiles][NT * K]  column sums of the staged bf16 panel (hi image, then lo image), or NULL
+  int spc;                      // slots (workgroups) per cloud
+  float* pmax;                  // [B * spc][C]  max over the slot's rows of the accumulator (= sgn * z with presigned weights)
+  int* pq;                      // [B * spc][C]  index inside the cloud of the 32-row block that held it (lowest on ties)
+  float* sumsq;                 // [B * spc][C]  sum over the slot's rows of z^2, or NULL
+  float* a1;                    // [B * spc][NT * K]  column sums of the staged bf16 rows (hi image, then lo image), or NULL
 };
+// PN_PANEL_DBG (timing ablations of the bf16, K = 128, statistics variant; WRONG results; tools/panel_probe.py): template bit mask DBG:
+// 1 no epilogue, 4 no activation loads, 8 no MFMAs
 
-// NS: 1 = bf16 operands, 3 = bf16 hi + lo (three products).  K compile time: every k loop unrolls.  MB = 32-row blocks per panel.
-template <int NS, int K, bool STATS, int MB>
-__global__ __launch_bounds__(256, 2) void panel_max_kernel(const PanelArgs g) {
-  constexpr int BM = 32 * MB, THREADS = 256, KS = K / 16;
+int panel_slots_per_cloud(int B, int N) {
+  const int tpc = cdiv(N, 64);
+  int spc = 256 / (B > 0 ? B : 1);
+  if (spc < 1) spc = 1;
+  return spc < tpc ? spc : tpc;
+}
+
+// KERNEL-STATIONARY: the bf16 kernel of the layer (K x C = 256 KB at 128 x 1024) is exactly what the eight waves of a workgroup can
+// hold in registers -- wave w keeps the B fragments of its CBW column blocks (CBW * K/16 * 4 VGPRs = 128 at CBW = 4, K = 128) for the
+// whole launch -- so the kernel is read from L2 once per workgroup and the main loop streams only activations:
+//   * 64-row panels of the workgroup's run go through a double-buffered bf16 LDS image (BN + ReLU applied on load, rounded once);
+//     the global loads of panel p+1 are issued before the MFMAs of panel p and converted after them: one barrier per panel;
+//   * per panel and owned column block: K/16 x 2 MFMAs 32x32x16 with A fragments from LDS, then the epilogue on the 2 x 16 accumulator
+//     values per lane: v_max3 chains (half an instruction per element) into a running (max, 32-row block) and packed fma into a
+//     running sum of squares -- both kept in registers across the run's panels and written once per (slot, channel);
+//   * bf16x3 operands need hi + lo fragments (twice the registers): a workgroup then owns half the columns (CBW = 2 per wave) and the
+//     grid's second dimension walks the column halves.
+template <int NS, int K, bool STATS, int CBW, int DBG = 0>
+__global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
+  constexpr int BM = 64, THREADS = 512, KS = K / 16;
   constexpr int PA = K + 8;                          // LDS row pitch (bf16 elements): rows r .. r+15 on 16 distinct 16-byte slots
   constexpr int NT = (NS == 3) ? 2 : 1;
-  __shared__ __attribute__((aligned(16))) __bf16 Ap[NT][BM * PA];
-  __shared__ float colsum[4][NT * K];
+  constexpr int CH = K / 8;                          // 16-byte bf16 chunks per row
+  constexpr int RP = THREADS / CH;                   // rows per staging pass
+  constexpr int P = BM / RP;                         // passes (2 at K = 128, 1 at K = 64)
+  constexpr int NBLK = CBW * NT;                     // B blocks (column block x image) of KS fragments each owned by a wave
+  constexpr int RB = NBLK < 3 ? NBLK : 3;            // ... of which this many live in registers (RB * KS * 4 VGPRs) and the rest in LDS:
+  constexpr int LB = NBLK - RB;                      // 4 x 32 VGPRs + accumulators + staging do not fit 256 registers without spills
+  __shared__ __attribute__((aligned(16))) __bf16 Ap[2][NT][BM * PA];
+  __shared__ float red[8][NT * K];
+  __shared__ u32x4 Bl[LB > 0 ? 8 : 1][LB > 0 ? LB * KS : 1][LB > 0 ? 64 : 1];   // [wave][block, k-step][lane]: lane-linear, conflict-free
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int bx = blockIdx.x;
-  const int cloud = bx / g.tiles_per_cloud, tin = bx - cloud * g.tiles_per_cloud;
-  const int row_in_cloud0 = tin * BM;
-  const int nrows = min(BM, g.N - row_in_cloud0);
-  const long long row0 = (long long)cloud * g.N + row_in_cloud0;
-  const int n_cb = g.C / 32;
+  const int slot = blockIdx.x, cg = blockIdx.y;
+  const int cloud = slot / g.spc, j = slot - cloud * g.spc;
+  const int tpc = (g.N + BM - 1) / BM;
+  const int p_begin = (int)((long long)j * tpc / g.spc), p_end = (int)((long long)(j + 1) * tpc / g.spc);
+  const long long cloud_row0 = (long long)cloud * g.N;
 
-  // this wave's first column block of the kernel is in flight while the activation panel is staged
+  // ---- this wave's columns of the kernel: loaded once, resident for the whole run ----------------------------------------------
   const u32x4* __restrict__ wfh = reinterpret_cast<const u32x4*>(g.wf_hi);
   const u32x4* __restrict__ wfl = reinterpret_cast<const u32x4*>(g.wf_lo);
-  u32x4 bnext[KS];
+  u32x4 bw[RB][KS];                                  // block q = i * NT + image (0 hi, 1 lo) of owned column block i
+  int cbs[CBW];
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) bnext[ks] = wfh[((long long)wave * KS + ks) * 64 + lane];
+  for (int i = 0; i < CBW; ++i) cbs[i] = (cg * CBW + i) * 8 + wave;
+#pragma unroll
+  for (int q = 0; q < NBLK; ++q) {
+    const u32x4* __restrict__ src = ((q % NT) ? wfl : wfh) + (long long)cbs[q / NT] * KS * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (q < RB) bw[q][ks] = src[ks * 64];
+      else Bl[wave][(q - RB) * KS + ks][lane] = src[ks * 64];      // read back by this wave only
+    }
+  }
 
-  // ---- stage the activation panel: thread <-> (row, 8 consecutive k); BN + ReLU coefficients indexed by k ---------------------
-  {
-    constexpr int CH = K / 8;                        // 16-byte bf16 chunks per row
-    constexpr int RP = THREADS / CH;                 // rows per pass
-    constexpr int P = BM / RP;
-    const int ch = tid % CH, rin = tid / CH;
-    const int k = ch * 8;
-    float4 x[P][2];
+  // ---- staging: thread <-> (row rin + 32 p, 8 consecutive k); BN + ReLU coefficients of its 8 columns --------------------------
+  const int ch = tid % CH, rin = tid / CH;
+  const int k = ch * 8;
+  const float lo = g.a.lo;
+  // column sums of the staged images (a1): accumulated in LDS, one float per column and wave (red[wave][..]), so that they cost no
+  // long-lived registers; a conversion adds its rows' values after a four-lane (K = 128) shuffle reduction
+  for (int i = tid; i < 8 * NT * K; i += THREADS) (&red[0][0])[i] = 0.f;
+  float4 x[P][2];
+  auto issue = [&](int panel) {
+    const int rbase = panel * BM, nrows = min(BM, g.N - rbase);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int rr = p * RP + rin;
-      const long long rsrc = (rr < nrows) ? rr : (nrows - 1);
-      const float* s = g.a.s1 + (row0 + rsrc) * g.a.ld + k;
-      x[p][0] = *reinterpret_cast<const float4*>(s);
-      x[p][1] = *reinterpret_cast<const float4*>(s + 4);
+      const long long rsrc = cloud_row0 + rbase + (rr < nrows ? rr : nrows - 1);
+      const float* s = g.a.s1 + rsrc * g.a.ld + k;
+      if (!(DBG & 4)) {
+        x[p][0] = *reinterpret_cast<const float4*>(s);
+        x[p][1] = *reinterpret_cast<const float4*>(s + 4);
+      } else {
+        x[p][0] = x[p][1] = make_float4(1.f, 2.f, 3.f, 4.f);
+      }
     }
+  };
+  auto convert = [&](int panel, int buf) {
+    const int nrows = min(BM, g.N - panel * BM);
+    // the BN + ReLU coefficients of this thread's 8 columns are re-read here (L1 hits) rather than kept in 16 registers across the
+    // MFMA sections: the kernel's fragments already take 128 of the 256
+    asm volatile("" ::: "memory");
     float ca[8], cc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ca[e] = 1.f; cc[e] = 0.f; }
@@ -153,7 +202,6 @@ __global__ __launch_bounds__(256, 2) void panel_max_kernel(const PanelArgs g) {
       const float4 t0 = *reinterpret_cast<const float4*>(g.a.cc + k), t1 = *reinterpret_cast<const float4*>(g.a.cc + k + 4);
       cc[0] = t0.x; cc[1] = t0.y; cc[2] = t0.z; cc[3] = t0.w; cc[4] = t1.x; cc[5] = t1.y; cc[6] = t1.z; cc[7] = t1.w;
     }
-    const float lo = g.a.lo;
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int rr = p * RP + rin;
@@ -166,168 +214,192 @@ __global__ __launch_bounds__(256, 2) void panel_max_kernel(const PanelArgs g) {
         hv[e] = (__bf16)t;
         if (NS == 3) lv[e] = (__bf16)(t - (float)hv[e]);
       }
-      *reinterpret_cast<bf16x8*>(&Ap[0][rr * PA + k]) = hv;
-      if (NS == 3) *reinterpret_cast<bf16x8*>(&Ap[NT - 1][rr * PA + k]) = lv;
-    }
-  }
-  __syncthreads();
-  if (STATS && g.a1) {
-    // column sums of the staged images: thread <-> (column, quarter of the rows), then four partials per column
-    for (int i = tid; i < 4 * NT * K; i += THREADS) {
-      const int col = i % (NT * K), qr = i / (NT * K);
-      const __bf16* img = Ap[col / K];
-      const int kk = col % K;
-      float s = 0.f;
-#pragma unroll 8
-      for (int rr = qr * (BM / 4); rr < (qr + 1) * (BM / 4); ++rr) s += (float)img[rr * PA + kk];
-      colsum[qr][col] = s;
-    }
-    __syncthreads();
-    for (int col = tid; col < NT * K; col += THREADS)
-      g.a1[(long long)bx * (NT * K) + col] = (colsum[0][col] + colsum[1][col]) + (colsum[2][col] + colsum[3][col]);
-  }
-
-  // ---- this wave's column blocks: cb = wave, wave + 4, ... ------------------------------------------------------------------
-  // One B buffer (KS x 16 bytes per lane) is consumed while the next one is in flight.  bf16 operands: one buffer per column block and
-  // the compiler keeps the wave's A fragments in registers across the column blocks (they do not depend on cb: 128 VGPRs at K = 128,
-  // four 32-row blocks), so the loop body is MFMAs only.  bf16x3: two buffers per column block -- first the hi image of the kernel
-  // (products a_lo.b_hi and a_hi.b_hi), then its lo image (a_hi.b_lo) -- and the A fragments (twice as many) are re-read from LDS in
-  // every phase: the compiler barriers below keep it from hoisting 256 registers' worth of them out of the loop.
-  const bool full = nrows == BM;                      // block-uniform
-  for (int cb = wave; cb < n_cb; cb += 4) {
-    u32x4 bcur[KS];
+      *reinterpret_cast<bf16x8*>(&Ap[buf][0][rr * PA + k]) = hv;
+      if (NS == 3) *reinterpret_cast<bf16x8*>(&Ap[buf][NT - 1][rr * PA + k]) = lv;
+      if (STATS) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) bcur[ks] = bnext[ks];
-    if (NS == 3) {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) bnext[ks] = wfl[((long long)cb * KS + ks) * 64 + lane];
-      asm volatile("" ::: "memory");
-    } else if (cb + 4 < n_cb) {                       // next column block: flies under this one's MFMAs
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) bnext[ks] = wfh[((long long)(cb + 4) * KS + ks) * 64 + lane];
-    }
-    f32x16 acc[MB];
-#pragma unroll
-    for (int m = 0; m < MB; ++m)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const bf16x8 vb = __builtin_bit_cast(bf16x8, bcur[ks]);
-#pragma unroll
-      for (int m = 0; m < MB; ++m) {
-        const int oa = (m * 32 + r) * PA + ks * 16 + h * 8;
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ap[0][oa]);
-        if (NS == 3) {
-          const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Ap[NT - 1][oa]);
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, vb, acc[m], 0, 0, 0);
+        for (int e = 0; e < 8; ++e) {
+          float sh = (float)hv[e], sl = NS == 3 ? (float)lv[e] : 0.f;
+          for (int o = CH; o < 64; o <<= 1) {          // lanes l, l + CH, ... of a wave hold the same 8 columns
+            sh += __shfl_xor(sh, o, 64);
+            if (NS == 3) sl += __shfl_xor(sl, o, 64);
+          }
+          if (lane < CH) {                             // lane = chunk index: one adder per (wave, column), no atomics needed
+            red[wave][lane * 8 + e] += sh;
+            if (NS == 3) red[wave][K + lane * 8 + e] += sl;
+          }
         }
-        acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vb, acc[m], 0, 0, 0);
       }
     }
-    if (NS == 3) {
+  };
+  issue(p_begin);
+  convert(p_begin, 0);
+  __syncthreads();
+
+  // ---- the run's panels ------------------------------------------------------------------------------------------------------
+  float best[CBW], ss[CBW];
+  int bq[CBW];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) bcur[ks] = bnext[ks];
-      if (cb + 4 < n_cb) {
+  for (int i = 0; i < CBW; ++i) { best[i] = -INFINITY; ss[i] = 0.f; bq[i] = 0; }
+  for (int pnl = p_begin; pnl < p_end; ++pnl) {
+    const int buf = (pnl - p_begin) & 1;
+    const int nrows = min(BM, g.N - pnl * BM);
+    const bool full = nrows == BM;                   // block-uniform
+    if (pnl + 1 < p_end) issue(pnl + 1);             // flies under this panel's MFMAs
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) bnext[ks] = wfh[((long long)(cb + 4) * KS + ks) * 64 + lane];
-      }
-      asm volatile("" ::: "memory");
+    for (int i = 0; i < CBW; ++i) {
+      asm volatile("" ::: "memory");                 // A fragments are re-read per column block: keeps them out of long-lived registers
+      f32x16 acc[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 vb = __builtin_bit_cast(bf16x8, bcur[ks]);
+        const bf16x8 vb = __builtin_bit_cast(bf16x8, (i * NT < RB) ? bw[i * NT < RB ? i * NT : 0][ks] : Bl[wave][(i * NT - RB) * KS + ks][lane]);
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ap[0][(m * 32 + r) * PA + ks * 16 + h * 8]);
-          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vb, acc[m], 0, 0, 0);
+        for (int m = 0; m < 2; ++m) {
+          const int oa = (m * 32 + r) * PA + ks * 16 + h * 8;
+          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ap[buf][0][oa]);
+          if (NS == 3) {
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Ap[buf][NT - 1][oa]);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, vb, acc[m], 0, 0, 0);
+          }
+          if (!(DBG & 8)) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vb, acc[m], 0, 0, 0);
+          else acc[m][0] += (float)ah[0] * (float)vb[0];
+        }
+        if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // at most two k-steps of A fragments in flight (registers)
+      }
+      if (NS == 3) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const bf16x8 vb = __builtin_bit_cast(bf16x8, (i * NT + 1 < RB) ? bw[i * NT + 1 < RB ? i * NT + 1 : 0][ks] : Bl[wave][(i * NT + 1 - RB) * KS + ks][lane]);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ap[buf][0][(m * 32 + r) * PA + ks * 16 + h * 8]);
+            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vb, acc[m], 0, 0, 0);
+          }
         }
       }
-    }
-    // ---- epilogue: this lane's column over its 16 rows of every 32-row block (the other half-wave holds the other 16) --------
-    float best = -INFINITY, ss = 0.f;
-    int bq = 0;
-    if (STATS) {
-      f32x2 s2 = {0.f, 0.f};                           // packed pairs: v_pk_fma_f32
-#pragma unroll
-      for (int m = 0; m < MB; ++m)
+      // ---- epilogue: this lane's column over its 16 rows of each 32-row block (the other half-wave holds the other 16) --------
+      if (DBG & 1) {                                   // ablation: keep the accumulators alive, skip the epilogue
+        ss[i] += acc[0][0] + acc[0][15] + acc[1][0] + acc[1][15];
+        continue;
+      }
+      if (STATS) {
+        f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};       // two independent packed chains (v_pk_fma_f32)
 #pragma unroll
         for (int e = 0; e < 16; e += 2) {
-          const f32x2 v2 = {acc[m][e], acc[m][e + 1]};
-          s2 = __builtin_elementwise_fma(v2, v2, s2);
+          const f32x2 v0 = {acc[0][e], acc[0][e + 1]}, v1 = {acc[1][e], acc[1][e + 1]};
+          s0 = __builtin_elementwise_fma(v0, v0, s0);
+          s1 = __builtin_elementwise_fma(v1, v1, s1);
         }
-      ss = s2.x + s2.y;
-    }
-#pragma unroll
-    for (int m = 0; m < MB; ++m) {
-      float mx;
-      if (full) {
-        mx = fmaxf(fmaxf(acc[m][0], acc[m][1]), acc[m][2]);              // v_max3_f32 chains
-#pragma unroll
-        for (int e = 3; e < 15; e += 2) mx = fmaxf(fmaxf(mx, acc[m][e]), acc[m][e + 1]);
-        mx = fmaxf(mx, acc[m][15]);
-      } else {
-        mx = -INFINITY;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int il = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          mx = fmaxf(mx, il < nrows ? acc[m][e] : -INFINITY);
-        }
+        ss[i] += (s0.x + s0.y) + (s1.x + s1.y);
       }
-      const bool better = mx > best;                   // blocks ascend: the first maximum wins
-      best = better ? mx : best;
-      bq = better ? m : bq;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float mx;
+        if (full) {
+          const float t0 = fmaxf(fmaxf(acc[m][0], acc[m][1]), acc[m][2]), t1 = fmaxf(fmaxf(acc[m][3], acc[m][4]), acc[m][5]);
+          const float t2 = fmaxf(fmaxf(acc[m][6], acc[m][7]), acc[m][8]), t3 = fmaxf(fmaxf(acc[m][9], acc[m][10]), acc[m][11]);
+          const float t4 = fmaxf(fmaxf(acc[m][12], acc[m][13]), acc[m][14]);
+          mx = fmaxf(fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)), fmaxf(t4, acc[m][15]));       // v_max3_f32 tree
+        } else {
+          mx = -INFINITY;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int il = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            mx = fmaxf(mx, il < nrows ? acc[m][e] : -INFINITY);
+          }
+        }
+        const bool better = mx > best[i];              // panels and blocks ascend: the first maximum wins
+        best[i] = better ? mx : best[i];
+        bq[i] = better ? (pnl * 2 + m) : bq[i];
+      }
     }
-    const float ob = __shfl_xor(best, 32, 64);
-    const int oq = __shfl_xor(bq, 32, 64);
-    const bool take = ob > best || (ob == best && oq < bq);
-    best = take ? ob : best;
-    bq = take ? oq : bq;
-    if (STATS) ss += __shfl_xor(ss, 32, 64);
+    if (pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);    // the other image was last read before the previous barrier
+    __syncthreads();
+  }
+
+  // ---- flush the run: one value per (slot, channel) --------------------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < CBW; ++i) {
+    const float ob = __shfl_xor(best[i], 32, 64);
+    const int oq = __shfl_xor(bq[i], 32, 64);
+    const bool take = ob > best[i] || (ob == best[i] && oq < bq[i]);
+    const float bv = take ? ob : best[i];
+    const int bqv = take ? oq : bq[i];
+    float sv = ss[i];
+    if (STATS || (DBG & 1)) sv += __shfl_xor(sv, 32, 64);
     if (h == 0) {
-      const long long o = (long long)bx * g.C + cb * 32 + r;
-      g.pmax[o] = best;
-      g.pq[o] = (row_in_cloud0 >> 5) + bq;
-      if (STATS && g.sumsq) g.sumsq[o] = ss;
+      const long long o = (long long)slot * g.C + cbs[i] * 32 + r;
+      g.pmax[o] = bv;
+      g.pq[o] = bqv;
+      if (STATS && g.sumsq) g.sumsq[o] = sv;
+    }
+  }
+  if (STATS && g.a1 && cg == 0) {
+    // (the last conversion is behind the loop's final barrier: red[][] is complete)
+    for (int col = tid; col < NT * K; col += THREADS) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += red[w][col];
+      g.a1[(long long)slot * (NT * K) + col] = t;
     }
   }
 }
 
-template <int NS, int K>
-static void launch_panel(const PanelArgs& g, dim3 grid, bool stats, int panel_rows, hipStream_t st) {
-  if (panel_rows == 128) {
-    if (stats) hipLaunchKernelGGL((panel_max_kernel<NS, K, true, 4>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((panel_max_kernel<NS, K, false, 4>), grid, dim3(256), 0, st, g);
-  } else {
-    if (stats) hipLaunchKernelGGL((panel_max_kernel<NS, K, true, 2>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((panel_max_kernel<NS, K, false, 2>), grid, dim3(256), 0, st, g);
+template <int NS, int K, int CBW>
+static void launch_panel(const PanelArgs& g, dim3 grid, bool stats, hipStream_t st) {
+  const int dbg = getenv("PN_PANEL_DBG") ? atoi(getenv("PN_PANEL_DBG")) : 0;   // read at every call: the probe flips it between runs
+  if constexpr (NS == 1 && K == 128 && CBW == 4) {
+    if (dbg && stats) {
+#define PN_PANEL_DBG_CASE(D)                                                                            \
+  if (dbg == D) {                                                                                       \
+    hipLaunchKernelGGL((panel_max_kernel<1, 128, true, 4, D>), grid, dim3(512), 0, st, g);             \
+    return;                                                                                             \
   }
+      PN_PANEL_DBG_CASE(1) PN_PANEL_DBG_CASE(4) PN_PANEL_DBG_CASE(8) PN_PANEL_DBG_CASE(9) PN_PANEL_DBG_CASE(13)
+#undef PN_PANEL_DBG_CASE
+    }
+  }
+  if (stats) hipLaunchKernelGGL((panel_max_kernel<NS, K, true, CBW>), grid, dim3(512), 0, st, g);
+  else hipLaunchKernelGGL((panel_max_kernel<NS, K, false, CBW>), grid, dim3(512), 0, st, g);
+}
+template <int NS, int K>
+static void launch_panel_cbw(const PanelArgs& g, int C, bool stats, hipStream_t st) {
+  constexpr int CBW_MAX = (NS == 3) ? 2 : 4;
+  int cbw = C / 256;                                   // column blocks per wave if one workgroup owned every column
+  if (cbw > CBW_MAX) cbw = CBW_MAX;
+  const dim3 grid(g.B * g.spc, C / (256 * cbw));
+  if (cbw == 4) { if constexpr (CBW_MAX >= 4) launch_panel<NS, K, 4>(g, grid, stats, st); }
+  else if (cbw == 2) launch_panel<NS, K, 2>(g, grid, stats, st);
+  else launch_panel<NS, K, 1>(g, grid, stats, st);
 }
 
 int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo, int B, int N, int K, int C, float* pmax, int* pq,
-                       float* sumsq, float* a1, int prec, int panel_rows, hipStream_t st) {
+                       float* sumsq, float* a1, int prec, hipStream_t st) {
   PN_CHECK_ARG(x && x->s1 && !x->s2, "pn_conv_fwd_max_panel: bad operand");
   PN_CHECK_ARG((reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && x->ld % 4 == 0 && x->ld >= K, "pn_conv_fwd_max_panel: operand alignment");
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_fwd_max_panel: B and N must be positive");
   PN_CHECK_ARG(K == 64 || K == 128, "pn_conv_fwd_max_panel: K must be 64 or 128 (K=%d)", K);
-  PN_CHECK_ARG(C >= 128 && C % 128 == 0, "pn_conv_fwd_max_panel: C must be a multiple of 128 (C=%d)", C);
+  PN_CHECK_ARG(C >= 256 && C % 256 == 0 && (C / 256 == 1 || C / 256 == 2 || C % 1024 == 0), "pn_conv_fwd_max_panel: C must be 256, 512 or a multiple of 1024 (C=%d)", C);
   PN_CHECK_ARG(wf_hi && pmax && pq, "pn_conv_fwd_max_panel: null pointer");
   PN_CHECK_ARG((sumsq == nullptr) == (a1 == nullptr), "pn_conv_fwd_max_panel: sumsq and a1 come together (both or neither)");
   PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && wf_lo), "pn_conv_fwd_max_panel: bad prec / missing lo weights");
-  PN_CHECK_ARG(panel_rows == 64 || panel_rows == 128, "pn_conv_fwd_max_panel: panel_rows must be 64 or 128");
   PanelArgs g;
   memset(&g, 0, sizeof(g));
   g.a = *x; g.wf_hi = reinterpret_cast<const __bf16*>(wf_hi); g.wf_lo = reinterpret_cast<const __bf16*>(wf_lo);
   g.B = B; g.N = N; g.C = C;
-  g.tiles_per_cloud = cdiv(N, panel_rows);
+  g.spc = panel_slots_per_cloud(B, N);
   g.pmax = pmax; g.pq = pq; g.sumsq = sumsq; g.a1 = a1;
-  const dim3 grid(B * g.tiles_per_cloud);
   const bool st_ = sumsq != nullptr;
   if (prec == PN_PREC_BF16X3) {
-    if (K == 128) launch_panel<3, 128>(g, grid, st_, panel_rows, st);
-    else launch_panel<3, 64>(g, grid, st_, panel_rows, st);
+    if (K == 128) launch_panel_cbw<3, 128>(g, C, st_, st);
+    else launch_panel_cbw<3, 64>(g, C, st_, st);
   } else {
-    if (K == 128) launch_panel<1, 128>(g, grid, st_, panel_rows, st);
-    else launch_panel<1, 64>(g, grid, st_, panel_rows, st);
+    if (K == 128) launch_panel_cbw<1, 128>(g, C, st_, st);
+    else launch_panel_cbw<1, 64>(g, C, st_, st);
   }
   PN_CHECK_LAUNCH();
   return PN_OK;
@@ -367,7 +439,16 @@ __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs 
     {
       const int col = tid % NTK, p0 = tid / NTK;
       double s = 0.0;
-      for (int p = p0; p < a.T; p += pstep) s += (double)a.a1[(long long)p * NTK + col];
+      for (int p = p0; p < a.T; p += 16 * pstep) {     // sixteen independent loads in flight, summed in panel order
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int pp = p + u * pstep;
+          v[u] = pp < a.T ? a.a1[(long long)pp * NTK + col] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += (double)v[u];
+      }
       a1s[tid] = s;                                    // slot p0 * NTK + col
     }
     __syncthreads();
@@ -399,7 +480,16 @@ __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs 
     }
     // (3) sum z^2 over the panels: thread <-> (channel, every 8th panel)
     double sq = 0.0;
-    for (int p = part; p < a.T; p += 8) sq += (double)a.sumsq[(long long)p * a.C + c];
+    for (int p = part; p < a.T; p += 8 * 16) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int pp = p + u * 8;
+        v[u] = pp < a.T ? a.sumsq[(long long)pp * a.C + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u) sq += (double)v[u];
+    }
     red[part][0][cl] = sz;
     red[part][1][cl] = sq;
     __syncthreads();
@@ -459,19 +549,18 @@ __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs 
 }
 
 int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const float* a1, const void* wf_hi, const void* wf_lo, int B, int N,
-                   int K, int C, int panel_rows, int prec, const float* gamma, const float* beta, float* mm, float* mv, float momentum,
+                   int K, int C, int prec, const float* gamma, const float* beta, float* mm, float* mv, float momentum,
                    float eps, int use_batch, int update, float* mean, float* invstd, float* scale, float* shift, float* g, float* zstar,
                    int* argq, hipStream_t st) {
   PN_CHECK_ARG(pmax && pq && gamma && beta && mm && mv && mean && invstd && scale && shift && g, "pn_panel_finalize: null pointer");
   PN_CHECK_ARG(!use_batch || (sumsq && a1 && wf_hi), "pn_panel_finalize: batch statistics need sumsq, a1 and the weight copy");
   PN_CHECK_ARG(B > 0 && N > 0 && C > 0 && C % 32 == 0 && (K == 64 || K == 128), "pn_panel_finalize: bad sizes");
-  PN_CHECK_ARG(panel_rows == 64 || panel_rows == 128, "pn_panel_finalize: panel_rows must be 64 or 128");
   PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && (!use_batch || wf_lo)), "pn_panel_finalize: bad prec / missing lo weights");
   PanelFinArgs a;
   memset(&a, 0, sizeof(a));
   a.pmax = pmax; a.pq = pq; a.sumsq = sumsq; a.a1 = a1;
   a.wf_hi = reinterpret_cast<const __bf16*>(wf_hi); a.wf_lo = reinterpret_cast<const __bf16*>(wf_lo);
-  a.tpc = cdiv(N, panel_rows); a.T = B * a.tpc; a.B = B; a.C = C; a.K = K; a.NT = prec == PN_PREC_BF16X3 ? 2 : 1;
+  a.tpc = panel_slots_per_cloud(B, N); a.T = B * a.tpc; a.B = B; a.C = C; a.K = K; a.NT = prec == PN_PREC_BF16X3 ? 2 : 1;
   a.n_blocks32 = cdiv(N, 32);
   a.inv_count = 1.0 / ((double)B * (double)N);
   a.gamma = gamma; a.beta = beta; a.mm = mm; a.mv = mv; a.momentum = momentum; a.eps = eps; a.use_batch = use_batch; a.update = update;

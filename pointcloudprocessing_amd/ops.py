@@ -75,22 +75,22 @@ def weights_prep(w, sgn=None):
     return hi, lo
 
 
-def conv_fwd_max_panel(x_op, wf, B, N, K, C_, prec, want_stats=True, panel_rows=128):
-    """the row-panel kernel: per tile and channel max of sgn*z, the 32-row block holding it and (want_stats) sum z^2; per tile the
-    column sums a1 of the staged panel.  wf = weights_prep(w, gamma)."""
+def conv_fwd_max_panel(x_op, wf, B, N, K, C_, prec, want_stats=True):
+    """the row-panel kernel: per slot (run of 64-row panels) and channel max of sgn*z, the 32-row block holding it and (want_stats)
+    sum z^2; per slot the column sums a1 of the staged rows.  wf = weights_prep(w, gamma)."""
     dev = wf[0].device
-    T = B * ((N + panel_rows - 1) // panel_rows)
+    T = B * lib().pn_panel_slots_per_cloud(B, N)
     nt = 2 if prec == 3 else 1
     pmax = torch.empty(T, C_, device=dev, dtype=F32)
     pblk = torch.empty(T, C_, device=dev, dtype=torch.int32)
     sumsq = torch.empty(T, C_, device=dev, dtype=F32) if want_stats else None
     a1 = torch.empty(T, nt * K, device=dev, dtype=F32) if want_stats else None
     check(lib().pn_conv_fwd_max_panel(C.byref(x_op), ptr(wf[0]), ptr(wf[1]), B, N, K, C_, ptr(pmax), ptr(pblk), ptr(sumsq), ptr(a1), prec,
-                                      panel_rows, current_stream()), "pn_conv_fwd_max_panel")
+                                      current_stream()), "pn_conv_fwd_max_panel")
     return pmax, pblk, sumsq, a1
 
 
-def panel_finalize(pmax, pblk, sumsq, a1, wf, B, N, K, prec, gamma, beta, moving_mean, moving_var, training=True, panel_rows=128,
+def panel_finalize(pmax, pblk, sumsq, a1, wf, B, N, K, prec, gamma, beta, moving_mean, moving_var, training=True,
                    momentum=0.99, eps=1e-3):
     """BN coefficients of the layer + reduce_max over each cloud's tiles -> (mean, invstd, scale, shift, g, zstar, arg_block)"""
     C_ = pmax.shape[1]
@@ -99,7 +99,7 @@ def panel_finalize(pmax, pblk, sumsq, a1, wf, B, N, K, prec, gamma, beta, moving
     g = torch.empty(B, C_, device=dev, dtype=F32)
     zstar = torch.empty(B, C_, device=dev, dtype=F32)
     argb = torch.empty(B, C_, device=dev, dtype=torch.int32)
-    check(lib().pn_panel_finalize(ptr(pmax), ptr(pblk), ptr(sumsq), ptr(a1), ptr(wf[0]), ptr(wf[1]), B, N, K, C_, panel_rows, prec,
+    check(lib().pn_panel_finalize(ptr(pmax), ptr(pblk), ptr(sumsq), ptr(a1), ptr(wf[0]), ptr(wf[1]), B, N, K, C_, prec,
                                   ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), momentum, eps, int(training), int(training),
                                   ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(g), ptr(zstar), ptr(argb), current_stream()),
           "pn_panel_finalize")

@@ -43,7 +43,7 @@ def test_inference_forward_matches_oracle(dev, vanilla, B, N):
     assert float(safe.double().mean()) > 0.5
 
 
-@pytest.mark.parametrize("profile", list(PROFILES))
+@pytest.mark.parametrize("profile", ["all", "classification_pretrain", "final", "heads_only"])
 @pytest.mark.parametrize("vanilla", [False, True])
 def test_training_step_gradients_match_oracle(dev, profile, vanilla):
     # batch-statistics BatchNormalization over the B rows of the T-Net dense layers amplifies rounding differences by

@@ -138,9 +138,9 @@ def test_conv_fwd_lazy_bn_relu_and_per_cloud_weights(dev, prec):
     assert err < tol * max(1.0, float(ref.abs().max())), float(err)
 
 
-@pytest.mark.parametrize("panel", [0, 64, 128])     # 0: the tiled kernel; 64 / 128: rows per panel of the panel kernel
+@pytest.mark.parametrize("panel", [0, 1])     # 0: the tiled kernel of the generic engine; 1: the kernel-stationary panel kernel
 @pytest.mark.parametrize("prec", [1, 3])
-@pytest.mark.parametrize("B,N", [(2, 256), (3, 200), (1, 1000), (2, 33), (16, 136)])
+@pytest.mark.parametrize("B,N", [(2, 256), (3, 200), (1, 1000), (2, 33), (16, 136), (40, 520), (300, 70)])
 def test_conv_fwd_max_matches_reduce_max(dev, prec, B, N, panel):
     """ConvLayer(128->1024)+BN+ReLU+reduce_max (PointNet.py:242-248) without the (B,N,1024) tensor."""
     ops = _ops()
@@ -158,10 +158,10 @@ def test_conv_fwd_max_matches_reduce_max(dev, prec, B, N, panel):
         # the row-panel kernel (the one the model plan uses): max / 32-row block / sum of squares per tile, column sums of the panel,
         # one finaliser for the BN coefficients and the reduce_max, and the row resolved among the block's 32 candidates
         wf = ops.weights_prep(w.to(dev), gamma.to(dev))
-        pmax, pblk, sumsq, a1 = ops.conv_fwd_max_panel(op, wf, B, N, K, C, prec, panel_rows=panel)
+        pmax, pblk, sumsq, a1 = ops.conv_fwd_max_panel(op, wf, B, N, K, C, prec)
         mmd, mvd = mm.to(dev), mv.to(dev)
         mean, invstd, scale, shift, gfeat, zstar, argb = ops.panel_finalize(pmax, pblk, sumsq, a1, wf, B, N, K, prec, gamma.to(dev),
-                                                                           beta.to(dev), mmd, mvd, training=True, panel_rows=panel)
+                                                                           beta.to(dev), mmd, mvd, training=True)
         arg = ops.max_resolve(op, wf, argb, B, N, K, C, prec)
         assert int(argb.min()) >= 0 and int(argb.max()) <= (N - 1) // 32
     else:
@@ -206,7 +206,7 @@ def test_panel_path_on_real_valued_clouds_with_duplicated_points(dev, prec):
     gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
     op = _lib().operand(x.to(dev), ca=sc.to(dev), cc=sh.to(dev), relu=True)
     wf = ops.weights_prep(w.to(dev), gamma.to(dev))
-    pmax, pblk, sumsq, a1 = ops.conv_fwd_max_panel(op, wf, B, N, K, C, prec, panel_rows=128)
+    pmax, pblk, sumsq, a1 = ops.conv_fwd_max_panel(op, wf, B, N, K, C, prec)
     mmd, mvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
     mean, invstd, scale, shift, gfeat, zstar, argb = ops.panel_finalize(pmax, pblk, sumsq, a1, wf, B, N, K, prec, gamma.to(dev), beta.to(dev),
                                                                        mmd, mvd, training=True)

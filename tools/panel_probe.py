@@ -13,7 +13,8 @@ from pointcloudprocessing_amd import _lib, ops   # noqa: E402
 
 dev = torch.device("cuda:0")
 K, C_ = 128, 1024
-for B, N in ((32, 1024), (32, 4096), (8, 4096), (32, 2048)):
+ABLATE = os.environ.get("PROBE_ABLATE", "0") == "1"      # time the PN_PANEL_DBG variants (bf16, statistics) instead of the product kernel
+for B, N in (((32, 1024), (32, 4096)) if ABLATE else ((32, 1024), (32, 4096), (8, 4096), (32, 2048))):
     g = torch.Generator().manual_seed(B * N)
     x = torch.randn(B * N, K, generator=g).to(dev)
     w = (torch.randn(K, C_, generator=g) / 11).to(dev)
@@ -21,16 +22,17 @@ for B, N in ((32, 1024), (32, 4096), (8, 4096), (32, 2048)):
     sc, sh = (torch.rand(K, generator=g) + 0.5).to(dev), (torch.randn(K, generator=g) * 0.3).to(dev)
     op = _lib.operand(x, ca=sc, cc=sh, relu=True)
     wf = ops.weights_prep(w, gamma)
-    for prec in (1, 3):
-        for rows in (128, 64):
-            for stats in (True, False):
+    for prec in ((1,) if ABLATE else (1, 3)):
+        for rows in (64,):
+            for stats, dbg in ([(True, d) for d in (0, 1, 4, 8, 9, 13)] if ABLATE else [(True, 0), (False, 0)]):
+                os.environ["PN_PANEL_DBG"] = str(dbg)
                 for _ in range(3):
-                    outs = ops.conv_fwd_max_panel(op, wf, B, N, K, C_, prec, want_stats=stats, panel_rows=rows)
-                T = B * ((N + rows - 1) // rows)
+                    outs = ops.conv_fwd_max_panel(op, wf, B, N, K, C_, prec, want_stats=stats)
+                T = outs[0].shape[0]
                 pmax, pblk = outs[0], outs[1]
                 sumsq, a1 = outs[2], outs[3]
                 args = (_lib.C.byref(op), _lib.ptr(wf[0]), _lib.ptr(wf[1]), B, N, K, C_, _lib.ptr(pmax), _lib.ptr(pblk), _lib.ptr(sumsq), _lib.ptr(a1),
-                        prec, rows, _lib.current_stream())
+                        prec, _lib.current_stream())
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 torch.cuda.synchronize()
                 e0.record()
@@ -40,5 +42,6 @@ for B, N in ((32, 1024), (32, 4096), (8, 4096), (32, 2048)):
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / 50
                 tf = 2.0 * K * C_ * B * N / (us * 1e-6) / 1e12
-                print(json.dumps({"B": B, "N": N, "prec": prec, "panel_rows": rows, "stats": stats, "tiles": T, "us": round(us, 2),
+                print(json.dumps({"B": B, "N": N, "prec": prec, "panel_rows": rows, "stats": stats, "dbg": dbg, "tiles": T, "us": round(us, 2),
                                   "TFLOPs": round(tf, 1), "frac_of_2.5PF": round(tf / 2500 / (3 if prec == 3 else 1), 4)}), flush=True)
+os.environ.pop("PN_PANEL_DBG", None)
