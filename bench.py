@@ -163,7 +163,7 @@ def main():
     for src, ml in layers:
         op = _lib.operand(wsf(src + ".Z").view(B * N, K_), ca=wsf(src + ".scale"), cc=wsf(src + ".shift"), relu=True)
         a = (C.byref(op), _lib.ptr(wsf(ml + ".wb_hi", torch.bfloat16)), _lib.ptr(wsf(ml + ".wb_lo", torch.bfloat16)), B, N, K_, C_,
-             _lib.ptr(wsf(ml + ".pmax")), _lib.ptr(wsf(ml + ".pq", torch.int32)), _lib.ptr(wsf(ml + ".sumsq")), _lib.ptr(wsf(ml + ".pa1")),
+             _lib.ptr(wsf(ml + ".pmax")), _lib.ptr(wsf(ml + ".pq", torch.int32)), _lib.ptr(wsf(ml + ".sumsq")), _lib.ptr(wsf(ml + ".sumz")),
              prec_id, _lib.current_stream())
         for _ in range(3):
             _lib.check(_lib.lib().pn_conv_fwd_max_panel(*a), "pn_conv_fwd_max_panel")

@@ -75,7 +75,7 @@ SIGNATURES = {
     "pn_weights_prep": (_I, [_P, _P, _I, _I, _P, _P, _P]),
     "pn_panel_slots_per_cloud": (_I, [_I, _I]),
     "pn_conv_fwd_max_panel": (_I, [_OP, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
-    "pn_panel_finalize": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pn_panel_finalize": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "pn_max_resolve": (_I, [_OP, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "pn_conv_bwd_data": (_I, [_OP, _P, _I64, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "pn_conv_wgrad": (_I, [_OP, _OP, _I, _I, _I, _I, _I, _P, _I, _P]),

@@ -28,11 +28,10 @@ int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, i
 int weights_prep(const float* w, const float* sgn, int K, int C, void* hi, void* lo, hipStream_t st);
 int panel_slots_per_cloud(int B, int N);
 int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo, int B, int N, int K, int C, float* pmax, int* pq,
-                       float* sumsq, float* a1, int prec, hipStream_t st);
-int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const float* a1, const void* wf_hi, const void* wf_lo, int B, int N,
-                   int K, int C, int prec, const float* gamma, const float* beta, float* mm, float* mv, float momentum,
-                   float eps, int use_batch, int update, float* mean, float* invstd, float* scale, float* shift, float* g, float* zstar,
-                   int* argq, hipStream_t st);
+                       float* sumsq, float* sumz, int prec, hipStream_t st);
+int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const float* sumz, int B, int N, int C, const float* gamma,
+                   const float* beta, float* mm, float* mv, float momentum, float eps, int use_batch, int update, float* mean, float* invstd,
+                   float* scale, float* shift, float* g, float* zstar, int* argq, hipStream_t st);
 
 // pn_pointwise.hip
 int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st);
@@ -113,8 +112,12 @@ int maxbwd_dw_batch(const DwJob* jobs, int n_jobs, int B, int N, int K, int C, h
 int maxbwd_dw(const pn_operand* x, const int* arg, const float* hs, int B, int N, int K, int C, const float* a1, const float* f,
               const float* e, const float* GW, float* dW, hipStream_t st);
 int maxbwd_q(const float* w, const float* f, int K, int C, float* q, hipStream_t st);
-int maxbwd_scatter(const pn_operand* x, const void* wf_hi, const void* wf_lo, int prec, const int* argq, int* arg, const float* hs,
-                   const float* wt, const float* q, int B, int N, int K, int C, float* D, hipStream_t st);
+int maxbwd_scatter(const int* arg, const float* hs, const float* wt, const float* q, int B, int N, int K, int C, float* D,
+                   hipStream_t st);
+int maxbwd_prep_resolve(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean,
+                        const float* invstd, const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege,
+                        float* f, float* dgamma, float* dbeta, const float* W, int K, float* Wt, float* We, const pn_operand* x,
+                        const void* wf_hi, const void* wf_lo, int prec, const int* argq, int N, int* arg, hipStream_t st);
 int max_resolve(const pn_operand* x, const void* wf_hi, const void* wf_lo, int prec, const int* argq, int B, int N, int K, int C, int* arg,
                 hipStream_t st);
 

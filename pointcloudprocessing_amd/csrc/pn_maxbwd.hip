@@ -19,19 +19,30 @@
 namespace pn {
 
 // block = 32 channels x 8 partitions of the clouds: h, S1, S2 -> hs (B,C), e, f, dgamma, dbeta
-__global__ __launch_bounds__(256) void maxbwd_prep_kernel(const float* __restrict__ dg, const float* __restrict__ dg2, const float* __restrict__ g,
-                                                          const float* __restrict__ zstar, int B, int C,
-                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                          const float* __restrict__ scale, int batch_stats, double inv_count,
-                                                          float* __restrict__ hs, float* __restrict__ e, float* __restrict__ nege,
-                                                          float* __restrict__ f, float* __restrict__ dgamma,
-                                                          float* __restrict__ dbeta, const float* __restrict__ W, int K,
-                                                          float* __restrict__ Wt, float* __restrict__ We) {
+struct PrepArgs {
+  const float *dg, *dg2, *g, *zstar;
+  int B, C;
+  const float *mean, *invstd, *scale;
+  int batch_stats;
+  double inv_count;
+  float *hs, *e, *nege, *f, *dgamma, *dbeta;
+  const float* W;
+  int K;
+  float *Wt, *We;
+};
+__device__ __forceinline__ void maxbwd_prep_body(const PrepArgs& a, int bx) {
+  const float* __restrict__ dg = a.dg; const float* __restrict__ dg2 = a.dg2; const float* __restrict__ g = a.g;
+  const float* __restrict__ zstar = a.zstar; const int B = a.B, C = a.C;
+  const float* __restrict__ mean = a.mean; const float* __restrict__ invstd = a.invstd; const float* __restrict__ scale = a.scale;
+  const int batch_stats = a.batch_stats; const double inv_count = a.inv_count;
+  float* __restrict__ hs = a.hs; float* __restrict__ e = a.e; float* __restrict__ nege = a.nege; float* __restrict__ f = a.f;
+  float* __restrict__ dgamma = a.dgamma; float* __restrict__ dbeta = a.dbeta; const float* __restrict__ W = a.W; const int K = a.K;
+  float* __restrict__ Wt = a.Wt; float* __restrict__ We = a.We;
   __shared__ double red[8][2][32];
   __shared__ float neg_s[32];
   __shared__ float tt[128][33];
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + tx;
+  const int c = bx * 32 + tx;
   float sc = 0.f, mu = 0.f, is = 0.f;
   double S1 = 0.0, S2 = 0.0;
   if (c < C) {
@@ -69,7 +80,7 @@ __global__ __launch_bounds__(256) void maxbwd_prep_kernel(const float* __restric
   }
   if (!W) return;
   // channel-major copies of this block's 32 kernel columns: Wt[c][k] = W[k][c], We[c][k] = -e[c] W[k][c]
-  const int c0 = blockIdx.x * 32;
+  const int c0 = bx * 32;
   for (int k0 = 0; k0 < K; k0 += 128) {           // 128 kernel rows per pass: 16 loads in flight per thread, one barrier pair
     float v[16];
 #pragma unroll
@@ -203,16 +214,24 @@ __device__ __forceinline__ void resolve_stage(const pn_operand& x, int cloud, in
   for (int i = tid; i < 32 * (K / 8); i += nthreads) {
     const int row = i / (K / 8), k = (i % (K / 8)) * 8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float ca[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, cc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (row < nr) {
       const float* s = x.s1 + ((long long)cloud * N + rbase + row) * x.ld + k;
       const float4 v0 = *reinterpret_cast<const float4*>(s), v1 = *reinterpret_cast<const float4*>(s + 4);
       v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
     }
+    if (x.ca) {
+      const float4 t0 = *reinterpret_cast<const float4*>(x.ca + k), t1 = *reinterpret_cast<const float4*>(x.ca + k + 4);
+      ca[0] = t0.x; ca[1] = t0.y; ca[2] = t0.z; ca[3] = t0.w; ca[4] = t1.x; ca[5] = t1.y; ca[6] = t1.z; ca[7] = t1.w;
+    }
+    if (x.cc) {
+      const float4 t0 = *reinterpret_cast<const float4*>(x.cc + k), t1 = *reinterpret_cast<const float4*>(x.cc + k + 4);
+      cc[0] = t0.x; cc[1] = t0.y; cc[2] = t0.z; cc[3] = t0.w; cc[4] = t1.x; cc[5] = t1.y; cc[6] = t1.z; cc[7] = t1.w;
+    }
     mb_bf16x8 hv, lv;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float ca = x.ca ? x.ca[k + e] : 1.f, cc = x.cc ? x.cc[k + e] : 0.f;
-      const float t = row < nr ? clamp_lo(fmaf(ca, v[e], cc), x.lo) : 0.f;
+      const float t = row < nr ? clamp_lo(fmaf(ca[e], v[e], cc[e]), x.lo) : 0.f;
       hv[e] = (__bf16)t;
       if (NT == 2) lv[e] = (__bf16)(t - (float)hv[e]);
     }
@@ -232,22 +251,34 @@ __device__ __forceinline__ int resolve_group(const __bf16* __restrict__ Ab_hi, c
   mb_f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  for (int ks = 0; ks < KS; ++ks) {
-    const long long chunk = ((long long)cb * KS + ks) * 64 + h * 32 + cl;
-    const mb_bf16x8 bh = *reinterpret_cast<const mb_bf16x8*>(wf_hi + chunk * 8);
-    const mb_bf16x8 ah = *reinterpret_cast<const mb_bf16x8*>(Ab_hi + r * RS_PITCH + ks * 16 + h * 8);
-    if (NT == 2) {
-      const mb_bf16x8 al = *reinterpret_cast<const mb_bf16x8*>(Ab_lo + r * RS_PITCH + ks * 16 + h * 8);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+  // every weight fragment of the group is requested before the first MFMA: the gathered 16-byte loads are one L2 round trip in all,
+  // not one per k-step (K <= 128: at most 8 k-steps)
+  constexpr int KSM = RS_KMAX / 16;
+  mb_bf16x8 bh[KSM], bl[NT == 2 ? KSM : 1];
+#pragma unroll
+  for (int ks = 0; ks < KSM; ++ks) {
+    const long long chunk = ((long long)cb * KS + (ks < KS ? ks : 0)) * 64 + h * 32 + cl;
+    bh[ks] = *reinterpret_cast<const mb_bf16x8*>(wf_hi + chunk * 8);
+    if (NT == 2) bl[ks] = *reinterpret_cast<const mb_bf16x8*>(wf_lo + chunk * 8);
+  }
+#pragma unroll
+  for (int ks = 0; ks < KSM; ++ks) {
+    if (ks < KS) {
+      const mb_bf16x8 ah = *reinterpret_cast<const mb_bf16x8*>(Ab_hi + r * RS_PITCH + ks * 16 + h * 8);
+      if (NT == 2) {
+        const mb_bf16x8 al = *reinterpret_cast<const mb_bf16x8*>(Ab_lo + r * RS_PITCH + ks * 16 + h * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[ks], acc, 0, 0, 0);
+      }
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[ks], acc, 0, 0, 0);
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
   }
   if (NT == 2) {
-    for (int ks = 0; ks < KS; ++ks) {
-      const long long chunk = ((long long)cb * KS + ks) * 64 + h * 32 + cl;
-      const mb_bf16x8 bl = *reinterpret_cast<const mb_bf16x8*>(wf_lo + chunk * 8);
-      const mb_bf16x8 ah = *reinterpret_cast<const mb_bf16x8*>(Ab_hi + r * RS_PITCH + ks * 16 + h * 8);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+#pragma unroll
+    for (int ks = 0; ks < KSM; ++ks) {
+      if (ks < KS) {
+        const mb_bf16x8 ah = *reinterpret_cast<const mb_bf16x8*>(Ab_hi + r * RS_PITCH + ks * 16 + h * 8);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[ks], acc, 0, 0, 0);
+      }
     }
   }
   float best = -INFINITY;
@@ -267,16 +298,16 @@ __device__ __forceinline__ int resolve_group(const __bf16* __restrict__ Ab_hi, c
   return (row >= 0 && row < nr) ? row : 0;
 }
 
-// standalone form (op-level API pn_max_resolve; the model plan resolves inside maxbwd_scatter_kernel): one workgroup per 32-row block
+// one workgroup per 32-row block of a cloud: the rows of every channel whose maximum the forward pass located in this block
 template <int NT>
-__global__ __launch_bounds__(256) void max_resolve_kernel(const pn_operand x, const __bf16* __restrict__ wf_hi, const __bf16* __restrict__ wf_lo,
-                                                          const int* __restrict__ argq, int N, int K, int C, int quarters_per_cloud,
-                                                          int* __restrict__ arg) {
+__device__ __forceinline__ void max_resolve_body(const pn_operand& x, const __bf16* __restrict__ wf_hi, const __bf16* __restrict__ wf_lo,
+                                                 const int* __restrict__ argq, int N, int K, int C, int quarters_per_cloud,
+                                                 int* __restrict__ arg, int bx) {
   __shared__ __attribute__((aligned(16))) __bf16 Ab_hi[32 * RS_PITCH];
   __shared__ __attribute__((aligned(16))) __bf16 Ab_lo[NT == 2 ? 32 * RS_PITCH : 8];
   __shared__ int hit_c[1024];
   __shared__ int nhit;
-  const int bx = blockIdx.x, cloud = bx / quarters_per_cloud, qin = bx - cloud * quarters_per_cloud;
+  const int cloud = bx / quarters_per_cloud, qin = bx - cloud * quarters_per_cloud;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int rbase = qin * 32, nr = min(32, N - rbase);
   bool staged = false;
@@ -303,6 +334,24 @@ __global__ __launch_bounds__(256) void max_resolve_kernel(const pn_operand x, co
     __syncthreads();
   }
 }
+// standalone form: the op-level API pn_max_resolve
+template <int NT>
+__global__ __launch_bounds__(256) void max_resolve_kernel(const pn_operand x, const __bf16* __restrict__ wf_hi, const __bf16* __restrict__ wf_lo,
+                                                          const int* __restrict__ argq, int N, int K, int C, int quarters_per_cloud,
+                                                          int* __restrict__ arg) {
+  max_resolve_body<NT>(x, wf_hi, wf_lo, argq, N, K, C, quarters_per_cloud, arg, blockIdx.x);
+}
+// the form the model plan uses: ONE launch for the preparation of the Gram-form backward (C / 32 workgroups: few, latency bound)
+// and the row resolution (one workgroup per 32-row block: many, independent of the former) -- the second rides in the first's shadow
+template <int NT>
+__global__ __launch_bounds__(256) void maxbwd_prep_resolve_kernel(const PrepArgs pa, int n_prep, const pn_operand x,
+                                                                  const __bf16* __restrict__ wf_hi, const __bf16* __restrict__ wf_lo,
+                                                                  const int* __restrict__ argq, int N, int K, int C,
+                                                                  int quarters_per_cloud, int* __restrict__ arg) {
+  if ((int)blockIdx.x < n_prep) maxbwd_prep_body(pa, blockIdx.x);
+  else max_resolve_body<NT>(x, wf_hi, wf_lo, argq, N, K, C, quarters_per_cloud, arg, (int)blockIdx.x - n_prep);
+}
+__global__ __launch_bounds__(256) void maxbwd_prep_kernel(const PrepArgs pa) { maxbwd_prep_body(pa, blockIdx.x); }
 
 // D[m][k] = q[k] + sum_{c : arg[b][c] == m} hs[b][c] * Wt[c][k]        one block per 32-row quarter tile.
 // Critical points are few: the 1024 arg-max rows of a cloud concentrate on a handful of points, so a tile can
@@ -310,55 +359,33 @@ __global__ __launch_bounds__(256) void max_resolve_kernel(const pn_operand x, co
 // with LDS atomics in 2^-40 FIXED POINT (int64): integer addition is associative, so the result does not depend on
 // the order in which the four waves process the hits -> full parallelism AND bitwise reproducibility.
 // |hs*W| < 2^22 is assumed (the products are gradient-sized).  K <= 128, K % 4 == 0.
-// The channels of this tile are those whose maximum the forward pass located in this 32-row block (argq); their exact rows are
-// resolved here first (resolve_row) and written to `arg` for the weight-gradient kernel and the tests.
-template <int NT>
-__global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const pn_operand x, const __bf16* __restrict__ wf_hi, const __bf16* __restrict__ wf_lo,
-                                                             const int* __restrict__ argq, int* __restrict__ arg, const float* __restrict__ hs,
+__global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restrict__ arg, const float* __restrict__ hs,
                                                              const float* __restrict__ wt, const float* __restrict__ q, int N,
                                                              int K, int C, int quarters_per_cloud, float* __restrict__ D) {
   constexpr int CHUNK = 1024;                  // channels examined per round (4 per thread)
   constexpr double FX = 1099511627776.0;       // 2^40
   __shared__ unsigned long long tile[32][128]; // 32 KB
-  __shared__ __attribute__((aligned(16))) __bf16 Ab_hi[32 * RS_PITCH];
-  __shared__ __attribute__((aligned(16))) __bf16 Ab_lo[NT == 2 ? 32 * RS_PITCH : 8];
   __shared__ int hit_pk[CHUNK];                // (row << 16) | channel-in-chunk, unordered
   __shared__ int nhit;
   const int bx = blockIdx.x, cloud = bx / quarters_per_cloud, qin = bx - cloud * quarters_per_cloud;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int rbase = qin * 32, nr = min(32, N - rbase);
-  const int* qb = argq + (long long)cloud * C;
+  const int* ab = arg + (long long)cloud * C;
   const float* hb = hs + (long long)cloud * C;
   for (int i = t; i < 32 * 128; i += 256) (&tile[0][0])[i] = 0ull;
   if (t == 0) nhit = 0;
   __syncthreads();
-  bool staged = false;
   for (int c0 = 0; c0 < C; c0 += CHUNK) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = c0 + 4 * t + i;
-      if (c < C && qb[c] == qin) hit_pk[atomicAdd(&nhit, 1)] = 4 * t + i;
+      const int m = (c < C) ? (ab[c] - rbase) : -1;
+      if (m >= 0 && m < nr) hit_pk[atomicAdd(&nhit, 1)] = (m << 16) | (4 * t + i);
     }
     __syncthreads();
     const int total = nhit;
-    if (total > 0 && !staged) {                // block-uniform
-      resolve_stage<NT>(x, cloud, N, K, rbase, nr, Ab_hi, Ab_lo, t, 256);
-      staged = true;
-      __syncthreads();
-    }
-    // the rows: 32 hits per wave at a time on the matrix cores (resolve_group); every hit's entry gets its row packed in
-    for (int g0 = wave * 32; g0 < total; g0 += 4 * 32) {          // wave-uniform
-      const int i = g0 + (lane & 31);
-      const int cc = hit_pk[min(i, total - 1)];
-      const int row = resolve_group<NT>(Ab_hi, Ab_lo, wf_hi, wf_lo, c0 + cc, K, nr, lane);
-      if (lane < 32 && i < total) {
-        hit_pk[i] = (row << 16) | cc;
-        arg[(long long)cloud * C + c0 + cc] = rbase + row;
-      }
-    }
-    __syncthreads();                           // the scatter below walks the list with another wave <-> hit assignment
-    // eight hits (16 row loads per lane) are in flight at a time: the arg-max rows of a cloud concentrate on a few points, so some
-    // tiles carry hundreds of hits and the launch lasts as long as its heaviest tile
+    // wave w takes hits w, w+4, ...; eight of them (16 row loads per lane) are in flight at a time: the arg-max rows of a cloud
+    // concentrate on a few points, so some tiles carry hundreds of hits and the launch lasts as long as its heaviest tile
     constexpr int UF = 8;                      // 16 in flight measured no better
     for (int i0 = wave; i0 < total; i0 += 4 * UF) {
       int pk[UF];
@@ -395,13 +422,44 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const pn_operand x,
   }
 }
 
+static PrepArgs make_prep(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean,
+                          const float* invstd, const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege,
+                          float* f, float* dgamma, float* dbeta, const float* W, int K, float* Wt, float* We) {
+  PrepArgs a;
+  a.dg = dg; a.dg2 = dg2; a.g = g; a.zstar = zstar; a.B = B; a.C = C; a.mean = mean; a.invstd = invstd; a.scale = scale;
+  a.batch_stats = batch_stats; a.inv_count = 1.0 / (double)count; a.hs = hs; a.e = e; a.nege = nege; a.f = f; a.dgamma = dgamma;
+  a.dbeta = dbeta; a.W = W; a.K = K; a.Wt = Wt; a.We = We;
+  return a;
+}
 int maxbwd_prep(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean, const float* invstd,
                 const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege, float* f, float* dgamma,
                 float* dbeta, const float* W, int K, float* Wt, float* We, hipStream_t st) {
   PN_CHECK_ARG((dg || dg2) && g && zstar && mean && invstd && scale && hs && e && nege && f, "maxbwd_prep: null pointer");
   PN_CHECK_ARG(!W || (Wt && We && K > 0), "maxbwd_prep: the transposed copies need Wt and We");
-  hipLaunchKernelGGL(maxbwd_prep_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, dg, dg2, g, zstar, B, C, mean, invstd, scale, batch_stats,
-                     1.0 / (double)count, hs, e, nege, f, dgamma, dbeta, W, K, Wt, We);
+  const PrepArgs a = make_prep(dg, dg2, g, zstar, B, C, mean, invstd, scale, batch_stats, count, hs, e, nege, f, dgamma, dbeta, W, K, Wt, We);
+  hipLaunchKernelGGL(maxbwd_prep_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, a);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+// the same + the rows of the maxima (argq -> arg) in one launch
+int maxbwd_prep_resolve(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean,
+                        const float* invstd, const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege,
+                        float* f, float* dgamma, float* dbeta, const float* W, int K, float* Wt, float* We, const pn_operand* x,
+                        const void* wf_hi, const void* wf_lo, int prec, const int* argq, int N, int* arg, hipStream_t st) {
+  PN_CHECK_ARG((dg || dg2) && g && zstar && mean && invstd && scale && hs && e && nege && f, "maxbwd_prep: null pointer");
+  PN_CHECK_ARG(!W || (Wt && We && K > 0), "maxbwd_prep: the transposed copies need Wt and We");
+  PN_CHECK_ARG(x && x->s1 && !x->s2 && wf_hi && argq && arg, "maxbwd_prep_resolve: null pointer");
+  PN_CHECK_ARG(K <= RS_KMAX && K % 16 == 0 && C % 32 == 0, "maxbwd_prep_resolve: K must be a multiple of 16, at most 128, C a multiple of 32");
+  PN_CHECK_ARG((reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && x->ld % 4 == 0, "maxbwd_prep_resolve: operand alignment");
+  PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && wf_lo), "maxbwd_prep_resolve: bad prec / missing lo weights");
+  const PrepArgs a = make_prep(dg, dg2, g, zstar, B, C, mean, invstd, scale, batch_stats, count, hs, e, nege, f, dgamma, dbeta, W, K, Wt, We);
+  const int n_prep = cdiv(C, 32), qpc = cdiv(N, 32);
+  const __bf16* wh = reinterpret_cast<const __bf16*>(wf_hi);
+  const __bf16* wl = reinterpret_cast<const __bf16*>(wf_lo);
+  if (prec == PN_PREC_BF16X3)
+    hipLaunchKernelGGL((maxbwd_prep_resolve_kernel<2>), dim3(n_prep + B * qpc), dim3(256), 0, st, a, n_prep, *x, wh, wl, argq, N, K, C, qpc, arg);
+  else
+    hipLaunchKernelGGL((maxbwd_prep_resolve_kernel<1>), dim3(n_prep + B * qpc), dim3(256), 0, st, a, n_prep, *x, wh, wl, argq, N, K, C, qpc, arg);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -444,20 +502,12 @@ int maxbwd_q(const float* w, const float* f, int K, int C, float* q, hipStream_t
   return PN_OK;
 }
 
-int maxbwd_scatter(const pn_operand* x, const void* wf_hi, const void* wf_lo, int prec, const int* argq, int* arg, const float* hs,
-                   const float* wt, const float* q, int B, int N, int K, int C, float* D, hipStream_t st) {
-  PN_CHECK_ARG(x && x->s1 && !x->s2 && wf_hi && argq && arg && hs && wt && q && D, "maxbwd_scatter: null pointer");
-  PN_CHECK_ARG(K <= RS_KMAX && K % 16 == 0 && C % 32 == 0, "maxbwd_scatter: K must be a multiple of 16, at most 128, C a multiple of 32 (K=%d C=%d)", K, C);
-  PN_CHECK_ARG(C <= 65536, "maxbwd_scatter: C must be at most 65536");
-  PN_CHECK_ARG((reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && x->ld % 4 == 0, "maxbwd_scatter: operand alignment");
-  PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && wf_lo), "maxbwd_scatter: bad prec / missing lo weights");
+int maxbwd_scatter(const int* arg, const float* hs, const float* wt, const float* q, int B, int N, int K, int C, float* D,
+                   hipStream_t st) {
+  PN_CHECK_ARG(arg && hs && wt && q && D, "maxbwd_scatter: null pointer");
+  PN_CHECK_ARG(K <= 128, "maxbwd_scatter: K must be <= 128 (K=%d)", K);
   const int qpc = cdiv(N, 32);
-  const __bf16* wh = reinterpret_cast<const __bf16*>(wf_hi);
-  const __bf16* wl = reinterpret_cast<const __bf16*>(wf_lo);
-  if (prec == PN_PREC_BF16X3)
-    hipLaunchKernelGGL((maxbwd_scatter_kernel<2>), dim3(B * qpc), dim3(256), 0, st, *x, wh, wl, argq, arg, hs, wt, q, N, K, C, qpc, D);
-  else
-    hipLaunchKernelGGL((maxbwd_scatter_kernel<1>), dim3(B * qpc), dim3(256), 0, st, *x, wh, wl, argq, arg, hs, wt, q, N, K, C, qpc, D);
+  hipLaunchKernelGGL(maxbwd_scatter_kernel, dim3(B * qpc), dim3(256), 0, st, arg, hs, wt, q, N, K, C, qpc, D);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

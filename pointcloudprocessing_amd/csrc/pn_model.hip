@@ -207,7 +207,7 @@ static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, 
   m.pmax = A.get<float>((n + ".pmax").c_str(), (size_t)B * cdiv(N, 64) * C);
   m.pq = A.get<int>((n + ".pq").c_str(), (size_t)B * cdiv(N, 64) * C);
   m.sumsq = A.get<float>((n + ".sumsq").c_str(), (size_t)B * cdiv(N, 64) * C);
-  m.pa1 = A.get<float>((n + ".pa1").c_str(), (size_t)B * cdiv(N, 64) * 2 * K);
+  m.pa1 = A.get<float>((n + ".sumz").c_str(), (size_t)B * cdiv(N, 64) * C);
   m.argq = A.get<int>((n + ".argq").c_str(), (size_t)B * C);
   m.wb_hi = A.get<unsigned short>((n + ".wb_hi").c_str(), (size_t)K * C);
   m.wb_lo = A.get<unsigned short>((n + ".wb_lo").c_str(), (size_t)K * C);
@@ -485,8 +485,8 @@ struct Run {
     PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.pmax, m.pq, ub ? m.sumsq : nullptr, ub ? m.pa1 : nullptr, prec, st));
     if (ev && ev[2 * prof_slot + 1]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot + 1]), st);
     // one finaliser: the layer's BatchNormalization coefficients (+ moving statistics) and the reduce_max over each cloud's panels
-    return panel_finalize(m.pmax, m.pq, m.sumsq, m.pa1, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, prec, p(r.gamma), p(r.beta), p(r.mm),
-                          p(r.mv), d.bn_momentum, d.bn_eps, ub, ub, l.mean, l.invstd, l.scale, l.shift, m.g, m.zstar, m.argq, st);
+    return panel_finalize(m.pmax, m.pq, m.sumsq, m.pa1, B, N, r.cout, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub,
+                          ub, l.mean, l.invstd, l.scale, l.shift, m.g, m.zstar, m.argq, st);
   }
   // out (B, C) = x (B, K) . W (+ bias): one launch (pn_dense.hip); trans reads W^T from the same (C, K)-major... kernel
   int dense_plain(const float* x, int ldx, const float* W, int ldw, bool trans, int K, int C, const float* bias, float* out) {
@@ -661,30 +661,11 @@ struct Run {
     const int K = r.cin, C = r.cout;
     const int bs = bn_batch(r.block) ? 1 : 0;
     const bool wg = tr(r.block) && G;
-    // + the channel-major copies Wt, We = -e (.) Wt used below, written by the same launch
-    PN_TRY(maxbwd_prep(dG, dG2, m.g, m.zstar, B, C, l.mean, l.invstd, l.scale, bs, M, m.hs, m.e, m.nege, m.f, wg ? gr(r.gamma) : nullptr,
-                       wg ? gr(r.beta) : nullptr, p(r.kernel), K, m.Wt, m.We, st));
-    // Pm[k'][k] = sum_c (-e_c) W[k'][c] W[k][c]: the contraction runs over the 1024 channels, so it is laid out as a
-    // weight-gradient problem over "rows" c (16 slabs of 64 channels -> 16 workgroups) instead of one 128x128 tile
-    // ... and q = W f (needs only maxbwd_prep's f) rides in the launch that reduces those slabs
-    {
-      int spc;
-      const int rows = (int)wgrad_slab_rows(1, C, K, K, &spc);
-      float* sl = cur_slabs();
-      if ((size_t)spc * K * K > (sl == w.slabs ? w.slab_floats : w.slab_main_floats)) {
-        set_error("wgrad: slab scratch too small");
-        return PN_ERR_WORKSPACE;
-      }
-      const pn_operand we = plain(m.We, K), wt = plain(m.Wt, K);
-      static const bool pm_small = !(getenv("PN_PM_SMALL") && atoi(getenv("PN_PM_SMALL")) == 0);
-      const WgradDesc pmd{we, wt, 1, C, K, K, rows, sl, PN_PREC_BF16X3, 0, pm_small ? 1 : 0};   // 64x64 tiles: 4x the workgroups of this 16-slab job
-      PN_TRY(conv_wgrad_batch(&pmd, 1, st));
-      PN_TRY(slab_reduce_q(sl, spc, (long long)K * K, m.Pm, p(r.kernel), m.f, K, C, m.q, st));
-    }
-    // the rows of the maxima are resolved inside the scatter (m.argq -> m.arg); the weight-gradient kernel reads m.arg afterwards
-    PN_TRY(maxbwd_scatter(&xop, m.wb_hi, m.wb_lo, prec, m.argq, m.arg, m.hs, m.Wt, m.q, B, N, K, C, m.D, st));
-    PN_TRY(conv_bwd_data(&xop, m.Pm, 0, B, N, K, K, m.D, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st));
-    // the parameter-gradient branch comes last: it reads m.arg, which the scatter above has just resolved
+    // + the channel-major copies Wt, We = -e (.) Wt used below, and -- in the same launch, on workgroups of their own -- the rows of
+    // the maxima (m.argq, left by the forward pass, -> m.arg: pn_maxbwd.hip)
+    PN_TRY(maxbwd_prep_resolve(dG, dG2, m.g, m.zstar, B, C, l.mean, l.invstd, l.scale, bs, M, m.hs, m.e, m.nege, m.f, wg ? gr(r.gamma) : nullptr,
+                               wg ? gr(r.beta) : nullptr, p(r.kernel), K, m.Wt, m.We, &xop, m.wb_hi, m.wb_lo, prec, m.argq, N, m.arg, st));
+    // the parameter-gradient branch forks here: it needs m.arg, hs, e, f of the launch above and nothing of what follows
     if (wg) {
       const ML mm = m;
       float* dw = gr(r.kernel);
@@ -714,6 +695,25 @@ struct Run {
       }));
       PN_TRY(flush());
     }
+    // Pm[k'][k] = sum_c (-e_c) W[k'][c] W[k][c]: the contraction runs over the 1024 channels, so it is laid out as a
+    // weight-gradient problem over "rows" c (16 slabs of 64 channels -> 16 workgroups) instead of one 128x128 tile
+    // ... and q = W f (needs only maxbwd_prep's f) rides in the launch that reduces those slabs
+    {
+      int spc;
+      const int rows = (int)wgrad_slab_rows(1, C, K, K, &spc);
+      float* sl = cur_slabs();
+      if ((size_t)spc * K * K > (sl == w.slabs ? w.slab_floats : w.slab_main_floats)) {
+        set_error("wgrad: slab scratch too small");
+        return PN_ERR_WORKSPACE;
+      }
+      const pn_operand we = plain(m.We, K), wt = plain(m.Wt, K);
+      static const bool pm_small = !(getenv("PN_PM_SMALL") && atoi(getenv("PN_PM_SMALL")) == 0);
+      const WgradDesc pmd{we, wt, 1, C, K, K, rows, sl, PN_PREC_BF16X3, 0, pm_small ? 1 : 0};   // 64x64 tiles: 4x the workgroups of this 16-slab job
+      PN_TRY(conv_wgrad_batch(&pmd, 1, st));
+      PN_TRY(slab_reduce_q(sl, spc, (long long)K * K, m.Pm, p(r.kernel), m.f, K, C, m.q, st));
+    }
+    PN_TRY(maxbwd_scatter(m.arg, m.hs, m.Wt, m.q, B, N, K, C, m.D, st));
+    PN_TRY(conv_bwd_data(&xop, m.Pm, 0, B, N, K, K, m.D, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st));
     return PN_OK;
   }
   // dense layer backward: da (B,C) -> dx (B,K) written to dx_out; parameter gradients

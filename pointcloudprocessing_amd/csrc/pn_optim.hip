@@ -86,13 +86,10 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ R, c
     s = fmaf(d, d, s);
     if (dR) dR[i] += gscale * d;
   }
-  red[threadIdx.x] = s;
+  s = wave_sum(s);                                   // fixed order: butterfly inside the wave, then the four waves in turn
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float a = 0.f;
-    for (int i = 0; i < 256; ++i) a += red[i];
-    if (loss_sum) *loss_sum = a;
-  }
+  if (threadIdx.x == 0 && loss_sum) *loss_sum = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // Orthogonality regulariser per cloud: E = I - R R^T; loss += c/2 * sum E^2; dR += -2c E R.   block per cloud

@@ -101,7 +101,7 @@ struct PanelArgs {
   float* pmax;                  // [B * spc][C]  max over the slot's rows of the accumulator (= sgn * z with presigned weights)
   int* pq;                      // [B * spc][C]  index inside the cloud of the 32-row block that held it (lowest on ties)
   float* sumsq;                 // [B * spc][C]  sum over the slot's rows of z^2, or NULL
-  float* a1;                    // [B * spc][NT * K]  column sums of the staged bf16 rows (hi image, then lo image), or NULL
+  float* sumz;                  // [B * spc][C]  sum over the slot's rows of the accumulator (sgn * z), or NULL (comes with sumsq)
 };
 // PN_PANEL_DBG (timing ablations of the bf16, K = 128, statistics variant; WRONG results; tools/panel_probe.py): template bit mask DBG:
 // 1 no epilogue, 4 no activation loads, 8 no MFMAs
@@ -132,10 +132,12 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
   constexpr int RP = THREADS / CH;                   // rows per staging pass
   constexpr int P = BM / RP;                         // passes (2 at K = 128, 1 at K = 64)
   constexpr int NBLK = CBW * NT;                     // B blocks (column block x image) of KS fragments each owned by a wave
-  constexpr int RB = NBLK < 3 ? NBLK : 3;            // ... of which this many live in registers (RB * KS * 4 VGPRs) and the rest in LDS:
+  constexpr int RBMAX = (NS == 3 || STATS) ? 3 : 4;
+  constexpr int RB = NBLK < RBMAX ? NBLK : RBMAX;    // ... of which this many live in registers (RB * KS * 4 VGPRs) and the rest in LDS:
   constexpr int LB = NBLK - RB;                      // 4 x 32 VGPRs + accumulators + staging do not fit 256 registers without spills
   __shared__ __attribute__((aligned(16))) __bf16 Ap[2][NT][BM * PA];
   __shared__ float red[8][NT * K];
+  __shared__ float a1s[NT * K];                      // column sums of the slot's staged rows (hi image, then lo image)
   __shared__ u32x4 Bl[LB > 0 ? 8 : 1][LB > 0 ? LB * KS : 1][LB > 0 ? 64 : 1];   // [wave][block, k-step][lane]: lane-linear, conflict-free
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -167,9 +169,9 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
   const int ch = tid % CH, rin = tid / CH;
   const int k = ch * 8;
   const float lo = g.a.lo;
-  // column sums of the staged images (a1): accumulated in LDS, one float per column and wave (red[wave][..]), so that they cost no
-  // long-lived registers; a conversion adds its rows' values after a four-lane (K = 128) shuffle reduction
-  for (int i = tid; i < 8 * NT * K; i += THREADS) (&red[0][0])[i] = 0.f;
+  float a1h[8], a1l[NS == 3 ? 8 : 1];                // this thread's share of the column sums of the staged images (its 8 columns)
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { a1h[e] = 0.f; if (NS == 3) a1l[e] = 0.f; }
   float4 x[P][2];
   auto issue = [&](int panel) {
     const int rbase = panel * BM, nrows = min(BM, g.N - rbase);
@@ -219,15 +221,8 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
       if (STATS) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          float sh = (float)hv[e], sl = NS == 3 ? (float)lv[e] : 0.f;
-          for (int o = CH; o < 64; o <<= 1) {          // lanes l, l + CH, ... of a wave hold the same 8 columns
-            sh += __shfl_xor(sh, o, 64);
-            if (NS == 3) sl += __shfl_xor(sl, o, 64);
-          }
-          if (lane < CH) {                             // lane = chunk index: one adder per (wave, column), no atomics needed
-            red[wave][lane * 8 + e] += sh;
-            if (NS == 3) red[wave][K + lane * 8 + e] += sl;
-          }
+          a1h[e] += (float)hv[e];
+          if (NS == 3) a1l[e] += (float)lv[e];
         }
       }
     }
@@ -247,74 +242,71 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
     const bool full = nrows == BM;                   // block-uniform
     if (pnl + 1 < p_end) issue(pnl + 1);             // flies under this panel's MFMAs
 #pragma unroll
-    for (int i = 0; i < CBW; ++i) {
-      asm volatile("" ::: "memory");                 // A fragments are re-read per column block: keeps them out of long-lived registers
-      f32x16 acc[2];
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+    for (int m = 0; m < 2; ++m) {                    // the panel's two 32-row blocks in turn
+      // this wave's A fragments of the block: read from LDS once and used for all its column blocks (KS x 4 VGPRs per image)
+      asm volatile("" ::: "memory");
+      bf16x8 af[KS], afl[NS == 3 ? KS : 1];
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 vb = __builtin_bit_cast(bf16x8, (i * NT < RB) ? bw[i * NT < RB ? i * NT : 0][ks] : Bl[wave][(i * NT - RB) * KS + ks][lane]);
-#pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const int oa = (m * 32 + r) * PA + ks * 16 + h * 8;
-          const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ap[buf][0][oa]);
-          if (NS == 3) {
-            const bf16x8 al = *reinterpret_cast<const bf16x8*>(&Ap[buf][NT - 1][oa]);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, vb, acc[m], 0, 0, 0);
-          }
-          if (!(DBG & 8)) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vb, acc[m], 0, 0, 0);
-          else acc[m][0] += (float)ah[0] * (float)vb[0];
-        }
-        if ((ks & 1) == 1) __builtin_amdgcn_sched_barrier(0);      // at most two k-steps of A fragments in flight (registers)
+        const int oa = (m * 32 + r) * PA + ks * 16 + h * 8;
+        af[ks] = *reinterpret_cast<const bf16x8*>(&Ap[buf][0][oa]);
+        if (NS == 3) afl[ks] = *reinterpret_cast<const bf16x8*>(&Ap[buf][NT - 1][oa]);
       }
-      if (NS == 3) {
+#pragma unroll
+      for (int i = 0; i < CBW; ++i) {                // one 32 x 32 accumulator (16 registers) at a time
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          const bf16x8 vb = __builtin_bit_cast(bf16x8, (i * NT + 1 < RB) ? bw[i * NT + 1 < RB ? i * NT + 1 : 0][ks] : Bl[wave][(i * NT + 1 - RB) * KS + ks][lane]);
+          const bf16x8 vb = __builtin_bit_cast(bf16x8, (i * NT < RB) ? bw[i * NT < RB ? i * NT : 0][ks] : Bl[wave][(i * NT - RB) * KS + ks][lane]);
+          if (NS == 3) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afl[ks], vb, acc, 0, 0, 0);
+          if (!(DBG & 8)) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], vb, acc, 0, 0, 0);
+          else acc[0] += (float)af[ks][0] * (float)vb[0];
+        }
+        if (NS == 3) {
 #pragma unroll
-          for (int m = 0; m < 2; ++m) {
-            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&Ap[buf][0][(m * 32 + r) * PA + ks * 16 + h * 8]);
-            acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, vb, acc[m], 0, 0, 0);
+          for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8 vb = __builtin_bit_cast(bf16x8, (i * NT + 1 < RB) ? bw[i * NT + 1 < RB ? i * NT + 1 : 0][ks] : Bl[wave][(i * NT + 1 - RB) * KS + ks][lane]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], vb, acc, 0, 0, 0);
           }
         }
-      }
-      // ---- epilogue: this lane's column over its 16 rows of each 32-row block (the other half-wave holds the other 16) --------
-      if (DBG & 1) {                                   // ablation: keep the accumulators alive, skip the epilogue
-        ss[i] += acc[0][0] + acc[0][15] + acc[1][0] + acc[1][15];
-        continue;
-      }
-      if (STATS) {
-        f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};       // two independent packed chains (v_pk_fma_f32)
-#pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-          const f32x2 v0 = {acc[0][e], acc[0][e + 1]}, v1 = {acc[1][e], acc[1][e + 1]};
-          s0 = __builtin_elementwise_fma(v0, v0, s0);
-          s1 = __builtin_elementwise_fma(v1, v1, s1);
+        // ---- epilogue: this lane's column over its 16 rows of the 32-row block (the other half-wave holds the other 16) ----------
+        if (DBG & 1) {                                 // ablation: keep the accumulator alive, skip the epilogue
+          ss[i] += acc[0] + acc[15];
+          continue;
         }
-        ss[i] += (s0.x + s0.y) + (s1.x + s1.y);
-      }
+        if (STATS) {
+          f32x2 s0 = {0.f, 0.f}, s1 = {0.f, 0.f};     // two independent packed chains (v_pk_fma_f32)
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+          for (int e = 0; e < 16; e += 4) {
+            const f32x2 v0 = {acc[e], acc[e + 1]}, v1 = {acc[e + 2], acc[e + 3]};
+            s0 = __builtin_elementwise_fma(v0, v0, s0);
+            s1 = __builtin_elementwise_fma(v1, v1, s1);
+          }
+          ss[i] += (s0.x + s0.y) + (s1.x + s1.y);
+        }
         float mx;
         if (full) {
-          const float t0 = fmaxf(fmaxf(acc[m][0], acc[m][1]), acc[m][2]), t1 = fmaxf(fmaxf(acc[m][3], acc[m][4]), acc[m][5]);
-          const float t2 = fmaxf(fmaxf(acc[m][6], acc[m][7]), acc[m][8]), t3 = fmaxf(fmaxf(acc[m][9], acc[m][10]), acc[m][11]);
-          const float t4 = fmaxf(fmaxf(acc[m][12], acc[m][13]), acc[m][14]);
-          mx = fmaxf(fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)), fmaxf(t4, acc[m][15]));       // v_max3_f32 tree
+          const float t0 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]), t1 = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
+          const float t2 = fmaxf(fmaxf(acc[6], acc[7]), acc[8]), t3 = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
+          const float t4 = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
+          mx = fmaxf(fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)), fmaxf(t4, acc[15]));       // v_max3_f32 tree
         } else {
           mx = -INFINITY;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
             const int il = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-            mx = fmaxf(mx, il < nrows ? acc[m][e] : -INFINITY);
+            mx = fmaxf(mx, il < nrows ? acc[e] : -INFINITY);
           }
         }
         const bool better = mx > best[i];              // panels and blocks ascend: the first maximum wins
         best[i] = better ? mx : best[i];
         bq[i] = better ? (pnl * 2 + m) : bq[i];
+        // pin the epilogue here: left alone, the scheduler sinks the sum-of-squares chains of all eight blocks of a panel behind
+        // the last MFMA and keeps 8 x 16 accumulator registers alive for them (spills); the other wave of the SIMD covers the gap
+        if (STATS) asm volatile("" : "+v"(ss[i]));
+        asm volatile("" : "+v"(best[i]));
       }
     }
     if (pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);    // the other image was last read before the previous barrier
@@ -338,13 +330,50 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
       if (STATS && g.sumsq) g.sumsq[o] = sv;
     }
   }
-  if (STATS && g.a1 && cg == 0) {
-    // (the last conversion is behind the loop's final barrier: red[][] is complete)
+  if (STATS && g.sumz) {
+    // sum over the slot's rows of z = (column sums of the staged rows) . W: the column sums a1 are gathered from the eight waves
+    // (lanes l, l + CH, ... of a wave hold the same 8 columns -> butterfly, one slot per (wave, column) in LDS, 8-way sum), then every
+    // lane dots them with the kernel fragments it still holds -- half of k per half-wave
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      for (int o = CH; o < 64; o <<= 1) {
+        a1h[e] += __shfl_xor(a1h[e], o, 64);
+        if (NS == 3) a1l[e] += __shfl_xor(a1l[e], o, 64);
+      }
+    }
+    if (lane < CH) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[wave][lane * 8 + e] = a1h[e];
+        if (NS == 3) red[wave][K + lane * 8 + e] = a1l[e];
+      }
+    }
+    __syncthreads();
     for (int col = tid; col < NT * K; col += THREADS) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) t += red[w][col];
-      g.a1[(long long)slot * (NT * K) + col] = t;
+      a1s[col] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < CBW; ++i) {
+      float sz = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const bf16x8 vh = __builtin_bit_cast(bf16x8, (i * NT < RB) ? bw[i * NT < RB ? i * NT : 0][ks] : Bl[wave][(i * NT - RB) * KS + ks][lane]);
+        bf16x8 vl;
+        if (NS == 3) vl = __builtin_bit_cast(bf16x8, (i * NT + 1 < RB) ? bw[i * NT + 1 < RB ? i * NT + 1 : 0][ks] : Bl[wave][(i * NT + 1 - RB) * KS + ks][lane]);
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+          const int kk = ks * 16 + h * 8 + jj;
+          const float wh = (float)vh[jj];
+          sz = fmaf(a1s[kk], wh, sz);                                   // a_hi . b_hi
+          if (NS == 3) sz = fmaf(a1s[K + kk], wh, fmaf(a1s[kk], (float)vl[jj], sz));     // + a_lo . b_hi + a_hi . b_lo
+        }
+      }
+      sz += __shfl_xor(sz, 32, 64);
+      if (h == 0) g.sumz[(long long)slot * g.C + cbs[i] * 32 + r] = sz;
     }
   }
 }
@@ -378,21 +407,21 @@ static void launch_panel_cbw(const PanelArgs& g, int C, bool stats, hipStream_t 
 }
 
 int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo, int B, int N, int K, int C, float* pmax, int* pq,
-                       float* sumsq, float* a1, int prec, hipStream_t st) {
+                       float* sumsq, float* sumz, int prec, hipStream_t st) {
   PN_CHECK_ARG(x && x->s1 && !x->s2, "pn_conv_fwd_max_panel: bad operand");
   PN_CHECK_ARG((reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && x->ld % 4 == 0 && x->ld >= K, "pn_conv_fwd_max_panel: operand alignment");
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_fwd_max_panel: B and N must be positive");
   PN_CHECK_ARG(K == 64 || K == 128, "pn_conv_fwd_max_panel: K must be 64 or 128 (K=%d)", K);
   PN_CHECK_ARG(C >= 256 && C % 256 == 0 && (C / 256 == 1 || C / 256 == 2 || C % 1024 == 0), "pn_conv_fwd_max_panel: C must be 256, 512 or a multiple of 1024 (C=%d)", C);
   PN_CHECK_ARG(wf_hi && pmax && pq, "pn_conv_fwd_max_panel: null pointer");
-  PN_CHECK_ARG((sumsq == nullptr) == (a1 == nullptr), "pn_conv_fwd_max_panel: sumsq and a1 come together (both or neither)");
+  PN_CHECK_ARG((sumsq == nullptr) == (sumz == nullptr), "pn_conv_fwd_max_panel: sumsq and sumz come together (both or neither)");
   PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && wf_lo), "pn_conv_fwd_max_panel: bad prec / missing lo weights");
   PanelArgs g;
   memset(&g, 0, sizeof(g));
   g.a = *x; g.wf_hi = reinterpret_cast<const __bf16*>(wf_hi); g.wf_lo = reinterpret_cast<const __bf16*>(wf_lo);
   g.B = B; g.N = N; g.C = C;
   g.spc = panel_slots_per_cloud(B, N);
-  g.pmax = pmax; g.pq = pq; g.sumsq = sumsq; g.a1 = a1;
+  g.pmax = pmax; g.pq = pq; g.sumsq = sumsq; g.sumz = sumz;
   const bool st_ = sumsq != nullptr;
   if (prec == PN_PREC_BF16X3) {
     if (K == 128) launch_panel_cbw<3, 128>(g, C, st_, st);
@@ -405,18 +434,15 @@ int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo
   return PN_OK;
 }
 
-// ---- finaliser: BatchNormalization statistics of the layer + reduce_max over each cloud's panels ---------------------------------
-// One workgroup per (column block of 32 channels, slice of the clouds).  Training statistics (use_batch): per channel
-//   sum z   = s_c * sum_k a1[k] * Wf[c][k]            a1 = sum over the panels of their column sums (both images for bf16x3)
-//   sum z^2 = sum over the panels of sumsq
-// combined in fp64 -> mean, invstd, scale, shift, moving statistics (only the workgroups of the first cloud slice write them);
-// otherwise the coefficients come from the moving statistics (inference / frozen layer, PointNet.py:585-591).  Then per cloud:
-// the largest pmax over its panels (lowest panel on ties: rows ascend with the panel index), zstar = s_c * max,
-// g = relu(scale * zstar + shift), and the 32-row block that holds the row.
+// ---- finaliser: BatchNormalization statistics of the layer + reduce_max over each cloud's slots ------------------------------------
+// One workgroup per (32 channels, slice of the clouds).  Training statistics (use_batch): per channel the sums of sumz and sumsq over
+// all slots, combined in fp64 -> mean (times the channel's sign: the panel kernel works on sgn * z), invstd, scale, shift, moving
+// statistics (only the workgroups of the first cloud slice write them); otherwise the coefficients come from the moving statistics
+// (inference / frozen layer, PointNet.py:585-591).  Then per cloud: the largest pmax over its slots (lowest slot on ties: rows ascend
+// with the slot index), zstar = s_c * max, g = relu(scale * zstar + shift), and the 32-row block that holds the row.
 struct PanelFinArgs {
-  const float* pmax; const int* pq; const float* sumsq; const float* a1;
-  const __bf16* wf_hi; const __bf16* wf_lo;
-  int T, tpc, B, C, K, NT, n_blocks32;
+  const float* pmax; const int* pq; const float* sumsq; const float* sumz;
+  int T, tpc, B, C, n_blocks32;
   double inv_count;
   const float* gamma; const float* beta; float* mm; float* mv;
   float momentum, eps;
@@ -425,82 +451,39 @@ struct PanelFinArgs {
   int* argq;
 };
 __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs a) {
-  __shared__ double a1s[256];
   __shared__ double red[8][2][32];
   __shared__ float sc_s[32], sh_s[32], sg_s[32];
   const int tid = threadIdx.x, cl = tid & 31, part = tid >> 5;
-  const int cb = blockIdx.x, c = cb * 32 + cl;
-  const int K = a.K, KS = K / 16, NTK = a.NT * K;       // NT * K <= 256
+  const int c = blockIdx.x * 32 + cl;
   const float gam = a.gamma[c];
   const float sg = gam < 0.f ? -1.f : 1.f;
   if (a.use_batch) {
-    // (1) column sums of A over all panels: thread <-> (column, every pstep-th panel); NT * K is 64, 128 or 256
-    const int pstep = 256 / NTK;
-    {
-      const int col = tid % NTK, p0 = tid / NTK;
-      double s = 0.0;
-      for (int p = p0; p < a.T; p += 16 * pstep) {     // sixteen independent loads in flight, summed in panel order
-        float v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-          const int pp = p + u * pstep;
-          v[u] = pp < a.T ? a.a1[(long long)pp * NTK + col] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) s += (double)v[u];
-      }
-      a1s[tid] = s;                                    // slot p0 * NTK + col
-    }
-    __syncthreads();
-    // (2) sum z for this block's 32 channels: thread <-> (channel, k-step)
-    double sz = 0.0;
-    for (int ks = part; ks < KS; ks += 8) {
-#pragma unroll
-      for (int hh = 0; hh < 2; ++hh) {
-        const long long chunk = ((long long)cb * KS + ks) * 64 + hh * 32 + cl;
-        const bf16x8 wh = *reinterpret_cast<const bf16x8*>(a.wf_hi + chunk * 8);
-        bf16x8 wl;
-        if (a.NT == 2) wl = *reinterpret_cast<const bf16x8*>(a.wf_lo + chunk * 8);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int k = ks * 16 + hh * 8 + j;
-          double ah = 0.0, al = 0.0;
-          for (int q = 0; q < pstep; ++q) {
-            ah += a1s[q * NTK + k];
-            if (a.NT == 2) al += a1s[q * NTK + K + k];
-          }
-          double w = (double)(float)wh[j];
-          if (a.NT == 2) {
-            sz += al * w;                              // a_lo . b_hi
-            w += (double)(float)wl[j];
-          }
-          sz += ah * w;                                // a_hi . (b_hi + b_lo)
-        }
-      }
-    }
-    // (3) sum z^2 over the panels: thread <-> (channel, every 8th panel)
-    double sq = 0.0;
+    // thread <-> (channel, every 8th slot): sixteen slots (32 independent loads) in flight, summed in slot order
+    double s1 = 0.0, s2 = 0.0;
     for (int p = part; p < a.T; p += 8 * 16) {
-      float v[16];
+      float v[16], q[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int pp = p + u * 8;
-        v[u] = pp < a.T ? a.sumsq[(long long)pp * a.C + c] : 0.f;
+        const long long o = (long long)(pp < a.T ? pp : p) * a.C + c;
+        v[u] = a.sumz[o];
+        q[u] = a.sumsq[o];
       }
 #pragma unroll
-      for (int u = 0; u < 16; ++u) sq += (double)v[u];
+      for (int u = 0; u < 16; ++u)
+        if (p + u * 8 < a.T) { s1 += (double)v[u]; s2 += (double)q[u]; }
     }
-    red[part][0][cl] = sz;
-    red[part][1][cl] = sq;
+    red[part][0][cl] = s1;
+    red[part][1][cl] = s2;
     __syncthreads();
     if (part == 0) {
-      double s1 = 0.0, s2 = 0.0;
+      s1 = 0.0; s2 = 0.0;
 #pragma unroll
       for (int q = 0; q < 8; ++q) { s1 += red[q][0][cl]; s2 += red[q][1][cl]; }
       const double mean = (double)sg * s1 * a.inv_count;
       double var = s2 * a.inv_count - mean * mean;
       var = var < 0.0 ? 0.0 : var;
-      const float is = (float)(1.0 / sqrt(var + (double)a.eps));
+      const float is = 1.0f / sqrtf((float)var + a.eps);
       const float scl = gam * is;
       const float sft = a.beta[c] - (float)mean * scl;
       sc_s[cl] = scl; sh_s[cl] = sft; sg_s[cl] = sg;
@@ -521,7 +504,7 @@ __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs 
     if (blockIdx.y == 0) { a.mean[c] = mean; a.invstd[c] = is; a.scale[c] = scl; a.shift[c] = sft; }
   }
   __syncthreads();
-  // (4) per cloud: thread <-> (channel, cloud); this block's slice of the clouds
+  // per cloud: thread <-> (channel, cloud); this block's slice of the clouds
   const float scl = sc_s[cl], sft = sh_s[cl], sgc = sg_s[cl];
   for (int b = blockIdx.y * 8 + part; b < a.B; b += 8 * gridDim.y) {
     float best = -INFINITY;
@@ -548,19 +531,16 @@ __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs 
   }
 }
 
-int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const float* a1, const void* wf_hi, const void* wf_lo, int B, int N,
-                   int K, int C, int prec, const float* gamma, const float* beta, float* mm, float* mv, float momentum,
-                   float eps, int use_batch, int update, float* mean, float* invstd, float* scale, float* shift, float* g, float* zstar,
-                   int* argq, hipStream_t st) {
+int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const float* sumz, int B, int N, int C, const float* gamma,
+                   const float* beta, float* mm, float* mv, float momentum, float eps, int use_batch, int update, float* mean, float* invstd,
+                   float* scale, float* shift, float* g, float* zstar, int* argq, hipStream_t st) {
   PN_CHECK_ARG(pmax && pq && gamma && beta && mm && mv && mean && invstd && scale && shift && g, "pn_panel_finalize: null pointer");
-  PN_CHECK_ARG(!use_batch || (sumsq && a1 && wf_hi), "pn_panel_finalize: batch statistics need sumsq, a1 and the weight copy");
-  PN_CHECK_ARG(B > 0 && N > 0 && C > 0 && C % 32 == 0 && (K == 64 || K == 128), "pn_panel_finalize: bad sizes");
-  PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && (!use_batch || wf_lo)), "pn_panel_finalize: bad prec / missing lo weights");
+  PN_CHECK_ARG(!use_batch || (sumsq && sumz), "pn_panel_finalize: batch statistics need sumsq and sumz");
+  PN_CHECK_ARG(B > 0 && N > 0 && C > 0 && C % 32 == 0, "pn_panel_finalize: bad sizes");
   PanelFinArgs a;
   memset(&a, 0, sizeof(a));
-  a.pmax = pmax; a.pq = pq; a.sumsq = sumsq; a.a1 = a1;
-  a.wf_hi = reinterpret_cast<const __bf16*>(wf_hi); a.wf_lo = reinterpret_cast<const __bf16*>(wf_lo);
-  a.tpc = panel_slots_per_cloud(B, N); a.T = B * a.tpc; a.B = B; a.C = C; a.K = K; a.NT = prec == PN_PREC_BF16X3 ? 2 : 1;
+  a.pmax = pmax; a.pq = pq; a.sumsq = sumsq; a.sumz = sumz;
+  a.tpc = panel_slots_per_cloud(B, N); a.T = B * a.tpc; a.B = B; a.C = C;
   a.n_blocks32 = cdiv(N, 32);
   a.inv_count = 1.0 / ((double)B * (double)N);
   a.gamma = gamma; a.beta = beta; a.mm = mm; a.mv = mv; a.momentum = momentum; a.eps = eps; a.use_batch = use_batch; a.update = update;

@@ -285,18 +285,20 @@ __device__ __forceinline__ void reduce_tiles_2(const float* __restrict__ part, i
   double a = 0.0, b = 0.0;
   if (c < C) {
     const float* p = part + c;
-    int t = ty;
-    for (; t + 48 < n_tiles; t += 64) {
-      const float x0 = p[(long long)t * 2 * C], y0 = p[(long long)t * 2 * C + C];
-      const float x1 = p[(long long)(t + 16) * 2 * C], y1 = p[(long long)(t + 16) * 2 * C + C];
-      const float x2 = p[(long long)(t + 32) * 2 * C], y2 = p[(long long)(t + 32) * 2 * C + C];
-      const float x3 = p[(long long)(t + 48) * 2 * C], y3 = p[(long long)(t + 48) * 2 * C + C];
-      a += (double)x0; a += (double)x1; a += (double)x2; a += (double)x3;
-      b += (double)y0; b += (double)y1; b += (double)y2; b += (double)y3;
-    }
-    for (; t < n_tiles; t += 16) {
-      a += (double)p[(long long)t * 2 * C];
-      b += (double)p[(long long)t * 2 * C + C];
+    // sixteen tiles (32 independent loads) in flight per thread: the kernel is one memory round trip per batch, and at the usual
+    // 256 tiles a thread has exactly one batch.  The summation order (tiles ascending per thread, then the 16 threads) is unchanged.
+    for (int t = ty; t < n_tiles; t += 16 * 16) {
+      float x[16], y[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int tt = t + 16 * u;
+        const long long o = (long long)(tt < n_tiles ? tt : t) * 2 * C;
+        x[u] = p[o];
+        y[u] = p[o + C];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (t + 16 * u < n_tiles) { a += (double)x[u]; b += (double)y[u]; }
     }
   }
   red[ty][0][tx] = a;

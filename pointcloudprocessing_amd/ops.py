@@ -77,21 +77,19 @@ def weights_prep(w, sgn=None):
 
 def conv_fwd_max_panel(x_op, wf, B, N, K, C_, prec, want_stats=True):
     """the row-panel kernel: per slot (run of 64-row panels) and channel max of sgn*z, the 32-row block holding it and (want_stats)
-    sum z^2; per slot the column sums a1 of the staged rows.  wf = weights_prep(w, gamma)."""
+    sum z^2 and sum sgn*z.  wf = weights_prep(w, gamma)."""
     dev = wf[0].device
     T = B * lib().pn_panel_slots_per_cloud(B, N)
-    nt = 2 if prec == 3 else 1
     pmax = torch.empty(T, C_, device=dev, dtype=F32)
     pblk = torch.empty(T, C_, device=dev, dtype=torch.int32)
     sumsq = torch.empty(T, C_, device=dev, dtype=F32) if want_stats else None
-    a1 = torch.empty(T, nt * K, device=dev, dtype=F32) if want_stats else None
-    check(lib().pn_conv_fwd_max_panel(C.byref(x_op), ptr(wf[0]), ptr(wf[1]), B, N, K, C_, ptr(pmax), ptr(pblk), ptr(sumsq), ptr(a1), prec,
+    sumz = torch.empty(T, C_, device=dev, dtype=F32) if want_stats else None
+    check(lib().pn_conv_fwd_max_panel(C.byref(x_op), ptr(wf[0]), ptr(wf[1]), B, N, K, C_, ptr(pmax), ptr(pblk), ptr(sumsq), ptr(sumz), prec,
                                       current_stream()), "pn_conv_fwd_max_panel")
-    return pmax, pblk, sumsq, a1
+    return pmax, pblk, sumsq, sumz
 
 
-def panel_finalize(pmax, pblk, sumsq, a1, wf, B, N, K, prec, gamma, beta, moving_mean, moving_var, training=True,
-                   momentum=0.99, eps=1e-3):
+def panel_finalize(pmax, pblk, sumsq, sumz, B, N, gamma, beta, moving_mean, moving_var, training=True, momentum=0.99, eps=1e-3):
     """BN coefficients of the layer + reduce_max over each cloud's tiles -> (mean, invstd, scale, shift, g, zstar, arg_block)"""
     C_ = pmax.shape[1]
     dev = pmax.device
@@ -99,7 +97,7 @@ def panel_finalize(pmax, pblk, sumsq, a1, wf, B, N, K, prec, gamma, beta, moving
     g = torch.empty(B, C_, device=dev, dtype=F32)
     zstar = torch.empty(B, C_, device=dev, dtype=F32)
     argb = torch.empty(B, C_, device=dev, dtype=torch.int32)
-    check(lib().pn_panel_finalize(ptr(pmax), ptr(pblk), ptr(sumsq), ptr(a1), ptr(wf[0]), ptr(wf[1]), B, N, K, C_, prec,
+    check(lib().pn_panel_finalize(ptr(pmax), ptr(pblk), ptr(sumsq), ptr(sumz), B, N, C_,
                                   ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), momentum, eps, int(training), int(training),
                                   ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(g), ptr(zstar), ptr(argb), current_stream()),
           "pn_panel_finalize")

@@ -158,10 +158,10 @@ def test_conv_fwd_max_matches_reduce_max(dev, prec, B, N, panel):
         # the row-panel kernel (the one the model plan uses): max / 32-row block / sum of squares per tile, column sums of the panel,
         # one finaliser for the BN coefficients and the reduce_max, and the row resolved among the block's 32 candidates
         wf = ops.weights_prep(w.to(dev), gamma.to(dev))
-        pmax, pblk, sumsq, a1 = ops.conv_fwd_max_panel(op, wf, B, N, K, C, prec)
+        pmax, pblk, sumsq, sumz = ops.conv_fwd_max_panel(op, wf, B, N, K, C, prec)
         mmd, mvd = mm.to(dev), mv.to(dev)
-        mean, invstd, scale, shift, gfeat, zstar, argb = ops.panel_finalize(pmax, pblk, sumsq, a1, wf, B, N, K, prec, gamma.to(dev),
-                                                                           beta.to(dev), mmd, mvd, training=True)
+        mean, invstd, scale, shift, gfeat, zstar, argb = ops.panel_finalize(pmax, pblk, sumsq, sumz, B, N, gamma.to(dev), beta.to(dev), mmd, mvd,
+                                                                           training=True)
         arg = ops.max_resolve(op, wf, argb, B, N, K, C, prec)
         assert int(argb.min()) >= 0 and int(argb.max()) <= (N - 1) // 32
     else:
@@ -206,10 +206,10 @@ def test_panel_path_on_real_valued_clouds_with_duplicated_points(dev, prec):
     gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
     op = _lib().operand(x.to(dev), ca=sc.to(dev), cc=sh.to(dev), relu=True)
     wf = ops.weights_prep(w.to(dev), gamma.to(dev))
-    pmax, pblk, sumsq, a1 = ops.conv_fwd_max_panel(op, wf, B, N, K, C, prec)
+    pmax, pblk, sumsq, sumz = ops.conv_fwd_max_panel(op, wf, B, N, K, C, prec)
     mmd, mvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-    mean, invstd, scale, shift, gfeat, zstar, argb = ops.panel_finalize(pmax, pblk, sumsq, a1, wf, B, N, K, prec, gamma.to(dev), beta.to(dev),
-                                                                       mmd, mvd, training=True)
+    mean, invstd, scale, shift, gfeat, zstar, argb = ops.panel_finalize(pmax, pblk, sumsq, sumz, B, N, gamma.to(dev), beta.to(dev), mmd, mvd,
+                                                                       training=True)
     arg = ops.max_resolve(op, wf, argb, B, N, K, C, prec).cpu().long()
     a = lazy_ref(x, sc, sh, relu=True).float()
     aq, wq = (bf16r(a), bf16r(w)) if prec == 1 else (a, w)

@@ -30,7 +30,7 @@ for B, N in (((32, 1024), (32, 4096)) if ABLATE else ((32, 1024), (32, 4096), (8
                     outs = ops.conv_fwd_max_panel(op, wf, B, N, K, C_, prec, want_stats=stats)
                 T = outs[0].shape[0]
                 pmax, pblk = outs[0], outs[1]
-                sumsq, a1 = outs[2], outs[3]
+                sumsq, a1 = outs[2], outs[3]      # (sumz)
                 args = (_lib.C.byref(op), _lib.ptr(wf[0]), _lib.ptr(wf[1]), B, N, K, C_, _lib.ptr(pmax), _lib.ptr(pblk), _lib.ptr(sumsq), _lib.ptr(a1),
                         prec, _lib.current_stream())
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
