@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32, help="clouds per GPU")
     ap.add_argument("--points", type=int, default=1024)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x3"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16_f32act", "bf16x3"])
     ap.add_argument("--profile", default="classification_pretrain", choices=["classification_pretrain", "final", "all"])
     ap.add_argument("--no-graph", action="store_true", help="do not replay the step from a hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -161,7 +161,7 @@ def main():
     REPS = 20
     kt = []
     for src, ml in layers:
-        op = _lib.operand(wsf(src + ".Z").view(B * N, K_), ca=wsf(src + ".scale"), cc=wsf(src + ".shift"), relu=True)
+        op = _lib.operand(wsf(src + ".Z", model.activation_dtype).view(B * N, K_), ca=wsf(src + ".scale"), cc=wsf(src + ".shift"), relu=True)
         a = (C.byref(op), _lib.ptr(wsf(ml + ".wb_hi", torch.bfloat16)), _lib.ptr(wsf(ml + ".wb_lo", torch.bfloat16)), B, N, K_, C_,
              _lib.ptr(wsf(ml + ".pmax")), _lib.ptr(wsf(ml + ".pq", torch.int32)), _lib.ptr(wsf(ml + ".sumsq")), _lib.ptr(wsf(ml + ".sumz")),
              prec_id, _lib.current_stream())
@@ -176,8 +176,10 @@ def main():
         kt.append(e0.elapsed_time(e1) * 1e-3 / REPS)
     k_mean = sum(kt) / len(kt)
     flop_per_launch = 2.0 * 128 * 1024 * B * N
-    # algorithmic bytes: pre-BN input rows read once (fp32) + the bf16 kernel copy + per-(cloud, channel) max / block / sum of squares
-    bytes_per_launch = 128 * 4 * B * N + 128 * 1024 * 2 * (2 if args.precision == "bf16x3" else 1) + B * 1024 * 12
+    # algorithmic bytes: pre-BN input rows read once (in their storage type) + the bf16 kernel copy + per-(cloud, channel) max / block /
+    # sum of squares
+    act_bytes = 2 if model.activation_dtype == torch.bfloat16 else 4
+    bytes_per_launch = 128 * act_bytes * B * N + 128 * 1024 * 2 * (2 if args.precision == "bf16x3" else 1) + B * 1024 * 12
     # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/, corrected per MI355X_MICROARCH.md: FETCH_SIZE x 2):
     # reported only while the kernel source is the one the counters were collected on
     traffic = None
@@ -202,7 +204,7 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "bf16" if args.precision == "bf16" else "bf16x3",
+        "dtype": "bf16x3" if args.precision == "bf16x3" else "bf16",
         "data": "synthetic",
         "config": {"workload": f"PointNet-cls training step (fwd + losses + bwd + grad all-reduce + Adam), N={N} points, "
                                f"batch {B} per GPU, profile {args.profile}, {CCLS} classes / {CSEG} parts, random-init weights",

@@ -18,7 +18,8 @@
  *     the host, and only enqueues work on the `stream` it is given (hipStream_t passed as void*), so
  *     every call is safe to capture into a hipGraph;
  *   - tensors are row-major and contiguous; point tensors are (B clouds) x (N points) x channels,
- *     flattened to M = B*N rows; all floating point storage is fp32;
+ *     flattened to M = B*N rows; floating point storage is fp32, except the per-point layer-boundary
+ *     tensors where the caller asks for bf16 (PN_STORE_BF16, pn_operand.h16);
  *   - `prec` selects the arithmetic of the per-point contractions with K >= 64, which run on the bf16
  *     MFMA pipe with fp32 accumulation:  PN_PREC_BF16  = operands rounded to bf16 (1 MFMA per product),
  *     PN_PREC_BF16X3 = operands split hi+lo into two bf16 each, 3 MFMAs per product (16 significant
@@ -35,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 3
+#define PN_ABI_VERSION 4
 
 typedef enum {
   PN_OK = 0,
@@ -47,6 +48,13 @@ typedef enum {
 
 #define PN_PREC_BF16 1
 #define PN_PREC_BF16X3 3
+/* OR-ed into `prec` of the entry points that WRITE (or read through plain pointers) per-point tensors -- z of pn_conv_fwd; out,
+ * addend and zmask of pn_conv_bwd_data; pn_model_desc.prec for every layer-boundary tensor of the model plan (Z, dy, X64, the
+ * max-pool backward's addend) -- those tensors are then stored as bf16 (round to nearest even of the fp32 value; 2 bytes per
+ * element, same row-major shape) instead of fp32.  The model plan accepts it with PN_PREC_BF16 only.  The layer-boundary tensors of a
+ * training step are its HBM traffic, and the contraction that consumes them rounds its operands to bf16 anyway under PN_PREC_BF16.
+ * Operands say the same about their sources with pn_operand.h16.  Statistics are always taken from the fp32 values before rounding. */
+#define PN_STORE_BF16 0x100
 
 typedef void* pn_stream; /* hipStream_t */
 
@@ -71,7 +79,7 @@ typedef struct pn_operand {
   const float* cc;
   int64_t ld; /* elements between consecutive rows of s1/s2 */
   float lo;   /* lower clamp: 0 for ReLU, -INFINITY for none */
-  int32_t pad_;
+  int32_t h16; /* 0: s1/s2 point to fp32 arrays; 1: to bf16 arrays (ld still in elements, rows 16-byte aligned: ld % 8 == 0) */
 } pn_operand;
 
 /* --- PointCloudNormalization.call  (pointnet/PointNet.py:691-706) --------------------------------
@@ -232,9 +240,10 @@ int pn_seg_out_fwd(const pn_operand* x, const float* w, const float* bias, int64
 int pn_bmm(const float* x, const float* R, int B, int N, int K, float* out, int prec, pn_stream stream);
 
 /* --- tf.debugging.check_numerics (PointNet.py:199,208,218,...,288; enabled by `debugging: true`, pointnet_train.py:112):
- * *count (device int32) += the number of NaN / Inf elements among x[0..n).  The Python model calls it once per check site of the
- * reference after a forward pass and raises with the reference's message for the first site whose count is non-zero. */
-int pn_count_nonfinite(const float* x, int64_t n, int32_t* count, pn_stream stream);
+ * *count (device int32) += the number of NaN / Inf elements among x[0..n); x is an fp32 array, or a bf16 array when is_bf16 != 0.
+ * The Python model calls it once per check site of the reference after a forward pass and raises with the reference's message for
+ * the first site whose count is non-zero. */
+int pn_count_nonfinite(const void* x, int64_t n, int is_bf16, int32_t* count, pn_stream stream);
 
 /* --- farthest point sampling (no counterpart in the reference; build-defined spec):
  * per cloud, start at `start_idx`, repeatedly take the point with the largest squared distance (fp32,

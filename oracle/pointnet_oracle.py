@@ -167,10 +167,11 @@ def normalize(pc: torch.Tensor):
 class _Ctx:
     """Per-call state: which blocks are trainable, new moving statistics, regularisation losses."""
 
-    def __init__(self, training, trainable, quant, dropout_masks, dropout_rate, tie_split, decisions=None):
+    def __init__(self, training, trainable, quant, dropout_masks, dropout_rate, tie_split, decisions=None, store_quant=None):
         self.training = training
         self.trainable = trainable
         self.quant = quant
+        self.store_quant = store_quant
         self.dropout_masks = dropout_masks or {}
         self.dropout_rate = dropout_rate
         self.new_stats: Dict[str, torch.Tensor] = {}
@@ -180,8 +181,22 @@ class _Ctx:
         self.decisions = decisions or {}
 
 
-def _bn(ctx: _Ctx, p, prefix: str, z: torch.Tensor):
-    """keras BatchNormalization over every axis but the last (PointNet.py:528,559,623,647)."""
+class _RoundGrad(torch.autograd.Function):
+    """identity whose gradient is rounded by `fn` on the way back (emulation of a 16-bit store of an activation gradient)"""
+
+    @staticmethod
+    def forward(ctx, x, fn):
+        ctx.fn = fn
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.fn(g), None
+
+
+def _bn(ctx: _Ctx, p, prefix: str, z: torch.Tensor, z_stored=None):
+    """keras BatchNormalization over every axis but the last (PointNet.py:528,559,623,647).  z_stored (storage emulation of the
+    implementation under test): the statistics come from z, the affine is applied to z_stored."""
     gamma, beta = p[f"{prefix}.bn.gamma"], p[f"{prefix}.bn.beta"]
     block_trainable = ctx.trainable.get(block_of(prefix), True)
     red = tuple(range(z.dim() - 1))
@@ -194,7 +209,7 @@ def _bn(ctx: _Ctx, p, prefix: str, z: torch.Tensor):
     else:                                                         # inference mode incl. frozen layers
         mean, var = p[f"{prefix}.bn.moving_mean"], p[f"{prefix}.bn.moving_var"]
     inv = torch.rsqrt(var + BN_EPS) * gamma                       # tf.nn.batch_normalization
-    return z * inv + (beta - mean * inv)
+    return (z if z_stored is None else z_stored) * inv + (beta - mean * inv)
 
 
 def _relu(ctx: _Ctx, prefix: str, y):
@@ -212,14 +227,19 @@ def _mm(ctx: _Ctx, a, w, quantize: bool):
     return a @ w
 
 
-def conv_layer(ctx, p, prefix, x, act="relu", mfma=True, kernel=None):
-    """ConvLayer.call PointNet.py:554-566: 1x1 conv == per-point matmul with kernel (Cin, Cout)."""
+def conv_layer(ctx, p, prefix, x, act="relu", mfma=True, kernel=None, stored=True):
+    """ConvLayer.call PointNet.py:554-566: 1x1 conv == per-point matmul with kernel (Cin, Cout).
+    stored / ctx.store_quant: emulation of an implementation that keeps this layer's pre-BN output and the gradient of its BN
+    output in a narrower type (tests only; the max-pooled layers are never stored)."""
     w = p[f"{prefix}.kernel"] if kernel is None else kernel
     z = _mm(ctx, x, w, mfma)
     ctx.taps[f"{prefix}.z"] = z
     if f"{prefix}.bn.gamma" in p:
-        z = _bn(ctx, p, prefix, z)
+        sq = ctx.store_quant if stored else None
+        z = _bn(ctx, p, prefix, z, None if sq is None else sq(z))
         ctx.taps[f"{prefix}.y"] = z
+        if sq is not None:
+            z = _RoundGrad.apply(z, sq)
     else:
         z = z + p[f"{prefix}.bias"]
     if act == "relu":
@@ -296,7 +316,7 @@ def tnet(ctx, p, name, x, regularize: bool):
     k = x.shape[-1]
     h = conv_layer(ctx, p, f"{name}.conv1", x, mfma=(k >= 64))    # K=3 first layer stays fp32 on the GPU
     h = conv_layer(ctx, p, f"{name}.conv2", h)
-    h = conv_layer(ctx, p, f"{name}.conv3", h)
+    h = conv_layer(ctx, p, f"{name}.conv3", h, stored=False)
     g = reduce_max_points(ctx, h, name)                           # :429
     ctx.taps[f"{name}.global"] = g
     h = dense_layer(ctx, p, f"{name}.dense1", g)                  # :432
@@ -314,15 +334,17 @@ def forward(p, pc, training: bool = False, trainable: Optional[Dict[str, bool]] 
             regularize_feature_transform: bool = False, dropout_rate: float = 0.3,
             dropout_masks: Optional[Dict[str, torch.Tensor]] = None,
             quant: Optional[Callable] = None, tie_split: bool = False, return_ctx: bool = False,
-            decisions: Optional[Dict[str, torch.Tensor]] = None):
+            decisions: Optional[Dict[str, torch.Tensor]] = None, store_quant: Optional[Callable] = None):
     """PointNet.call PointNet.py:197-292.  Returns [cls (B,Ccls), seg (B,N,Cseg), R (B,3,3)] and, in
     training mode, the updated moving statistics (ctx.new_stats) plus add_loss terms (ctx.reg_losses).
 
     `dropout_masks`: {"dropout_1": (B,512) 0/1, "dropout_2": (B,256) 0/1} keep-masks; if absent in
     training mode dropout is skipped (the reference's dropout is unseeded, so it has no reproducible
     stream to match).  `quant`: optional rounding applied to both operands of every per-point matmul
-    with K >= 64 (emulates the GPU's bf16 MFMA operand rounding for the bf16 configs)."""
-    ctx = _Ctx(training, trainable or {}, quant, dropout_masks, dropout_rate, tie_split, decisions)
+    with K >= 64 (emulates the GPU's bf16 MFMA operand rounding for the bf16 configs).  `store_quant`: optional rounding of the
+    per-point layer-boundary tensors an implementation stores between kernels (pre-BN outputs, X_64, and the gradients of the BN
+    outputs on the way back) -- emulates bf16 storage; statistics are taken before it."""
+    ctx = _Ctx(training, trainable or {}, quant, dropout_masks, dropout_rate, tie_split, decisions, store_quant)
     pcn, _ = normalize(pc)                                        # :202
     ctx.taps["pcn"] = pcn
     if not vanilla:
@@ -337,12 +359,14 @@ def forward(p, pc, training: bool = False, trainable: Optional[Dict[str, bool]] 
         R64 = tnet(ctx, p, "feature_transform", x, regularize_feature_transform)  # :227
         ctx.taps["R64"] = R64
         x64 = _mm(ctx, x, R64, True)                              # :228
+        if store_quant is not None:
+            x64 = _RoundGrad.apply(store_quant(x64), store_quant)
     else:
         x64 = x
     ctx.taps["x64"] = x64
     h = conv_layer(ctx, p, "mlp_2_1", x64)                        # :236
     h = conv_layer(ctx, p, "mlp_2_2", h)                          # :239
-    h = conv_layer(ctx, p, "mlp_2_3", h)                          # :242
+    h = conv_layer(ctx, p, "mlp_2_3", h, stored=False)            # :242
     g = reduce_max_points(ctx, h, "mlp_2_3")                      # :248
     ctx.taps["global"] = g
 
@@ -358,8 +382,10 @@ def forward(p, pc, training: bool = False, trainable: Optional[Dict[str, bool]] 
     w1 = p["mlp_seg_1.kernel"]
     z1 = _mm(ctx, x64, w1[:64], True) + (g @ w1[64:]).unsqueeze(1)
     ctx.taps["mlp_seg_1.z"] = z1
-    z1 = _bn(ctx, p, "mlp_seg_1", z1)
+    z1 = _bn(ctx, p, "mlp_seg_1", z1, None if store_quant is None else store_quant(z1))
     ctx.taps["mlp_seg_1.y"] = z1
+    if store_quant is not None:
+        z1 = _RoundGrad.apply(z1, store_quant)
     s = _relu(ctx, "mlp_seg_1", z1)                               # :275
     s = conv_layer(ctx, p, "mlp_seg_2", s)                        # :278
     s = conv_layer(ctx, p, "mlp_seg_3", s)                        # :281

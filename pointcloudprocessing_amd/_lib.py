@@ -15,9 +15,12 @@ CSRC = os.path.join(_HERE, "csrc")
 
 PN_PREC_BF16 = 1
 PN_PREC_BF16X3 = 3
-ABI_VERSION = 3            # PN_ABI_VERSION of include/pointnet_hip.h this binding was written against
+PN_STORE_BF16 = 0x100      # or-ed into prec: the per-point layer-boundary tensors are stored as bf16
+ABI_VERSION = 4            # PN_ABI_VERSION of include/pointnet_hip.h this binding was written against
 PN_NUM_BLOCKS = 15
-PREC = {"bf16": PN_PREC_BF16, "bf16x3": PN_PREC_BF16X3}
+# "bf16": bf16 MFMA operands AND bf16 storage of the layer-boundary tensors (half the HBM traffic of a step);
+# "bf16_f32act": bf16 operands, fp32 storage; "bf16x3": split operands (fp32-grade products), fp32 storage
+PREC = {"bf16": PN_PREC_BF16 | PN_STORE_BF16, "bf16_f32act": PN_PREC_BF16, "bf16x3": PN_PREC_BF16X3}
 
 BLOCK_NAMES = ["input_transform", "mlp_1_1", "mlp_1_2", "feature_transform", "mlp_2_1", "mlp_2_2", "mlp_2_3",
                "mlp_cls_1", "mlp_cls_2", "mlp_cls_3", "mlp_seg_1", "mlp_seg_2", "mlp_seg_3", "mlp_seg_4",
@@ -30,7 +33,7 @@ class PointNetHipError(RuntimeError):
 
 class pn_operand(C.Structure):
     _fields_ = [("s1", C.c_void_p), ("s2", C.c_void_p), ("ca", C.c_void_p), ("cb", C.c_void_p),
-                ("cc", C.c_void_p), ("ld", C.c_int64), ("lo", C.c_float), ("pad_", C.c_int32)]
+                ("cc", C.c_void_p), ("ld", C.c_int64), ("lo", C.c_float), ("h16", C.c_int32)]
 
 
 class pn_model_desc(C.Structure):
@@ -94,7 +97,7 @@ SIGNATURES = {
     "pn_seg_out_fwd": (_I, [_OP, _P, _P, _I64, _I, _I, _P, _F, _P, _P, _P, _P]),
     "pn_bmm": (_I, [_P, _P, _I, _I, _I, _P, _I, _P]),
     "pn_dropout_masks": (_I, [_P, _I64, _P, _I64, _F, C.c_uint64, _P, _P]),
-    "pn_count_nonfinite": (_I, [_P, _I64, _P, _P]),
+    "pn_count_nonfinite": (_I, [_P, _I64, _I, _P, _P]),
     "pn_fps_workspace_bytes": (C.c_size_t, [_I, _I]),
     "pn_fps": (_I, [_P, _I, _I, _I, _I, _P, _P, _P, C.c_size_t, _P]),
     "pn_voxel_workspace_bytes": (C.c_size_t, [_I]),
@@ -190,5 +193,9 @@ def operand(s1, ca=None, cc=None, s2=None, cb=None, relu=False, ld=None):
     o.cc = cc.data_ptr() if cc is not None else None
     o.ld = ld if ld is not None else s1.shape[-1]
     o.lo = 0.0 if relu else float("-inf")
+    import torch
+    o.h16 = 1 if s1.dtype == torch.bfloat16 else 0       # bf16 sources (s2 must match s1)
+    if s2 is not None and s2.dtype != s1.dtype:
+        raise PointNetHipError("operand: s1 and s2 must have the same dtype")
     o._keepalive = (s1, s2, ca, cb, cc)   # the struct holds raw device pointers: keep their owners alive
     return o

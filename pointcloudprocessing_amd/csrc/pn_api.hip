@@ -124,7 +124,9 @@ int pn_bmm(const float* x, const float* R, int B, int N, int K, float* out, int 
 int pn_dropout_masks(uint8_t* keep1, int64_t n1, uint8_t* keep2, int64_t n2, float rate, uint64_t seed, uint32_t* step, pn_stream stream) {
   return dropout_masks(keep1, n1, keep2, n2, rate, seed, step, S(stream));
 }
-int pn_count_nonfinite(const float* x, int64_t n, int32_t* count, pn_stream stream) { return count_nonfinite(x, (long long)n, count, S(stream)); }
+int pn_count_nonfinite(const void* x, int64_t n, int is_bf16, int32_t* count, pn_stream stream) {
+  return count_nonfinite(reinterpret_cast<const float*>(x), (long long)n, count, S(stream), is_bf16 ? 1 : 0);
+}
 size_t pn_fps_workspace_bytes(int B, int N) { return fps_workspace_bytes(B, N); }
 int pn_fps(const float* xyz, int B, int N, int M, int start_idx, int32_t* idx_out, float* mindist, void* ws, size_t ws_bytes,
            pn_stream stream) {

@@ -49,6 +49,46 @@ __device__ __forceinline__ float wave_sum(float v) {
 // fmaxf return the OTHER operand for a NaN, which would turn a diverged (NaN) activation into a silent zero and leave the loss finite.
 __device__ __forceinline__ float clamp_lo(float v, float lo) { return v < lo ? lo : v; }
 __device__ __forceinline__ float clip_nan(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// ---- 16-bit storage of the per-point tensors (pn_operand.h16 / PN_STORE_BF16): the pointer is typed float* in every signature and
+// reinterpreted here; indices are ELEMENT indices either way ----
+__device__ __forceinline__ float bf16_bits_f32(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ unsigned short f32_bf16_bits(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }   // RNE
+__device__ __forceinline__ float act_load(const float* p, long long i, int h16) {
+  return h16 ? bf16_bits_f32(reinterpret_cast<const unsigned short*>(p)[i]) : p[i];
+}
+__device__ __forceinline__ void act_store(float* p, long long i, int h16, float v) {
+  if (h16) reinterpret_cast<unsigned short*>(p)[i] = f32_bf16_bits(v);
+  else p[i] = v;
+}
+// compile-time forms: a run of loads behind a RUN-TIME storage flag compiles to a branch per load (the loads no longer fly together),
+// so kernels switch once, outside their loops:  act_switch(flag, [&](auto h) { ... act_ld<h.value>(p, i) ... });
+template <bool H16>
+__device__ __forceinline__ float act_ld(const float* p, long long i) {
+  if constexpr (H16) return bf16_bits_f32(reinterpret_cast<const unsigned short*>(p)[i]);
+  else return p[i];
+}
+template <bool H16>
+__device__ __forceinline__ void act_st(float* p, long long i, float v) {
+  if constexpr (H16) reinterpret_cast<unsigned short*>(p)[i] = f32_bf16_bits(v);
+  else p[i] = v;
+}
+template <bool V>
+struct BoolTag { static constexpr bool value = V; };
+template <class F>
+__device__ __forceinline__ void act_switch(int h16, F&& f) {
+  if (h16) f(BoolTag<true>{});
+  else f(BoolTag<false>{});
+}
+// eight consecutive elements from a 16-byte aligned position of a bf16 array
+__device__ __forceinline__ uint4 act_load8_raw(const float* p, long long i) {
+  return *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned short*>(p) + i);
+}
+__device__ __forceinline__ void bf16x8_unpack(const uint4& t, float (&v)[8]) {
+  v[0] = __builtin_bit_cast(float, t.x << 16); v[1] = __builtin_bit_cast(float, t.x & 0xffff0000u);
+  v[2] = __builtin_bit_cast(float, t.y << 16); v[3] = __builtin_bit_cast(float, t.y & 0xffff0000u);
+  v[4] = __builtin_bit_cast(float, t.z << 16); v[5] = __builtin_bit_cast(float, t.z & 0xffff0000u);
+  v[6] = __builtin_bit_cast(float, t.w << 16); v[7] = __builtin_bit_cast(float, t.w & 0xffff0000u);
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

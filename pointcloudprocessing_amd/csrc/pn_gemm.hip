@@ -53,6 +53,7 @@ struct GemmArgs {
   const float* sgn;         // MAX
   float* pmax;              // MAX [tiles][C]
   int* pidx;                // MAX [tiles][C]
+  int store16;              // STORE: out, addend and zmask are bf16 arrays (PN_STORE_BF16)
   int colsum;               // WGRAD: also emit sum_rows a[row][i] as an extra row after each slab (slab stride Ci*C + Ci)
   int dbg;                  // PN_GEMM_DBG ablations (tools/gemm_probe.py): 1 no output stores, 2 no statistics, 4 no A loads, 8 no W loads
 };
@@ -81,13 +82,16 @@ __device__ __forceinline__ void cvt_store8(__bf16* hi, __bf16* lo, const float (
 // into a branch and waits vmcnt(0) per load, which serialises the tile (cdna_hip_programming.md section 5, trap 4c).
 
 // ---- "natural" stager: source[(row)*ld + k], k contiguous; coefficients indexed by k ------------------
-template <int TR, int BK, bool HAS2>
+// H16: the sources are bf16 arrays -- eight consecutive k are ONE 16-byte load (compile-time: a run-time storage flag inside the
+// unrolled loops costs registers and, worse, a branch per load)
+template <int TR, int BK, bool HAS2, bool H16>
 struct NatStage {
   static constexpr int CH = BK / 8;     // 16-byte bf16 chunks per LDS row
   static constexpr int RP = 256 / CH;   // rows per pass
   static constexpr int P = TR / RP;
-  float4 x[P][2];
-  float4 y[HAS2 ? P : 1][2];
+  static constexpr int Q = H16 ? 1 : 2; // register quads per 8 elements
+  float4 x[P][Q];
+  float4 y[HAS2 ? P : 1][Q];
 
   __device__ __forceinline__ void issue(const pn_operand& op, long long base, int nvalid_rows, int k0, int tid) {
     const int ch = tid % CH, rin = tid / CH;
@@ -96,13 +100,18 @@ struct NatStage {
     for (int p = 0; p < P; ++p) {
       const int r = p * RP + rin;
       const long long rr = (r < nvalid_rows) ? r : (nvalid_rows - 1);
-      const float* s = op.s1 + base + rr * op.ld + k;
-      x[p][0] = *reinterpret_cast<const float4*>(s);
-      x[p][1] = *reinterpret_cast<const float4*>(s + 4);
-      if (HAS2) {
-        const float* s2 = op.s2 + base + rr * op.ld + k;
-        y[p][0] = *reinterpret_cast<const float4*>(s2);
-        y[p][1] = *reinterpret_cast<const float4*>(s2 + 4);
+      if constexpr (H16) {
+        x[p][0] = __builtin_bit_cast(float4, act_load8_raw(op.s1, base + rr * op.ld + k));
+        if (HAS2) y[p][0] = __builtin_bit_cast(float4, act_load8_raw(op.s2, base + rr * op.ld + k));
+      } else {
+        const float* s = op.s1 + base + rr * op.ld + k;
+        x[p][0] = *reinterpret_cast<const float4*>(s);
+        x[p][1] = *reinterpret_cast<const float4*>(s + 4);
+        if (HAS2) {
+          const float* s2 = op.s2 + base + rr * op.ld + k;
+          y[p][0] = *reinterpret_cast<const float4*>(s2);
+          y[p][1] = *reinterpret_cast<const float4*>(s2 + 4);
+        }
       }
     }
   }
@@ -110,7 +119,7 @@ struct NatStage {
 #pragma unroll
     for (int p = 0; p < P; ++p)
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
+      for (int q = 0; q < Q; ++q) {
         asm volatile("" : "+v"(x[p][q].x), "+v"(x[p][q].y), "+v"(x[p][q].z), "+v"(x[p][q].w));
         if (HAS2) asm volatile("" : "+v"(y[p][q].x), "+v"(y[p][q].y), "+v"(y[p][q].z), "+v"(y[p][q].w));
       }
@@ -141,11 +150,17 @@ struct NatStage {
     for (int p = 0; p < P; ++p) {
       const int r = p * RP + rin;
       const bool rv = r < nvalid_rows;
-      float v[8] = {x[p][0].x, x[p][0].y, x[p][0].z, x[p][0].w, x[p][1].x, x[p][1].y, x[p][1].z, x[p][1].w};
-      float w[8];
-      if (HAS2) {
-        w[0] = y[p][0].x; w[1] = y[p][0].y; w[2] = y[p][0].z; w[3] = y[p][0].w;
-        w[4] = y[p][1].x; w[5] = y[p][1].y; w[6] = y[p][1].z; w[7] = y[p][1].w;
+      float v[8], w[8];
+      if constexpr (H16) {
+        bf16x8_unpack(__builtin_bit_cast(uint4, x[p][0]), v);
+        if (HAS2) bf16x8_unpack(__builtin_bit_cast(uint4, y[p][0]), w);
+      } else {
+        v[0] = x[p][0].x; v[1] = x[p][0].y; v[2] = x[p][0].z; v[3] = x[p][0].w;
+        v[4] = x[p][Q - 1].x; v[5] = x[p][Q - 1].y; v[6] = x[p][Q - 1].z; v[7] = x[p][Q - 1].w;
+        if (HAS2) {
+          w[0] = y[p][0].x; w[1] = y[p][0].y; w[2] = y[p][0].z; w[3] = y[p][0].w;
+          w[4] = y[p][Q - 1].x; w[5] = y[p][Q - 1].y; w[6] = y[p][Q - 1].z; w[7] = y[p][Q - 1].w;
+        }
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -159,30 +174,51 @@ struct NatStage {
 };
 
 // ---- "transposed" stager: source[(k)*ld + r], r (= the LDS row / channel) contiguous in memory;
-//      coefficients indexed by r.  Each lane owns one channel and gathers 8 consecutive k for it. -------
-template <int TR, int BK, bool HAS2>
+//      coefficients indexed by r.  Each lane owns one channel and gathers 8 consecutive k for it.
+//      H16 (bf16 sources): a lane takes a PAIR of channels -- one 4-byte load per k -- so a pass covers twice the k-groups and half
+//      the passes (and load instructions) are needed. -------
+template <int TR, int BK, bool HAS2, bool H16>
 struct TrnStage {
-  static constexpr int KG = BK / 8;      // k-groups per chunk
-  static constexpr int TPG = 256 / TR;   // k-groups covered per pass
-  static constexpr int P = KG / TPG;
-  static_assert(KG % TPG == 0, "tile geometry");
-  float x[P][8];
+  static constexpr int KG = BK / 8;                  // k-groups per chunk
+  static constexpr int TRL = H16 ? TR / 2 : TR;      // lanes across the channels
+  static constexpr int TPG = 256 / TRL;              // k-groups covered per pass
+  static constexpr int P = (KG + TPG - 1) / TPG;     // (KG < TPG: the upper lanes of the single pass idle)
+  static_assert(KG % TPG == 0 || TPG % KG == 0, "tile geometry");
+  float x[P][8];                                     // H16: raw pairs (even channel in the low half)
   float y[HAS2 ? P : 1][8];
 
   __device__ __forceinline__ void issue(const pn_operand& op, long long base, int nvalid_k, int nvalid_r, int tid) {
-    const int r = tid % TR, kgin = tid / TR;
-    const int rc = (r < nvalid_r) ? r : (nvalid_r - 1);
-    const float* p1 = op.s1 + base + rc;
-    const float* p2 = HAS2 ? (op.s2 + base + rc) : nullptr;
+    const int rl = tid % TRL, kgin = tid / TRL;
+    if constexpr (H16) {
+      const int rc = (2 * rl < nvalid_r) ? 2 * rl : ((nvalid_r - 1) & ~1);     // nvalid_r is even (channel counts are multiples of 64)
+      const unsigned* p1 = reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(op.s1) + base + rc);
+      const unsigned* p2 = HAS2 ? reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(op.s2) + base + rc) : nullptr;
+      const long long ld2 = op.ld / 2;
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int kg = p * TPG + kgin;
+      for (int p = 0; p < P; ++p) {
+        const int kg = p * TPG + kgin;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = kg * 8 + e;
-        const long long kk = (k < nvalid_k) ? k : (nvalid_k - 1);
-        x[p][e] = p1[kk * op.ld];
-        if (HAS2) y[p][e] = p2[kk * op.ld];
+        for (int e = 0; e < 8; ++e) {
+          const int k = kg * 8 + e;
+          const long long kk = (k < nvalid_k) ? k : (nvalid_k - 1);
+          x[p][e] = __builtin_bit_cast(float, p1[kk * ld2]);
+          if (HAS2) y[p][e] = __builtin_bit_cast(float, p2[kk * ld2]);
+        }
+      }
+    } else {
+      const int rc = (rl < nvalid_r) ? rl : (nvalid_r - 1);
+      const float* p1 = op.s1 + base + rc;
+      const float* p2 = HAS2 ? (op.s2 + base + rc) : nullptr;
+#pragma unroll
+      for (int p = 0; p < P; ++p) {
+        const int kg = p * TPG + kgin;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = kg * 8 + e;
+          const long long kk = (k < nvalid_k) ? k : (nvalid_k - 1);
+          x[p][e] = p1[kk * op.ld];
+          if (HAS2) y[p][e] = p2[kk * op.ld];
+        }
       }
     }
   }
@@ -195,35 +231,54 @@ struct TrnStage {
         if (HAS2) asm volatile("" : "+v"(y[p][e]));
       }
   }
-  // returns (when want_sum, block-uniform) the sum of the values this lane staged: its channel, the rows it gathered
+  // returns (when want_sum, block-uniform) the sum of the values this lane staged: .x its channel (H16: the even channel of its pair,
+  // .y the odd one), the rows it gathered
   template <int NS>
-  __device__ __forceinline__ float finish(__bf16* __restrict__ Thi, __bf16* __restrict__ Tlo, const pn_operand& op,
-                                          int nvalid_k, int nvalid_r, int coef0, int tid, bool want_sum = false) {
+  __device__ __forceinline__ float2 finish(__bf16* __restrict__ Thi, __bf16* __restrict__ Tlo, const pn_operand& op,
+                                           int nvalid_k, int nvalid_r, int coef0, int tid, bool want_sum = false) {
     constexpr int PITCH = Geo<BK>::PITCH;
-    float csum = 0.f;
-    const int r = tid % TR, kgin = tid / TR;
-    const bool rv = r < nvalid_r;
-    const int rc = rv ? r : (nvalid_r - 1);
-    float ca = 1.f, cb = 0.f, cc = 0.f;
-    if (op.ca) ca = op.ca[coef0 + rc];
-    if (HAS2 && op.cb) cb = op.cb[coef0 + rc];
-    if (op.cc) cc = op.cc[coef0 + rc];
+    constexpr int NH = H16 ? 2 : 1;
+    float csum[2] = {0.f, 0.f};
+    const int rl = tid % TRL, kgin = tid / TRL;
     const float lo = op.lo;
 #pragma unroll
-    for (int p = 0; p < P; ++p) {
-      const int kg = p * TPG + kgin;
-      float v[8];
+    for (int hf = 0; hf < NH; ++hf) {                        // H16: the even, then the odd channel of this lane's pair
+      const int r = H16 ? 2 * rl + hf : rl;
+      const bool rv = r < nvalid_r;
+      const int rc = rv ? r : (nvalid_r - 1);
+      float ca = 1.f, cb = 0.f, cc = 0.f;
+      if (op.ca) ca = op.ca[coef0 + rc];
+      if (HAS2 && op.cb) cb = op.cb[coef0 + rc];
+      if (op.cc) cc = op.cc[coef0 + rc];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = kg * 8 + e;
-        float t = fmaf(ca, x[p][e], cc);
-        if (HAS2) t = fmaf(cb, y[p][e], t);
-        v[e] = (rv && k < nvalid_k) ? clamp_lo(t, lo) : 0.f;
+      for (int p = 0; p < P; ++p) {
+        const int kg = p * TPG + kgin;
+        if (KG < TPG && kg >= KG) continue;                  // lanes beyond the chunk (single pass wider than the chunk)
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = kg * 8 + e;
+          float xs, ys = 0.f;
+          if constexpr (H16) {
+            const unsigned ux = __builtin_bit_cast(unsigned, x[p][e]);
+            xs = hf ? __builtin_bit_cast(float, ux & 0xffff0000u) : __builtin_bit_cast(float, ux << 16);
+            if (HAS2) {
+              const unsigned uy = __builtin_bit_cast(unsigned, y[p][e]);
+              ys = hf ? __builtin_bit_cast(float, uy & 0xffff0000u) : __builtin_bit_cast(float, uy << 16);
+            }
+          } else {
+            xs = x[p][e];
+            if (HAS2) ys = y[p][e];
+          }
+          float t = fmaf(ca, xs, cc);
+          if (HAS2) t = fmaf(cb, ys, t);
+          v[e] = (rv && k < nvalid_k) ? clamp_lo(t, lo) : 0.f;
+        }
+        if (want_sum) csum[hf] += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        cvt_store8(Thi + r * PITCH + kg * 8, Tlo + r * PITCH + kg * 8, v, NS == 3);
       }
-      if (want_sum) csum += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
-      cvt_store8(Thi + r * PITCH + kg * 8, Tlo + r * PITCH + kg * 8, v, NS == 3);
     }
-    return csum;
+    return make_float2(csum[0], csum[1]);
   }
 };
 
@@ -263,7 +318,7 @@ __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT][NT], const __bf16* A
 
 // ---- STORE epilogue for one (m-block, n-block) pair of accumulator registers; all uniform options are template
 //      parameters so that the unrolled body has no branches at all (a scalar branch per element serialises the wave)
-template <bool FULL, bool HAS_ADD, bool HAS_MASK, bool HAS_OUT>
+template <bool FULL, bool HAS_ADD, bool HAS_MASK, bool HAS_OUT, bool S16>
 __device__ __forceinline__ void epi_store_block(const f32x16& acc, const GemmArgs& g, long long row0, int il0, int nrows, int j, bool jv,
                                                 float bias, float msc, float msh, float& a1, float& a2) {
   float ad[16], zm[16];
@@ -273,8 +328,8 @@ __device__ __forceinline__ void epi_store_block(const f32x16& acc, const GemmArg
     for (int e = 0; e < 16; ++e) {          // unconditional, clamped loads first so they are all in flight together
       const int il = il0 + (e & 3) + 8 * (e >> 2);
       const long long oc = (row0 + (FULL || il < nrows ? il : nrows - 1)) * g.C + jc;
-      if (HAS_ADD) ad[e] = g.addend[oc];
-      if (HAS_MASK) zm[e] = g.zmask[oc];
+      if (HAS_ADD) ad[e] = act_ld<S16>(g.addend, oc);
+      if (HAS_MASK) zm[e] = act_ld<S16>(g.zmask, oc);
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
@@ -295,8 +350,7 @@ __device__ __forceinline__ void epi_store_block(const f32x16& acc, const GemmArg
     }
     if (!FULL) v = ok ? v : 0.f;
     if (HAS_OUT) {
-      if (FULL) g.out[(row0 + il) * g.C + j] = v;
-      else if (ok) g.out[(row0 + il) * g.C + j] = v;
+      if (FULL || ok) act_st<S16>(g.out, (row0 + il) * g.C + j, v);
     }
     a1 += v;
     a2 = fmaf(v, w2, a2);
@@ -304,8 +358,8 @@ __device__ __forceinline__ void epi_store_block(const f32x16& acc, const GemmArg
 }
 
 // ---- one weight-gradient tile: slab bx of output tile (by, bz) ----------------------------------------------
-template <int BM, int BN, int NS, bool A2, bool B2>
-__device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, const int by, const int bz, unsigned char* lds_raw) {
+template <int BM, int BN, int NS, bool A2, bool B2, bool AH, bool BH>
+__device__ __forceinline__ void wgrad_tile_t(const GemmArgs& g, const int bx, const int by, const int bz, unsigned char* lds_raw) {
   constexpr int BK = (NS == 3) ? 32 : 64;
   constexpr int PITCH = Geo<BK>::PITCH;
   constexpr int MT = BM / 64, NT = BN / 64;
@@ -328,13 +382,13 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
   const int cloud = bx / g.tiles_per_cloud, tin = bx - cloud * g.tiles_per_cloud;
   const int i0 = by * BM, j0 = bz * BN;
   const bool want_cs = g.colsum != 0 && bz == 0;     // block-uniform
-  float cs = 0.f;
+  float cs = 0.f, cs2 = 0.f;
   const int rbeg = tin * g.K;
   const int rend = min(g.N, rbeg + g.K);
   // the loads of chunk i+1 are issued before the MFMAs of chunk i and converted after them: one register set, global latency
   // hidden behind the matrix cores
-  TrnStage<BM, BK, A2> sa;
-  TrnStage<BN, BK, B2> sb;
+  TrnStage<BM, BK, A2, AH> sa;
+  TrnStage<BN, BK, B2, BH> sb;
   if (rbeg < rend) {
     const long long rowbase = (long long)cloud * g.N + rbeg;
     const int nk = min(BK, rend - rbeg);
@@ -344,7 +398,8 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
   for (int r0 = rbeg; r0 < rend; r0 += BK) {
     const int nk = min(BK, rend - r0);
     sa.pin();
-    cs += sa.template finish<NS>(Ahi, Alo, g.a, nk, g.Ci - i0, i0, tid, want_cs);
+    const float2 csp = sa.template finish<NS>(Ahi, Alo, g.a, nk, g.Ci - i0, i0, tid, want_cs);
+    cs += csp.x; cs2 += csp.y;
     sb.pin();
     sb.template finish<NS>(Bhi, Blo, g.b, nk, g.C - j0, j0, tid);
     __syncthreads();
@@ -364,12 +419,19 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
     // the 256 / BM threads that share a channel combine through LDS (the tiles are dead after the last barrier), fixed order
     constexpr int TPGA = 256 / BM;
     float* red = reinterpret_cast<float*>(lds_raw);
-    red[(tid / BM) * BM + (tid % BM)] = cs;
+    if constexpr (AH) {                  // a lane staged a channel pair: twice the partitions per channel
+      constexpr int BM2 = BM / 2;
+      red[(tid / BM2) * BM + 2 * (tid % BM2)] = cs;
+      red[(tid / BM2) * BM + 2 * (tid % BM2) + 1] = cs2;
+    } else {
+      red[(tid / BM) * BM + (tid % BM)] = cs;
+    }
     __syncthreads();
     if (tid < BM && i0 + tid < g.Ci) {
       float t = red[tid];
+      constexpr int PARTS = AH ? 2 * TPGA : TPGA;
 #pragma unroll
-      for (int q = 1; q < TPGA; ++q) t += red[q * BM + tid];
+      for (int q = 1; q < PARTS; ++q) t += red[q * BM + tid];
       slab[(long long)g.Ci * g.C + i0 + tid] = t;
     }
   }
@@ -385,6 +447,18 @@ __device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, cons
         if (i < g.Ci && j < g.C) slab[(long long)i * g.C + j] = acc[m][n][e];
       }
     }
+}
+
+// the storage type of either operand is block-uniform: switch once, outside the loops (pn_common.h: act_switch)
+template <int BM, int BN, int NS, bool A2, bool B2>
+__device__ __forceinline__ void wgrad_tile(const GemmArgs& g, const int bx, const int by, const int bz, unsigned char* lds_raw) {
+  if (g.a.h16) {
+    if (g.b.h16) wgrad_tile_t<BM, BN, NS, A2, B2, true, true>(g, bx, by, bz, lds_raw);
+    else wgrad_tile_t<BM, BN, NS, A2, B2, true, false>(g, bx, by, bz, lds_raw);
+  } else {
+    if (g.b.h16) wgrad_tile_t<BM, BN, NS, A2, B2, false, true>(g, bx, by, bz, lds_raw);
+    else wgrad_tile_t<BM, BN, NS, A2, B2, false, false>(g, bx, by, bz, lds_raw);
+  }
 }
 
 template <int BM, int BN, int NS>
@@ -418,18 +492,13 @@ __global__ __launch_bounds__(256) void wgrad_batch_kernel(const WgradBatch wb) {
 
 // ---- the kernel ----------------------------------------------------------------------------------------
 // 256 threads = 4 waves arranged 2 (rows) x 2 (cols); wave tile (BM/2) x (BN/2) = MT x NT MFMA tiles.
-template <int BM, int BN, int NS, int MODE, bool A2, bool B2, int EPI, bool ADD = false, bool MASK = false>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
+template <int BM, int BN, int NS, int MODE, bool A2, int EPI, bool ADD, bool MASK, bool AH, bool S16>
+__device__ __forceinline__ void rows_tile_t(const GemmArgs& g, unsigned char* lds_raw) {
   constexpr int BK = (NS == 3) ? 32 : 64;
   constexpr int PITCH = Geo<BK>::PITCH;
   constexpr int MT = BM / 64, NT = BN / 64;
   constexpr int WTM = BM / 2, WTN = BN / 2;
   constexpr int TILE_A = BM * PITCH, TILE_B = BN * PITCH;
-  constexpr int NTILES = (NS == 3) ? 2 : 1;
-  constexpr int LDS_TILES_BYTES = (TILE_A + TILE_B) * NTILES * 2;
-  constexpr int LDS_EPI_BYTES = 2 * BN * 4 * 4;  // [2 waves rows][BN] x (up to 4 floats)
-  constexpr int LDS_BYTES = LDS_TILES_BYTES > LDS_EPI_BYTES ? LDS_TILES_BYTES : LDS_EPI_BYTES;
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
   __bf16* Ahi = reinterpret_cast<__bf16*>(lds_raw);
   __bf16* Bhi = Ahi + TILE_A;
   __bf16* Alo = (NS == 3) ? (Bhi + TILE_B) : Ahi;
@@ -450,12 +519,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   const int bx = blockIdx.x;
   const int cloud = bx / g.tiles_per_cloud, tin = bx - cloud * g.tiles_per_cloud;
 
-  if (MODE == MODE_WGRAD) {
-    wgrad_tile<BM, BN, NS, A2, B2>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds_raw);
-    return;
-  }
-
-  // ---- FWD / BWD_DATA ----
   const int row_in_cloud0 = tin * BM;
   const int nrows = min(BM, g.N - row_in_cloud0);
   const long long row0 = (long long)cloud * g.N + row_in_cloud0;
@@ -463,13 +526,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   const long long wbase = (long long)cloud * g.w_cloud_stride;
   pn_operand wop;
   wop.s1 = g.w; wop.s2 = nullptr; wop.ca = nullptr; wop.cb = nullptr; wop.cc = nullptr;
-  wop.lo = -INFINITY;
+  wop.lo = -INFINITY; wop.h16 = 0;
   wop.ld = (MODE == MODE_FWD) ? g.C : g.K;
 
   // same one-chunk-ahead pipeline as the weight-gradient loop: chunk k+1's loads fly under chunk k's MFMAs
-  NatStage<BM, BK, A2> sa;
-  TrnStage<BN, BK, false> sbT;      // FWD: weights W[k][j], k slow
-  NatStage<BN, BK, false> sbN;      // BWD: weights W[j][k], k fast
+  NatStage<BM, BK, A2, AH> sa;
+  TrnStage<BN, BK, false, false> sbT;      // FWD: weights W[k][j], k slow
+  NatStage<BN, BK, false, false> sbN;      // BWD: weights W[j][k], k fast
   auto issue_chunk = [&](int k0) {
     if (!(g.dbg & 4)) sa.issue(g.a, row0 * g.a.ld, nrows, k0, tid);
     if (MODE == MODE_FWD) {
@@ -513,11 +576,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
       for (int m = 0; m < MT; ++m) {
         const int il0 = wrow0 + m * 32 + 4 * h;
         if (full) {
-          if (g.out && !(g.dbg & 1)) epi_store_block<true, ADD, MASK, true>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
-          else epi_store_block<true, ADD, MASK, false>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
+          if (g.out && !(g.dbg & 1)) epi_store_block<true, ADD, MASK, true, S16>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
+          else epi_store_block<true, ADD, MASK, false, S16>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
         } else {
-          if (g.out) epi_store_block<false, ADD, MASK, true>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
-          else epi_store_block<false, ADD, MASK, false>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
+          if (g.out) epi_store_block<false, ADD, MASK, true, S16>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
+          else epi_store_block<false, ADD, MASK, false, S16>(acc[m][n], g, row0, il0, nrows, j, jv, bias, msc, msh, a1, a2);
         }
       }
       s1[n] = a1 + __shfl_xor(a1, 32, 64);
@@ -597,6 +660,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs g) {
   }
 }
 
+// the forward form is two registers over the 256 that let two workgroups share a CU: held to that budget
+template <int BM, int BN, int NS, int MODE, bool A2, bool B2, int EPI, bool ADD = false, bool MASK = false>
+__global__ __launch_bounds__(256, (MODE == MODE_FWD && EPI == EPI_STORE) ? 2 : 1) void gemm_kernel(const GemmArgs g) {
+  constexpr int BK = (NS == 3) ? 32 : 64;
+  constexpr int LDS_TILES_BYTES = (BM + BN) * Geo<BK>::PITCH * ((NS == 3) ? 2 : 1) * 2;
+  constexpr int LDS_EPI_BYTES = 2 * BN * 4 * 4;  // [2 waves rows][BN] x (up to 4 floats)
+  constexpr int LDS_BYTES = LDS_TILES_BYTES > LDS_EPI_BYTES ? LDS_TILES_BYTES : LDS_EPI_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[LDS_BYTES];
+  if constexpr (MODE == MODE_WGRAD) {
+    wgrad_tile<BM, BN, NS, A2, B2>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds_raw);
+  } else {
+    // the storage types of the operand and of the epilogue's tensors are block-uniform: one switch, outside every loop
+    if (g.a.h16) {
+      if (EPI == EPI_STORE && g.store16) rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, true, EPI == EPI_STORE>(g, lds_raw);
+      else rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, true, false>(g, lds_raw);
+    } else {
+      if (EPI == EPI_STORE && g.store16) rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, false, EPI == EPI_STORE>(g, lds_raw);
+      else rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, false, false>(g, lds_raw);
+    }
+  }
+}
+
 // ---- host-side dispatch ----------------------------------------------------------------------------------
 template <int BM, int BN, int NS, int MODE, bool A2, bool B2, int EPI, bool ADD = false, bool MASK = false>
 static int launch(const GemmArgs& g, dim3 grid, hipStream_t st) {
@@ -613,6 +698,7 @@ static int check_operand(const pn_operand* o, const char* name) {
   PN_CHECK_ARG((!o->ca || aligned16(o->ca)) && (!o->cb || aligned16(o->cb)) && (!o->cc || aligned16(o->cc)),
                "%s: coefficient vectors must be 16-byte aligned", name);
   PN_CHECK_ARG(o->ld > 0 && o->ld % 4 == 0, "%s: ld must be a positive multiple of 4", name);
+  PN_CHECK_ARG(o->h16 == 0 || (o->h16 == 1 && o->ld % 8 == 0), "%s: h16 must be 0 or 1, and 16-bit rows need ld %% 8 == 0", name);
   return PN_OK;
 }
 
@@ -655,9 +741,12 @@ int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, i
   PN_CHECK_ARG(C >= 64 && C % 64 == 0, "pn_conv_fwd: C must be a multiple of 64 (C=%d)", C);
   PN_CHECK_ARG(x->ld >= K, "pn_conv_fwd: x.ld < K");
   PN_CHECK_ARG(w && aligned16(w), "pn_conv_fwd: w null or unaligned");
+  const int store16 = (prec & PN_STORE_BF16) ? 1 : 0;
+  prec &= ~PN_STORE_BF16;
   PN_CHECK_ARG(prec == PN_PREC_BF16 || prec == PN_PREC_BF16X3, "pn_conv_fwd: bad prec %d", prec);
   GemmArgs g;
   memset(&g, 0, sizeof(g));
+  g.store16 = store16;
   g.a = *x; g.w = w; g.w_cloud_stride = wcs; g.B = B; g.N = N; g.K = K; g.C = C;
   g.tiles_per_cloud = cdiv(N, 128);
   g.out = z; g.cloud_bias = cloud_bias; g.stat_partials = stat_partials;
@@ -694,9 +783,12 @@ int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, in
   PN_CHECK_ARG(dz->ld >= K, "pn_conv_bwd_data: dz.ld < K");
   PN_CHECK_ARG(w && aligned16(w), "pn_conv_bwd_data: w null or unaligned");
   PN_CHECK_ARG(!zmask || (msc && msh), "pn_conv_bwd_data: zmask needs msc and msh");
+  const int store16 = (prec & PN_STORE_BF16) ? 1 : 0;
+  prec &= ~PN_STORE_BF16;
   PN_CHECK_ARG(prec == PN_PREC_BF16 || prec == PN_PREC_BF16X3, "pn_conv_bwd_data: bad prec %d", prec);
   GemmArgs g;
   memset(&g, 0, sizeof(g));
+  g.store16 = store16;
   g.a = *dz; g.w = w; g.w_cloud_stride = wcs; g.B = B; g.N = N; g.K = K; g.C = C;
   g.tiles_per_cloud = cdiv(N, 128);
   g.out = out; g.addend = addend; g.zmask = zmask; g.msc = msc; g.msh = msh; g.stat_partials = stat_partials;
@@ -725,6 +817,7 @@ static int wgrad_args(const pn_operand* a, const pn_operand* b, int B, int N, in
   PN_CHECK_ARG(slab_rows >= 64 && slab_rows % 64 == 0, "pn_conv_wgrad: slab_rows must be a multiple of 64");
   PN_CHECK_ARG(a->ld >= Ci && b->ld >= Cj, "pn_conv_wgrad: ld too small");
   PN_CHECK_ARG(slabs != nullptr, "pn_conv_wgrad: null slabs");
+  prec &= ~PN_STORE_BF16;
   PN_CHECK_ARG(prec == PN_PREC_BF16 || prec == PN_PREC_BF16X3, "pn_conv_wgrad: bad prec %d", prec);
   memset(&g, 0, sizeof(g));
   g.a = *a; g.b = *b; g.B = B; g.N = N; g.K = slab_rows; g.C = Cj; g.Ci = Ci;
@@ -751,7 +844,7 @@ int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st) {
   std::vector<char> done(n > 0 ? n : 0, 0);
   auto key = [&](const WgradDesc& q) {
     const int shape = q.small_tiles ? 2 : (q.Ci % 128 == 0 && q.Cj % 128 == 0) ? 0 : (q.Cj % 128 == 0 ? 1 : 2);
-    return shape * 8 + (q.b.s2 ? 4 : 0) + (q.prec == PN_PREC_BF16X3 ? 1 : 0);
+    return shape * 8 + (q.b.s2 ? 4 : 0) + ((q.prec & ~PN_STORE_BF16) == PN_PREC_BF16X3 ? 1 : 0);
   };
   for (int i = 0; i < n; ++i) {
     if (done[i]) continue;
@@ -795,6 +888,7 @@ int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, i
   PN_CHECK_ARG(slab_rows >= 64 && slab_rows % 64 == 0, "pn_conv_wgrad: slab_rows must be a multiple of 64");
   PN_CHECK_ARG(a->ld >= Ci && b->ld >= Cj, "pn_conv_wgrad: ld too small");
   PN_CHECK_ARG(slabs != nullptr, "pn_conv_wgrad: null slabs");
+  prec &= ~PN_STORE_BF16;
   PN_CHECK_ARG(prec == PN_PREC_BF16 || prec == PN_PREC_BF16X3, "pn_conv_wgrad: bad prec %d", prec);
   GemmArgs g;
   memset(&g, 0, sizeof(g));

@@ -35,7 +35,7 @@ int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const f
 
 // pn_pointwise.hip
 int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st);
-int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st);
+int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st, int store16 = 0);
 int conv3_wgrad(const float* x3, const pn_operand* dz, int B, int N, int C, float* slabs, hipStream_t st);
 int slab_reduce(const float* slabs, int n_slabs, int per_group, long long elems, float* out, hipStream_t st);
 // several whole-range slab reductions (out_j = sum over the n_slabs_j slabs of job j, same summation order as slab_reduce) in one launch
@@ -89,7 +89,7 @@ int seg_out_fwd(const pn_operand* x, const float* w, const float* bias, long lon
 int seg_out_part_stride();
 int seg_out_part_rows();
 int seg_out_bwd(const pn_operand* x, const float* w, const float* dlogits, int B, int N, int K, int C, float* dyhat, float* stat_part,
-                float* wslab, hipStream_t st);
+                float* wslab, hipStream_t st, int store16 = 0);
 int sum_partials(const float* part, int n, int stride, int elems, float* out, hipStream_t st);
 
 // pn_maxbwd.hip
@@ -113,7 +113,7 @@ int maxbwd_dw(const pn_operand* x, const int* arg, const float* hs, int B, int N
               const float* e, const float* GW, float* dW, hipStream_t st);
 int maxbwd_q(const float* w, const float* f, int K, int C, float* q, hipStream_t st);
 int maxbwd_scatter(const int* arg, const float* hs, const float* wt, const float* q, int B, int N, int K, int C, float* D,
-                   hipStream_t st);
+                   int store16, hipStream_t st);
 int maxbwd_prep_resolve(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean,
                         const float* invstd, const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege,
                         float* f, float* dgamma, float* dbeta, const float* W, int K, float* Wt, float* We, const pn_operand* x,
@@ -140,7 +140,7 @@ int fold3_fwd(const float* R, const float* W, int B, int C, float* Weff, hipStre
 int fold3_bwd(const float* dWeff, const float* R, const float* W, int B, int C, float* dR, float* dW, hipStream_t st);
 int fill_eye3(float* out, int B, hipStream_t st);
 int axpy(const float* x, float a, float* y, long long n, hipStream_t st);
-int count_nonfinite(const float* x, long long n, int* count, hipStream_t st);
+int count_nonfinite(const float* x, long long n, int* count, hipStream_t st, int h16 = 0);
 int zero_fill(float* p, long long n, hipStream_t st);
 int zero_fill2(float* p, long long n, float* p2, int n2, hipStream_t st);   // + a second, small region
 int add2(const float* a, const float* b, float* out, long long n, hipStream_t st);

@@ -119,13 +119,16 @@ __global__ __launch_bounds__(256) void colsum_lazy_kernel(const pn_operand x, in
   const float ca = x.ca ? x.ca[c] : 1.f, cc = x.cc ? x.cc[c] : 0.f;
   const int r0 = tin * 128 + wave * 32, r1 = min(N, r0 + 32);
   float s = 0.f;
-  for (int rb = r0; rb < r1; rb += 8) {
-    float v[8];
+  act_switch(x.h16, [&](auto h) {
+    constexpr bool H = decltype(h)::value;
+    for (int rb = r0; rb < r1; rb += 8) {
+      float v[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = x.s1[((long long)cloud * N + min(rb + u, r1 - 1)) * x.ld + c];
+      for (int u = 0; u < 8; ++u) v[u] = act_ld<H>(x.s1, ((long long)cloud * N + min(rb + u, r1 - 1)) * x.ld + c);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += (rb + u < r1) ? clamp_lo(fmaf(ca, v[u], cc), x.lo) : 0.f;
-  }
+      for (int u = 0; u < 8; ++u) s += (rb + u < r1) ? clamp_lo(fmaf(ca, v[u], cc), x.lo) : 0.f;
+    }
+  });
   red[wave][lane] = s;
   __syncthreads();
   if (threadIdx.x < 64) part[(long long)bx * C + c] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
@@ -160,14 +163,17 @@ __global__ __launch_bounds__(128) void maxbwd_dw_kernel(const DwBatch jb, int B,
       const int k = threadIdx.x + 128 * kk;
       if (k < K) {
         const float ca = x.ca ? x.ca[k] : 1.f, cc = x.cc ? x.cc[k] : 0.f;
-        for (int bb = 0; bb < nb; bb += 8) {
-          float v[8];
+        act_switch(x.h16, [&](auto h) {
+          constexpr bool H = decltype(h)::value;
+          for (int bb = 0; bb < nb; bb += 8) {
+            float v[8];
 #pragma unroll
-          for (int u = 0; u < 8; ++u) v[u] = x.s1[srow[min(bb + u, nb - 1)] + k];
+            for (int u = 0; u < 8; ++u) v[u] = act_ld<H>(x.s1, srow[min(bb + u, nb - 1)] + k);
 #pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (bb + u < nb) acc[kk] = fmaf(clamp_lo(fmaf(ca, v[u], cc), x.lo), sw[bb + u], acc[kk]);
-        }
+            for (int u = 0; u < 8; ++u)
+              if (bb + u < nb) acc[kk] = fmaf(clamp_lo(fmaf(ca, v[u], cc), x.lo), sw[bb + u], acc[kk]);
+          }
+        });
       }
     }
   }
@@ -215,7 +221,9 @@ __device__ __forceinline__ void resolve_stage(const pn_operand& x, int cloud, in
     const int row = i / (K / 8), k = (i % (K / 8)) * 8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float ca[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, cc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (row < nr) {
+    if (row < nr && x.h16) {
+      bf16x8_unpack(act_load8_raw(x.s1, ((long long)cloud * N + rbase + row) * x.ld + k), v);
+    } else if (row < nr) {
       const float* s = x.s1 + ((long long)cloud * N + rbase + row) * x.ld + k;
       const float4 v0 = *reinterpret_cast<const float4*>(s), v1 = *reinterpret_cast<const float4*>(s + 4);
       v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
@@ -361,7 +369,7 @@ __global__ __launch_bounds__(256) void maxbwd_prep_kernel(const PrepArgs pa) { m
 // |hs*W| < 2^22 is assumed (the products are gradient-sized).  K <= 128, K % 4 == 0.
 __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restrict__ arg, const float* __restrict__ hs,
                                                              const float* __restrict__ wt, const float* __restrict__ q, int N,
-                                                             int K, int C, int quarters_per_cloud, float* __restrict__ D) {
+                                                             int K, int C, int quarters_per_cloud, float* __restrict__ D, int store16) {
   constexpr int CHUNK = 1024;                  // channels examined per round (4 per thread)
   constexpr double FX = 1099511627776.0;       // 2^40
   __shared__ unsigned long long tile[32][128]; // 32 KB
@@ -416,8 +424,10 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restri
     const int k = t & 127, r0 = (t >> 7) * 16;
     if (k < K) {
       const float qk = q[k];
-      for (int r = r0; r < min(r0 + 16, nr); ++r)
-        D[((long long)cloud * N + rbase + r) * K + k] = (float)((double)(long long)tile[r][k] * (1.0 / FX)) + qk;
+      act_switch(store16, [&](auto h) {
+        for (int r = r0; r < min(r0 + 16, nr); ++r)
+          act_st<decltype(h)::value>(D, ((long long)cloud * N + rbase + r) * K + k, (float)((double)(long long)tile[r][k] * (1.0 / FX)) + qk);
+      });
     }
   }
 }
@@ -451,7 +461,9 @@ int maxbwd_prep_resolve(const float* dg, const float* dg2, const float* g, const
   PN_CHECK_ARG(x && x->s1 && !x->s2 && wf_hi && argq && arg, "maxbwd_prep_resolve: null pointer");
   PN_CHECK_ARG(K <= RS_KMAX && K % 16 == 0 && C % 32 == 0, "maxbwd_prep_resolve: K must be a multiple of 16, at most 128, C a multiple of 32");
   PN_CHECK_ARG((reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && x->ld % 4 == 0, "maxbwd_prep_resolve: operand alignment");
+  prec &= ~PN_STORE_BF16;
   PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && wf_lo), "maxbwd_prep_resolve: bad prec / missing lo weights");
+  PN_CHECK_ARG(x->h16 == 0 || (x->h16 == 1 && x->ld % 8 == 0), "maxbwd_prep_resolve: 16-bit rows need ld %% 8 == 0");
   const PrepArgs a = make_prep(dg, dg2, g, zstar, B, C, mean, invstd, scale, batch_stats, count, hs, e, nege, f, dgamma, dbeta, W, K, Wt, We);
   const int n_prep = cdiv(C, 32), qpc = cdiv(N, 32);
   const __bf16* wh = reinterpret_cast<const __bf16*>(wf_hi);
@@ -503,11 +515,11 @@ int maxbwd_q(const float* w, const float* f, int K, int C, float* q, hipStream_t
 }
 
 int maxbwd_scatter(const int* arg, const float* hs, const float* wt, const float* q, int B, int N, int K, int C, float* D,
-                   hipStream_t st) {
+                   int store16, hipStream_t st) {
   PN_CHECK_ARG(arg && hs && wt && q && D, "maxbwd_scatter: null pointer");
   PN_CHECK_ARG(K <= 128, "maxbwd_scatter: K must be <= 128 (K=%d)", K);
   const int qpc = cdiv(N, 32);
-  hipLaunchKernelGGL(maxbwd_scatter_kernel, dim3(B * qpc), dim3(256), 0, st, arg, hs, wt, q, N, K, C, qpc, D);
+  hipLaunchKernelGGL(maxbwd_scatter_kernel, dim3(B * qpc), dim3(256), 0, st, arg, hs, wt, q, N, K, C, qpc, D, store16);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -517,7 +529,9 @@ int max_resolve(const pn_operand* x, const void* wf_hi, const void* wf_lo, int p
   PN_CHECK_ARG(x && x->s1 && !x->s2 && wf_hi && argq && arg, "pn_max_resolve: null pointer");
   PN_CHECK_ARG(K <= 128 && K % 16 == 0 && C % 32 == 0, "pn_max_resolve: K must be a multiple of 16, at most 128, C a multiple of 32 (K=%d C=%d)", K, C);
   PN_CHECK_ARG((reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && x->ld % 4 == 0, "pn_max_resolve: operand alignment");
+  prec &= ~PN_STORE_BF16;
   PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && wf_lo), "pn_max_resolve: bad prec / missing lo weights");
+  PN_CHECK_ARG(x->h16 == 0 || (x->h16 == 1 && x->ld % 8 == 0), "pn_max_resolve: 16-bit rows need ld %% 8 == 0");
   const int qpc = cdiv(N, 32);
   const __bf16* wh = reinterpret_cast<const __bf16*>(wf_hi);
   const __bf16* wl = reinterpret_cast<const __bf16*>(wf_lo);

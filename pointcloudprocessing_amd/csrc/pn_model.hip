@@ -181,10 +181,16 @@ static size_t wgrad_slab_floats(int B, int N, int Ci, int Cj) {
   return (size_t)B * spc * Ci * Cj;
 }
 
-static void plan_cl(Arena& A, CL& l, const char* nm, long long M, int T, int C, bool store_z, bool training) {
+// a per-point tensor (M x C): fp32, or bf16 when the plan stores the layer-boundary tensors in 16 bits (PN_STORE_BF16); typed float*
+// either way (every kernel that touches one takes the flag)
+static float* plan_act(Arena& A, const std::string& name, size_t elems, bool s16) {
+  if (s16) return reinterpret_cast<float*>(A.get<unsigned short>(name.c_str(), elems));
+  return A.get<float>(name.c_str(), elems);
+}
+static void plan_cl(Arena& A, CL& l, const char* nm, long long M, int T, int C, bool store_z, bool training, bool s16) {
   std::string n(nm);
   l.C = C;
-  l.Z = store_z ? A.get<float>((n + ".Z").c_str(), (size_t)M * C) : nullptr;
+  l.Z = store_z ? plan_act(A, n + ".Z", (size_t)M * C, s16) : nullptr;
   l.part = A.get<float>((n + ".part").c_str(), (size_t)T * 2 * C);
   l.mean = A.get<float>((n + ".mean").c_str(), C);
   l.invstd = A.get<float>((n + ".invstd").c_str(), C);
@@ -194,13 +200,13 @@ static void plan_cl(Arena& A, CL& l, const char* nm, long long M, int T, int C, 
     l.ca = A.get<float>((n + ".ca").c_str(), C);
     l.cb = A.get<float>((n + ".cb").c_str(), C);
     l.cc = A.get<float>((n + ".cc").c_str(), C);
-    l.dy = store_z ? A.get<float>((n + ".dy").c_str(), (size_t)M * C) : nullptr;
+    l.dy = store_z ? plan_act(A, n + ".dy", (size_t)M * C, s16) : nullptr;
   }
 }
 
 static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, int T, int K, int C, bool training, int prec) {
   std::string n(nm);
-  (void)prec;
+  const bool s16 = (prec & PN_STORE_BF16) != 0;
   m.rows = 64;
   m.tpc64 = panel_slots_per_cloud(B, N);   // slots (workgroups) per cloud of the panel kernel; never more than ceil(N / 64)
   m.T64 = B * m.tpc64;
@@ -225,7 +231,7 @@ static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, 
     m.GW = A.get<float>((n + ".GW").c_str(), (size_t)K * C);
     m.Pm = A.get<float>((n + ".Pm").c_str(), (size_t)K * K);
     m.q = A.get<float>((n + ".q").c_str(), K);
-    m.D = A.get<float>((n + ".D").c_str(), (size_t)M * K);
+    m.D = plan_act(A, n + ".D", (size_t)M * K, s16);
     m.Wt = A.get<float>((n + ".Wt").c_str(), (size_t)K * C);
     m.We = A.get<float>((n + ".We").c_str(), (size_t)K * C);
     m.dG = A.get<float>((n + ".dG").c_str(), (size_t)B * C);
@@ -245,9 +251,10 @@ static void plan_dl(Arena& A, DLs& d, const char* nm, int B, int K, int C, bool 
 }
 static void plan_tn(Arena& A, TN& t, const char* nm, int B, int N, long long M, int T, int K, bool training, int prec) {
   std::string n(nm);
-  plan_cl(A, t.c1, (n + ".c1").c_str(), M, T, 64, true, training);
-  plan_cl(A, t.c2, (n + ".c2").c_str(), M, T, 128, true, training);
-  plan_cl(A, t.c3, (n + ".c3").c_str(), M, 1, 1024, false, training);                 // statistics live in the panel buffers (plan_ml)
+  const bool s16 = (prec & PN_STORE_BF16) != 0;
+  plan_cl(A, t.c1, (n + ".c1").c_str(), M, T, 64, true, training, s16);
+  plan_cl(A, t.c2, (n + ".c2").c_str(), M, T, 128, true, training, s16);
+  plan_cl(A, t.c3, (n + ".c3").c_str(), M, 1, 1024, false, training, s16);            // statistics live in the panel buffers (plan_ml)
   plan_ml(A, t.m3, (n + ".m3").c_str(), B, N, M, T, 128, 1024, training, prec);
   plan_dl(A, t.d1, (n + ".d1").c_str(), B, 1024, 512, training);
   plan_dl(A, t.d2, (n + ".d2").c_str(), B, 512, 256, training);
@@ -261,6 +268,7 @@ static void plan_tn(Arena& A, TN& t, const char* nm, int B, int N, long long M, 
 static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool training) {
   const long long M = (long long)B * N;
   const int T = B * cdiv(N, 128);
+  const bool s16 = (d.prec & PN_STORE_BF16) != 0;
   w.pcn = A.get<float>("pcn", (size_t)M * 3);
   w.cent = A.get<float>("centroid", (size_t)B * 3);
   w.scl = A.get<float>("scale", B);
@@ -268,21 +276,21 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
     plan_tn(A, w.iT, "iT", B, N, M, T, 3, training, d.prec);
     plan_tn(A, w.fT, "fT", B, N, M, T, 64, training, d.prec);
   }
-  plan_cl(A, w.m11, "m11", M, T, 64, true, training);
-  plan_cl(A, w.m12, "m12", M, T, 64, true, training);
-  plan_cl(A, w.m21, "m21", M, T, 64, true, training);
-  plan_cl(A, w.m22, "m22", M, T, 128, true, training);
-  plan_cl(A, w.m23, "m23", M, 1, 1024, false, training);                              // statistics live in the panel buffers (plan_ml)
+  plan_cl(A, w.m11, "m11", M, T, 64, true, training, s16);
+  plan_cl(A, w.m12, "m12", M, T, 64, true, training, s16);
+  plan_cl(A, w.m21, "m21", M, T, 64, true, training, s16);
+  plan_cl(A, w.m22, "m22", M, T, 128, true, training, s16);
+  plan_cl(A, w.m23, "m23", M, 1, 1024, false, training, s16);                            // statistics live in the panel buffers (plan_ml)
   plan_ml(A, w.mm23, "mm23", B, N, M, T, 128, 1024, training, d.prec);
-  plan_cl(A, w.s1, "s1", M, T, 512, true, training);
-  plan_cl(A, w.s2, "s2", M, T, 256, true, training);
-  plan_cl(A, w.s3, "s3", M, T, 128, true, training);
-  plan_cl(A, w.s4, "s4", M, T, 128, true, training);
+  plan_cl(A, w.s1, "s1", M, T, 512, true, training, s16);
+  plan_cl(A, w.s2, "s2", M, T, 256, true, training, s16);
+  plan_cl(A, w.s3, "s3", M, T, 128, true, training, s16);
+  plan_cl(A, w.s4, "s4", M, T, 128, true, training, s16);
   plan_dl(A, w.c1, "c1", B, 1024, 512, training);
   plan_dl(A, w.c2, "c2", B, 512, 256, training);
   plan_dl(A, w.c3, "c3", B, 256, d.ccls, training);
   w.Weff1 = A.get<float>("Weff1", (size_t)B * 3 * 64);
-  w.X64 = d.vanilla ? nullptr : A.get<float>("X64", (size_t)M * 64);
+  w.X64 = d.vanilla ? nullptr : plan_act(A, "X64", (size_t)M * 64, s16);
   w.gb = A.get<float>("gb", (size_t)B * 512);
   w.cls_logits = A.get<float>("cls_logits", (size_t)B * d.ccls);
   w.seg_part = A.get<float>("seg_part", (size_t)cdivll(M, seg_out_part_rows()) * seg_out_part_stride());
@@ -294,8 +302,8 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
   w.slabs = w.slabs_main = w.slab_pool = nullptr;
   if (training) {
     w.dWeff1 = A.get<float>("dWeff1", (size_t)B * 3 * 64);
-    w.dX64 = A.get<float>("dX64", (size_t)M * 64);
-    w.tmpA12 = A.get<float>("tmpA12", (size_t)M * 64);
+    w.dX64 = plan_act(A, "dX64", (size_t)M * 64, s16);
+    w.tmpA12 = plan_act(A, "tmpA12", (size_t)M * 64, s16);
     w.dgb = A.get<float>("dgb", (size_t)B * 512);
     w.dGseg = A.get<float>("dGseg", (size_t)B * 1024);
     w.dGcls = A.get<float>("dGcls", (size_t)B * 1024);
@@ -345,7 +353,8 @@ struct Run {
   const pn_model_io& io;
   Layout L;
   WS w;
-  int B, N, T, tpc, prec;
+  int B, N, T, tpc, prec;      // prec: PN_PREC_* (| PN_STORE_BF16: what the per-point launchers are given)
+  int s16 = 0;                 // the per-point layer-boundary tensors (Z, dy, X64, dX64, D) are bf16
   long long M;
   hipStream_t st;
   bool training;
@@ -448,10 +457,15 @@ struct Run {
   float* p(long long off) const { return off >= 0 ? P + off : nullptr; }
   float* gr(long long off) const { return (G && off >= 0) ? G + off : nullptr; }
 
-  static pn_operand lazy(const CL& l) {
+  pn_operand lazy(const CL& l) const {
     pn_operand o;
     memset(&o, 0, sizeof(o));
-    o.s1 = l.Z; o.ca = l.scale; o.cc = l.shift; o.ld = l.C; o.lo = 0.f;
+    o.s1 = l.Z; o.ca = l.scale; o.cc = l.shift; o.ld = l.C; o.lo = 0.f; o.h16 = s16;
+    return o;
+  }
+  pn_operand plain_act(const float* x, long long ld) const {     // a per-point tensor as it is
+    pn_operand o = plain(x, ld);
+    o.h16 = s16;
     return o;
   }
   static pn_operand plain(const float* x, long long ld) {
@@ -460,10 +474,10 @@ struct Run {
     o.s1 = x; o.ld = ld; o.lo = -INFINITY;
     return o;
   }
-  static pn_operand dzop(const CL& l) {
+  pn_operand dzop(const CL& l) const {
     pn_operand o;
     memset(&o, 0, sizeof(o));
-    o.s1 = l.dy; o.s2 = l.Z; o.ca = l.ca; o.cb = l.cb; o.cc = l.cc; o.ld = l.C; o.lo = -INFINITY;
+    o.s1 = l.dy; o.s2 = l.Z; o.ca = l.ca; o.cb = l.cb; o.cc = l.cc; o.ld = l.C; o.lo = -INFINITY; o.h16 = s16;
     return o;
   }
 
@@ -501,7 +515,7 @@ struct Run {
   }
   int fwd_tnet(TN& t, const TRef& r, const pn_operand* x) {
     if (r.K == 3) {
-      PN_TRY(conv3_fwd(w.pcn, p(r.c1.kernel), 0, B, N, 64, t.c1.Z, bn_batch(r.c1.block) ? t.c1.part : nullptr, st));
+      PN_TRY(conv3_fwd(w.pcn, p(r.c1.kernel), 0, B, N, 64, t.c1.Z, bn_batch(r.c1.block) ? t.c1.part : nullptr, st, s16));
       PN_TRY(bn_fin(t.c1, r.c1));
     } else {
       PN_TRY(fwd_conv(t.c1, r.c1, *x, p(r.c1.kernel), 0, nullptr));
@@ -513,7 +527,7 @@ struct Run {
     return dense_plain(t.d2.a, 256, p(r.w), r.K * r.K, false, 256, r.K * r.K, p(r.b), t.R);
   }
 
-  pn_operand x64op() const { return d.vanilla ? lazy(w.m12) : plain(w.X64, 64); }
+  pn_operand x64op() const { return d.vanilla ? lazy(w.m12) : plain_act(w.X64, 64); }
 
   int forward() {
     {   // bf16 channel-major copies of the three 128->1024 kernels (they only change in the optimizer) + the dense layers' arrival counters
@@ -529,9 +543,9 @@ struct Run {
     if (!d.vanilla) {
       PN_TRY(fwd_tnet(w.iT, L.iT, nullptr));
       PN_TRY(fold3_fwd(w.iT.R, p(L.m11.kernel), B, 64, w.Weff1, st, io.out_R));   // also copies R to the third output
-      PN_TRY(conv3_fwd(w.pcn, w.Weff1, 192, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st));
+      PN_TRY(conv3_fwd(w.pcn, w.Weff1, 192, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st, s16));
     } else {
-      PN_TRY(conv3_fwd(w.pcn, p(L.m11.kernel), 0, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st));
+      PN_TRY(conv3_fwd(w.pcn, p(L.m11.kernel), 0, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st, s16));
     }
     PN_TRY(bn_fin(w.m11, L.m11));
     PN_TRY(fwd_conv(w.m12, L.m12, lazy(w.m11), p(L.m12.kernel), 0, nullptr));
@@ -712,7 +726,7 @@ struct Run {
       PN_TRY(conv_wgrad_batch(&pmd, 1, st));
       PN_TRY(slab_reduce_q(sl, spc, (long long)K * K, m.Pm, p(r.kernel), m.f, K, C, m.q, st));
     }
-    PN_TRY(maxbwd_scatter(m.arg, m.hs, m.Wt, m.q, B, N, K, C, m.D, st));
+    PN_TRY(maxbwd_scatter(m.arg, m.hs, m.Wt, m.q, B, N, K, C, m.D, s16, st));
     PN_TRY(conv_bwd_data(&xop, m.Pm, 0, B, N, K, K, m.D, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st));
     return PN_OK;
   }
@@ -806,7 +820,7 @@ struct Run {
     if (has_seg) {
       if (d_seg) PN_TRY(softmax_bwd_rows(io.out_seg, d_seg, M, d.cseg, w.seg_dlogits, st));
       const pn_operand a4 = lazy(w.s4);
-      PN_TRY(seg_out_bwd(&a4, p(L.s5.kernel), w.seg_dlogits, B, N, 128, d.cseg, w.s4.dy, w.bpart, w.s5slab, st));
+      PN_TRY(seg_out_bwd(&a4, p(L.s5.kernel), w.seg_dlogits, B, N, 128, d.cseg, w.s4.dy, w.bpart, w.s5slab, st, s16));
       if (tr(BLK_S5)) {
         PN_TRY(side([=] {
           if (!aux) jobs.push_back(SlabJob{w.s5slab, gr(L.s5.kernel), (long long)128 * d.cseg, T});     // s5slab is this job's own region
@@ -875,7 +889,7 @@ struct Run {
       const bool have_dx = has_seg || has_cls;
       if (!have_dx) PN_TRY(zero_fill(w.fT.dR, (long long)B * 4096, st));     // otherwise the slab reduction below is its first writer
       if (have_dx) {
-        const pn_operand dx = plain(w.dX64, 64);
+        const pn_operand dx = plain_act(w.dX64, 64);
         PN_TRY(wgrad_to(a12, dx, 64, 64, w.fT.dR, true));
         PN_TRY(conv_bwd_data(&dx, w.fT.R, 4096, B, N, 64, 64, nullptr, nullptr, nullptr, nullptr, w.tmpA12, nullptr, prec, st));
       }
@@ -913,7 +927,8 @@ static int check_desc(const pn_model_desc* d) {
   PN_CHECK_ARG(d->ccls >= 1 && d->ccls <= 4096, "pn_model: classification width %d out of range", d->ccls);
   PN_CHECK_ARG(d->cseg >= 1 && d->cseg <= 16, "pn_model: segmentation width %d not in [1,16]", d->cseg);
   PN_CHECK_ARG(d->dropout_rate >= 0.f && d->dropout_rate < 1.f, "pn_model: dropout rate must be in [0,1)");
-  PN_CHECK_ARG(d->prec == PN_PREC_BF16 || d->prec == PN_PREC_BF16X3, "pn_model: bad prec %d", d->prec);
+  PN_CHECK_ARG(d->prec == PN_PREC_BF16 || d->prec == PN_PREC_BF16X3 || d->prec == (PN_PREC_BF16 | PN_STORE_BF16),
+               "pn_model: bad prec %d (PN_PREC_BF16, PN_PREC_BF16X3 or PN_PREC_BF16 | PN_STORE_BF16)", d->prec);
   return PN_OK;
 }
 
@@ -926,7 +941,7 @@ static int make_run(const pn_model_desc* d, const pn_model_io* io, hipStream_t s
   r->L = make_layout(*d);
   r->B = io->B; r->N = io->N; r->M = (long long)io->B * io->N;
   r->tpc = cdiv(io->N, 128); r->T = io->B * r->tpc;
-  r->prec = d->prec; r->st = st; r->training = io->training != 0;
+  r->prec = d->prec; r->s16 = (d->prec & PN_STORE_BF16) ? 1 : 0; r->st = st; r->training = io->training != 0;
   r->P = io->params; r->G = io->grads;
   r->aux = reinterpret_cast<hipStream_t>(io->aux_stream);
   if (r->aux == st) r->aux = nullptr;

@@ -323,19 +323,19 @@ int zero_fill2(float* p, long long n, float* p2, int n2, hipStream_t st) {
 }
 
 // tf.debugging.check_numerics (PointNet.py:199-288, `debugging: true`): *count += number of NaN / Inf elements of x
-__global__ __launch_bounds__(256) void count_nonfinite_kernel(const float* __restrict__ x, long long n, int* __restrict__ count) {
+__global__ __launch_bounds__(256) void count_nonfinite_kernel(const float* __restrict__ x, long long n, int* __restrict__ count, int h16) {
   int bad = 0;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-    bad += (__builtin_isfinite(x[i]) ? 0 : 1);
+    bad += (__builtin_isfinite(act_load(x, i, h16)) ? 0 : 1);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) bad += __shfl_xor(bad, o, 64);
   if ((threadIdx.x & 63) == 0 && bad) atomicAdd(count, bad);
 }
-int count_nonfinite(const float* x, long long n, int* count, hipStream_t st) {
+int count_nonfinite(const float* x, long long n, int* count, hipStream_t st, int h16) {
   PN_CHECK_ARG(x && count && n >= 0, "pn_count_nonfinite: bad arguments");
   if (n == 0) return PN_OK;
   const long long blocks = cdivll(n, 256 * 8);
-  hipLaunchKernelGGL(count_nonfinite_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks < 2048 ? blocks : 2048))), dim3(256), 0, st, x, n, count);
+  hipLaunchKernelGGL(count_nonfinite_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks < 2048 ? blocks : 2048))), dim3(256), 0, st, x, n, count, h16);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -123,7 +123,7 @@ int panel_slots_per_cloud(int B, int N) {
 //     running sum of squares -- both kept in registers across the run's panels and written once per (slot, channel);
 //   * bf16x3 operands need hi + lo fragments (twice the registers): a workgroup then owns half the columns (CBW = 2 per wave) and the
 //     grid's second dimension walks the column halves.
-template <int NS, int K, bool STATS, int CBW, int DBG = 0>
+template <int NS, int K, bool STATS, int CBW, int DBG = 0, bool H16 = false>
 __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
   constexpr int BM = 64, THREADS = 512, KS = K / 16;
   constexpr int PA = K + 8;                          // LDS row pitch (bf16 elements): rows r .. r+15 on 16 distinct 16-byte slots
@@ -172,19 +172,23 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
   float a1h[8], a1l[NS == 3 ? 8 : 1];                // this thread's share of the column sums of the staged images (its 8 columns)
 #pragma unroll
   for (int e = 0; e < 8; ++e) { a1h[e] = 0.f; if (NS == 3) a1l[e] = 0.f; }
-  float4 x[P][2];
+  float4 x[P][H16 ? 1 : 2];                          // H16: the activations are stored as bf16 -- eight of them are one 16-byte load
   auto issue = [&](int panel) {
     const int rbase = panel * BM, nrows = min(BM, g.N - rbase);
 #pragma unroll
     for (int p = 0; p < P; ++p) {
       const int rr = p * RP + rin;
       const long long rsrc = cloud_row0 + rbase + (rr < nrows ? rr : nrows - 1);
-      const float* s = g.a.s1 + rsrc * g.a.ld + k;
-      if (!(DBG & 4)) {
-        x[p][0] = *reinterpret_cast<const float4*>(s);
-        x[p][1] = *reinterpret_cast<const float4*>(s + 4);
+      if constexpr (H16) {
+        x[p][0] = __builtin_bit_cast(float4, act_load8_raw(g.a.s1, rsrc * g.a.ld + k));
       } else {
-        x[p][0] = x[p][1] = make_float4(1.f, 2.f, 3.f, 4.f);
+        const float* s = g.a.s1 + rsrc * g.a.ld + k;
+        if (!(DBG & 4)) {
+          x[p][0] = *reinterpret_cast<const float4*>(s);
+          x[p][1] = *reinterpret_cast<const float4*>(s + 4);
+        } else {
+          x[p][0] = x[p][1] = make_float4(1.f, 2.f, 3.f, 4.f);
+        }
       }
     }
   };
@@ -208,7 +212,13 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
     for (int p = 0; p < P; ++p) {
       const int rr = p * RP + rin;
       const bool rv = rr < nrows;
-      const float v[8] = {x[p][0].x, x[p][0].y, x[p][0].z, x[p][0].w, x[p][1].x, x[p][1].y, x[p][1].z, x[p][1].w};
+      float v[8];
+      if constexpr (H16) {
+        bf16x8_unpack(__builtin_bit_cast(uint4, x[p][0]), v);
+      } else {
+        v[0] = x[p][0].x; v[1] = x[p][0].y; v[2] = x[p][0].z; v[3] = x[p][0].w;
+        v[4] = x[p][H16 ? 0 : 1].x; v[5] = x[p][H16 ? 0 : 1].y; v[6] = x[p][H16 ? 0 : 1].z; v[7] = x[p][H16 ? 0 : 1].w;
+      }
       bf16x8 hv, lv;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -392,6 +402,13 @@ static void launch_panel(const PanelArgs& g, dim3 grid, bool stats, hipStream_t 
 #undef PN_PANEL_DBG_CASE
     }
   }
+  if constexpr (NS == 1) {
+    if (g.a.h16) {
+      if (stats) hipLaunchKernelGGL((panel_max_kernel<NS, K, true, CBW, 0, true>), grid, dim3(512), 0, st, g);
+      else hipLaunchKernelGGL((panel_max_kernel<NS, K, false, CBW, 0, true>), grid, dim3(512), 0, st, g);
+      return;
+    }
+  }
   if (stats) hipLaunchKernelGGL((panel_max_kernel<NS, K, true, CBW>), grid, dim3(512), 0, st, g);
   else hipLaunchKernelGGL((panel_max_kernel<NS, K, false, CBW>), grid, dim3(512), 0, st, g);
 }
@@ -415,7 +432,10 @@ int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo
   PN_CHECK_ARG(C >= 256 && C % 256 == 0 && (C / 256 == 1 || C / 256 == 2 || C % 1024 == 0), "pn_conv_fwd_max_panel: C must be 256, 512 or a multiple of 1024 (C=%d)", C);
   PN_CHECK_ARG(wf_hi && pmax && pq, "pn_conv_fwd_max_panel: null pointer");
   PN_CHECK_ARG((sumsq == nullptr) == (sumz == nullptr), "pn_conv_fwd_max_panel: sumsq and sumz come together (both or neither)");
+  prec &= ~PN_STORE_BF16;
   PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && wf_lo), "pn_conv_fwd_max_panel: bad prec / missing lo weights");
+  PN_CHECK_ARG(x->h16 == 0 || (x->h16 == 1 && prec == PN_PREC_BF16 && x->ld % 8 == 0),
+               "pn_conv_fwd_max_panel: a 16-bit operand needs PN_PREC_BF16 and ld %% 8 == 0");
   PanelArgs g;
   memset(&g, 0, sizeof(g));
   g.a = *x; g.wf_hi = reinterpret_cast<const __bf16*>(wf_hi); g.wf_lo = reinterpret_cast<const __bf16*>(wf_lo);

@@ -72,7 +72,7 @@ int normalize(const float* xyz, int B, int N, float* out, float* centroid, float
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv3_fwd_kernel(const float* __restrict__ x3, const float* __restrict__ w,
                                                         long long wcs, int N, int C, int tiles_per_cloud,
-                                                        float* __restrict__ z, float* __restrict__ part) {
+                                                        float* __restrict__ z, float* __restrict__ part, int store16) {
   __shared__ float red[4][2][64];
   const int bx = blockIdx.x, cloud = bx / tiles_per_cloud, tin = bx - cloud * tiles_per_cloud;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,15 +84,18 @@ __global__ __launch_bounds__(256) void conv3_fwd_kernel(const float* __restrict_
   const int r0 = tin * 128 + __builtin_amdgcn_readfirstlane(wave) * 32;
   const int r1 = min(N, r0 + 32);
   float s1 = 0.f, s2 = 0.f;
+  act_switch(store16, [&](auto h) {
+    constexpr bool H = decltype(h)::value;
 #pragma unroll 4
-  for (int r = r0; r < r1; ++r) {
-    const long long row = (long long)cloud * N + r;
-    const float a0 = x3[row * 3], a1 = x3[row * 3 + 1], a2 = x3[row * 3 + 2];
-    const float v = fmaf(a2, w2, fmaf(a1, w1, a0 * w0));
-    if (z) z[row * C + c] = v;
-    s1 += v;
-    s2 = fmaf(v, v, s2);
-  }
+    for (int r = r0; r < r1; ++r) {
+      const long long row = (long long)cloud * N + r;
+      const float a0 = x3[row * 3], a1 = x3[row * 3 + 1], a2 = x3[row * 3 + 2];
+      const float v = fmaf(a2, w2, fmaf(a1, w1, a0 * w0));
+      if (z) act_st<H>(z, row * C + c, v);
+      s1 += v;
+      s2 = fmaf(v, v, s2);
+    }
+  });
   if (part) {
     red[wave][0][lane] = s1;
     red[wave][1][lane] = s2;
@@ -105,12 +108,12 @@ __global__ __launch_bounds__(256) void conv3_fwd_kernel(const float* __restrict_
   }
 }
 
-int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st) {
+int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st, int store16) {
   PN_CHECK_ARG(x3 && w, "pn_conv3_fwd: null pointer");
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv3_fwd: B and N must be positive");
   PN_CHECK_ARG(C >= 64 && C % 64 == 0, "pn_conv3_fwd: C must be a multiple of 64 (C=%d)", C);
   const int tpc = cdiv(N, 128);
-  hipLaunchKernelGGL(conv3_fwd_kernel, dim3(B * tpc, C / 64), dim3(256), 0, st, x3, w, wcs, N, C, tpc, z, part);
+  hipLaunchKernelGGL(conv3_fwd_kernel, dim3(B * tpc, C / 64), dim3(256), 0, st, x3, w, wcs, N, C, tpc, z, part, store16);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -127,26 +130,67 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float* __restric
   const int r1 = min(N, r0 + 32);
   float g0 = 0.f, g1 = 0.f, g2 = 0.f;
   const bool two = dz.s2 != nullptr;
-  for (int rb = r0; rb < r1; rb += 8) {
-    float y[8], zz[8], xa[8], xb[8], xc[8];
+  if (dz.h16) {
+    // bf16 sources: a lane takes a PAIR of channels (4-byte loads) and every other row of the wave's 32; the two row halves of a
+    // pair meet through a cross-half shuffle and land in LDS as in the fp32 form
+    const int pr = lane & 31, half = lane >> 5;
+    const int c2 = blockIdx.y * 64 + 2 * pr;
+    const float ca0 = dz.ca ? dz.ca[c2] : 1.f, ca1 = dz.ca ? dz.ca[c2 + 1] : 1.f;
+    const float cb0 = (two && dz.cb) ? dz.cb[c2] : 0.f, cb1 = (two && dz.cb) ? dz.cb[c2 + 1] : 0.f;
+    const float cc0 = dz.cc ? dz.cc[c2] : 0.f, cc1 = dz.cc ? dz.cc[c2 + 1] : 0.f;
+    const unsigned* s1 = reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(dz.s1) + c2);
+    const unsigned* s2 = two ? reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned short*>(dz.s2) + c2) : nullptr;
+    const long long ld2 = dz.ld / 2;
+    float h0[3] = {0.f, 0.f, 0.f}, h1[3] = {0.f, 0.f, 0.f};
+    for (int rb = r0; rb < r1; rb += 16) {
+      unsigned y[8], zz[8];
+      float xa[8], xb[8], xc[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {            // 8 rows in flight; rows past the end are clamped and masked below
-      const long long row = (long long)cloud * N + min(rb + u, r1 - 1);
-      y[u] = dz.s1[row * dz.ld + c];
-      zz[u] = two ? dz.s2[row * dz.ld + c] : 0.f;
-      xa[u] = x3[row * 3]; xb[u] = x3[row * 3 + 1]; xc[u] = x3[row * 3 + 2];
+      for (int u = 0; u < 8; ++u) {            // 8 rows per half-wave in flight; rows past the end are clamped and masked below
+        const long long row = (long long)cloud * N + min(rb + 2 * u + half, r1 - 1);
+        y[u] = s1[row * ld2];
+        zz[u] = two ? s2[row * ld2] : 0u;
+        xa[u] = x3[row * 3]; xb[u] = x3[row * 3 + 1]; xc[u] = x3[row * 3 + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const bool ok = rb + 2 * u + half < r1;
+        float d0 = fmaf(cb0, bf16_bits_f32(zz[u] & 0xffffu), fmaf(ca0, bf16_bits_f32(y[u] & 0xffffu), cc0));
+        float d1 = fmaf(cb1, __builtin_bit_cast(float, zz[u] & 0xffff0000u), fmaf(ca1, __builtin_bit_cast(float, y[u] & 0xffff0000u), cc1));
+        d0 = ok ? clamp_lo(d0, dz.lo) : 0.f;
+        d1 = ok ? clamp_lo(d1, dz.lo) : 0.f;
+        h0[0] = fmaf(xa[u], d0, h0[0]); h0[1] = fmaf(xb[u], d0, h0[1]); h0[2] = fmaf(xc[u], d0, h0[2]);
+        h1[0] = fmaf(xa[u], d1, h1[0]); h1[1] = fmaf(xb[u], d1, h1[1]); h1[2] = fmaf(xc[u], d1, h1[2]);
+      }
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      float d = fmaf(ca, y[u], cc);
-      d = fmaf(cb, zz[u], d);
-      d = (rb + u < r1) ? clamp_lo(d, dz.lo) : 0.f;
-      g0 = fmaf(xa[u], d, g0);
-      g1 = fmaf(xb[u], d, g1);
-      g2 = fmaf(xc[u], d, g2);
+    for (int kk = 0; kk < 3; ++kk) {
+      h0[kk] += __shfl_xor(h0[kk], 32, 64);
+      h1[kk] += __shfl_xor(h1[kk], 32, 64);
+      if (half == 0) { red[wave][kk][2 * pr] = h0[kk]; red[wave][kk][2 * pr + 1] = h1[kk]; }
     }
+  } else {
+    for (int rb = r0; rb < r1; rb += 8) {
+      float y[8], zz[8], xa[8], xb[8], xc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {            // 8 rows in flight; rows past the end are clamped and masked below
+        const long long row = (long long)cloud * N + min(rb + u, r1 - 1);
+        y[u] = dz.s1[row * dz.ld + c];
+        zz[u] = two ? dz.s2[row * dz.ld + c] : 0.f;
+        xa[u] = x3[row * 3]; xb[u] = x3[row * 3 + 1]; xc[u] = x3[row * 3 + 2];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float d = fmaf(ca, y[u], cc);
+        d = fmaf(cb, zz[u], d);
+        d = (rb + u < r1) ? clamp_lo(d, dz.lo) : 0.f;
+        g0 = fmaf(xa[u], d, g0);
+        g1 = fmaf(xb[u], d, g1);
+        g2 = fmaf(xc[u], d, g2);
+      }
+    }
+    red[wave][0][lane] = g0; red[wave][1][lane] = g1; red[wave][2][lane] = g2;
   }
-  red[wave][0][lane] = g0; red[wave][1][lane] = g1; red[wave][2][lane] = g2;
   __syncthreads();
   if (tid < 192) {
     const int kk = tid >> 6, l = tid & 63;

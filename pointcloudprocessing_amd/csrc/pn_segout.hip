@@ -70,15 +70,26 @@ __global__ __launch_bounds__(SEG_RPB) void seg_out_fwd_kernel(const pn_operand x
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[e] = 0.f;
       float4 xv[8][2];
+      if (x.h16) {                          // wave-uniform: eight bf16 = one 16-byte load, raw bits in the first quad
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        xv[ks][0] = *reinterpret_cast<const float4*>(src + ks * 16);
-        xv[ks][1] = *reinterpret_cast<const float4*>(src + ks * 16 + 4);
+        for (int ks = 0; ks < 8; ++ks) xv[ks][0] = __builtin_bit_cast(float4, act_load8_raw(x.s1, rr * x.ld + 8 * lg + ks * 16));
+      } else {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          xv[ks][0] = *reinterpret_cast<const float4*>(src + ks * 16);
+          xv[ks][1] = *reinterpret_cast<const float4*>(src + ks * 16 + 4);
+        }
       }
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const int k0 = ks * 16 + 8 * lg;
-        const float v[8] = {xv[ks][0].x, xv[ks][0].y, xv[ks][0].z, xv[ks][0].w, xv[ks][1].x, xv[ks][1].y, xv[ks][1].z, xv[ks][1].w};
+        float v[8];
+        if (x.h16) {
+          bf16x8_unpack(__builtin_bit_cast(uint4, xv[ks][0]), v);
+        } else {
+          v[0] = xv[ks][0].x; v[1] = xv[ks][0].y; v[2] = xv[ks][0].z; v[3] = xv[ks][0].w;
+          v[4] = xv[ks][1].x; v[5] = xv[ks][1].y; v[6] = xv[ks][1].z; v[7] = xv[ks][1].w;
+        }
         seg_bf16x8 ah, al;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -110,7 +121,13 @@ __global__ __launch_bounds__(SEG_RPB) void seg_out_fwd_kernel(const pn_operand x
       const float* src = x.s1 + row * x.ld;
 #pragma unroll 4
       for (int k = 0; k < K; k += 4) {
-        const float4 v = *reinterpret_cast<const float4*>(src + k);
+        float4 v;
+        if (x.h16) {
+          const uint2 t = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(x.s1) + row * x.ld + k);
+          v = make_float4(bf16_bits_f32(t.x & 0xffffu), bf16_bits_f32(t.x >> 16), bf16_bits_f32(t.y & 0xffffu), bf16_bits_f32(t.y >> 16));
+        } else {
+          v = *reinterpret_cast<const float4*>(src + k);
+        }
         const float a0 = clamp_lo(fmaf(ca[k], v.x, cc[k]), x.lo), a1 = clamp_lo(fmaf(ca[k + 1], v.y, cc[k + 1]), x.lo);
         const float a2 = clamp_lo(fmaf(ca[k + 2], v.z, cc[k + 2]), x.lo), a3 = clamp_lo(fmaf(ca[k + 3], v.w, cc[k + 3]), x.lo);
 #pragma unroll
@@ -203,7 +220,7 @@ __global__ __launch_bounds__(SEG_RPB) void seg_out_fwd_kernel(const pn_operand x
 __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, const float* __restrict__ w,
                                                           const float* __restrict__ dlogits, int N, int C, int tiles_per_cloud,
                                                           float* __restrict__ dyhat, float* __restrict__ stat_part,
-                                                          float* __restrict__ wslab) {
+                                                          float* __restrict__ wslab, int store16) {
   constexpr int K = 128;
   __shared__ float red[128][2 + SEG_CM];
   __shared__ float out_s[128 * SEG_CM];
@@ -218,9 +235,11 @@ __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, co
   const float ca = x.ca ? x.ca[k] : 1.f, cc = x.cc ? x.cc[k] : 0.f, lo = x.lo;
   const int r0 = tin * 128 + stream * 64, r1 = min(N, r0 + 64);
   float S1 = 0.f, S2 = 0.f;
+  act_switch(x.h16, [&](auto hx) { act_switch(store16, [&](auto hs) {
+  constexpr bool HX = decltype(hx)::value, HS = decltype(hs)::value;
   for (int r = r0; r < r1; ++r) {
     const long long row = (long long)cloud * N + r;
-    const float z = x.s1[row * x.ld + k];
+    const float z = act_ld<HX>(x.s1, row * x.ld + k);
     const float pre = fmaf(ca, z, cc);
     const float a = clamp_lo(pre, lo);
     // the row is the same for every lane of a wave (stream = threadIdx.x >> 7), but only readfirstlane lets the compiler see it:
@@ -235,10 +254,11 @@ __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, co
         gw[c] = fmaf(a, g, gw[c]);
       }
     if (!(pre > lo)) d = 0.f;   // relu'(pre) with lo = 0; lo = -inf keeps everything
-    dyhat[row * K + k] = d;
+    act_st<HS>(dyhat, row * K + k, d);
     S1 += d;
     S2 = fmaf(d, z, S2);
   }
+  }); });
   if (stream == 1) {
     red[k][0] = S1; red[k][1] = S2;
 #pragma unroll
@@ -304,12 +324,12 @@ int seg_out_part_stride() { return 2 + SEG_CM; }
 int seg_out_part_rows() { return SEG_RPB; }
 
 int seg_out_bwd(const pn_operand* x, const float* w, const float* dlogits, int B, int N, int K, int C, float* dyhat, float* stat_part,
-                float* wslab, hipStream_t st) {
+                float* wslab, hipStream_t st, int store16) {
   PN_CHECK_ARG(x && x->s1 && w && dlogits && dyhat && wslab, "seg_out_bwd: null pointer");
   PN_CHECK_ARG(K == 128, "seg_out_bwd: the layer feeding the segmentation output must be 128 wide (K=%d)", K);
   PN_CHECK_ARG(C >= 1 && C <= SEG_CM, "seg_out_bwd: segmentation width %d not in [1,%d]", C, SEG_CM);
   const int tpc = cdiv(N, 128);
-  hipLaunchKernelGGL(seg_out_bwd_kernel, dim3(B * tpc), dim3(256), 0, st, *x, w, dlogits, N, C, tpc, dyhat, stat_part, wslab);
+  hipLaunchKernelGGL(seg_out_bwd_kernel, dim3(B * tpc), dim3(256), 0, st, *x, w, dlogits, N, C, tpc, dyhat, stat_part, wslab, store16);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

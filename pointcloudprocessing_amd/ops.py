@@ -47,8 +47,9 @@ def conv3_wgrad(x3, dz_op, B, N, C_):
 
 
 def conv_fwd(x_op, w, B, N, K, C_, prec, w_cloud_stride=0, cloud_bias=None, store=True, want_stats=True):
+    """prec | _lib.PN_STORE_BF16: z comes back as a bf16 tensor"""
     dev = w.device
-    z = torch.empty(B * N, C_, device=dev, dtype=F32) if store else None
+    z = torch.empty(B * N, C_, device=dev, dtype=torch.bfloat16 if prec & _lib.PN_STORE_BF16 else F32) if store else None
     part = torch.empty(_tiles(B, N), 2, C_, device=dev, dtype=F32) if want_stats else None
     check(lib().pn_conv_fwd(C.byref(x_op), ptr(w), w_cloud_stride, B, N, K, C_, ptr(cloud_bias), ptr(z), ptr(part), prec,
                             current_stream()), "pn_conv_fwd")
@@ -114,8 +115,13 @@ def max_resolve(x_op, wf, argb, B, N, K, C_, prec):
 
 def conv_bwd_data(dz_op, w, B, N, K, C_, prec, w_cloud_stride=0, addend=None, zmask=None, msc=None, msh=None,
                   want_stats=True):
+    """prec | _lib.PN_STORE_BF16: out comes back as a bf16 tensor and addend / zmask must be bf16 tensors"""
     dev = w.device
-    out = torch.empty(B * N, C_, device=dev, dtype=F32)
+    s16 = bool(prec & _lib.PN_STORE_BF16)
+    for t, name in ((addend, "addend"), (zmask, "zmask")):
+        if t is not None and t.dtype != (torch.bfloat16 if s16 else F32):
+            raise _lib.PointNetHipError(f"conv_bwd_data: {name} must be {'bf16' if s16 else 'fp32'} for this prec")
+    out = torch.empty(B * N, C_, device=dev, dtype=torch.bfloat16 if s16 else F32)
     part = torch.empty(_tiles(B, N), 2, C_, device=dev, dtype=F32) if want_stats else None
     check(lib().pn_conv_bwd_data(C.byref(dz_op), ptr(w), w_cloud_stride, B, N, K, C_, ptr(addend), ptr(zmask), ptr(msc),
                                  ptr(msh), ptr(out), ptr(part), prec, current_stream()), "pn_conv_bwd_data")

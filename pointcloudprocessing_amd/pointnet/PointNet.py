@@ -616,6 +616,11 @@ class PointNet(torch.nn.Module):
             self._ws[key] = ws
         return ws
 
+    @property
+    def activation_dtype(self):
+        """storage type of the per-point layer-boundary tensors of the plan (workspace entries *.Z, *.dy, *.D, X64, dX64, tmpA12)"""
+        return torch.bfloat16 if self._desc.prec & _lib.PN_STORE_BF16 else torch.float32
+
     def workspace_tensor(self, name: str, B: int, N: int, training: bool, dtype=torch.float32) -> torch.Tensor:
         """View of a named intermediate of the last call of that shape (test introspection)."""
         off, nb = C.c_int64(), C.c_int64()
@@ -690,16 +695,17 @@ class PointNet(torch.nn.Module):
         first site holding a NaN / Inf raises with the reference's own message.  One host read per call: debug mode only, never inside
         a captured step."""
         B, N, _ = pc.shape
-        def t(name):
-            return self.workspace_tensor(name, B, N, training)
-        conv = lambda wn: [t(wn + ".Z"), t(wn + ".scale"), t(wn + ".shift")]          # noqa: E731
+        def t(name, dtype=torch.float32):
+            return self.workspace_tensor(name, B, N, training, dtype)
+        act = self.activation_dtype
+        conv = lambda wn: [t(wn + ".Z", act), t(wn + ".scale"), t(wn + ".shift")]          # noqa: E731
         sites = [("Input point cloud contains nan values", "pointnet_input", [pc])]
         if not self._vanilla:
             sites.append(("Input transform produced nan values.", self.input_transform.name, [t("iT.R"), t("Weff1")]))
         sites += [("mlp_1_1 produced nan values.", self.mlp_1_1.name, conv("m11")),
                   ("mlp_1_2 produced nan values.", self.mlp_1_2.name, conv("m12"))]
         if not self._vanilla:
-            sites.append(("Feature transform produced nan values.", self.feature_transform.name, [t("fT.R"), t("X64")]))
+            sites.append(("Feature transform produced nan values.", self.feature_transform.name, [t("fT.R"), t("X64", act)]))
         sites += [("mlp_2_1 produced nan values.", self.mlp_2_1.name, conv("m21")),
                   ("mlp_2_2 produced nan values.", self.mlp_2_2.name, conv("m22")),
                   ("mlp_2_3 produced nan values.", self.mlp_2_3.name, [t("mm23.zstar"), t("mm23.g")]),
@@ -714,7 +720,8 @@ class PointNet(torch.nn.Module):
         counts = torch.zeros(len(sites), dtype=torch.int32, device=pc.device)
         for i, (_, _, tensors) in enumerate(sites):
             for x in tensors:
-                check(lib().pn_count_nonfinite(ptr(x), x.numel(), ptr(counts[i:i + 1]), current_stream()), "pn_count_nonfinite")
+                check(lib().pn_count_nonfinite(ptr(x), x.numel(), int(x.dtype == torch.bfloat16), ptr(counts[i:i + 1]), current_stream()),
+                      "pn_count_nonfinite")
         bad = counts.cpu().tolist()
         for (msg, layer, _), n in zip(sites, bad):
             if n:

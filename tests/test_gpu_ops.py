@@ -609,3 +609,123 @@ def test_bmm_per_cloud_matrices(dev, K):
     L.check(L.lib().pn_bmm(L.ptr(xd), L.ptr(Rd), B, N, K, L.ptr(out), 1, L.current_stream()), "pn_bmm")
     torch.cuda.synchronize()
     assert torch.equal(out.cpu().view(B, N, K), torch.bmm(x, R))
+
+
+# ------------------------------------------------------------------------------------------------
+# bf16 storage of the per-point tensors (pn_operand.h16, PN_STORE_BF16): fed bf16-representable values, every kernel must give
+# bit for bit what it gives from the same values stored as fp32 (the 16-bit path changes loads and stores, never the arithmetic),
+# and a bf16 output is the round-to-nearest-even of the fp32 output.
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("prec", [1, 3])
+@pytest.mark.parametrize("B,N,K,C", [(2, 300, 64, 128), (1, 130, 128, 64), (3, 64, 512, 256)])
+def test_bf16_storage_conv_fwd(dev, prec, B, N, K, C):
+    ops, L = _ops(), _lib()
+    g = torch.Generator().manual_seed(31)
+    x = _bf(torch.randn(B * N, K, generator=g)).to(dev)
+    ca = (torch.rand(K, generator=g) + 0.5).to(dev); cc = (torch.randn(K, generator=g) * 0.3).to(dev)
+    w = (torch.randn(K, C, generator=g) * 0.2).to(dev)
+    bias = torch.randn(B, C, generator=g).to(dev)
+    z32, p32 = ops.conv_fwd(L.operand(x.float(), ca=ca, cc=cc, relu=True), w, B, N, K, C, prec, cloud_bias=bias)
+    z16, p16 = ops.conv_fwd(L.operand(x, ca=ca, cc=cc, relu=True), w, B, N, K, C, prec | L.PN_STORE_BF16, cloud_bias=bias)
+    assert z16.dtype == torch.bfloat16
+    assert torch.equal(z16, _bf(z32))
+    assert torch.equal(p16, p32)                 # statistics come from the fp32 values before rounding
+    # mixed: 16-bit source, fp32 store
+    z_mixed, _ = ops.conv_fwd(L.operand(x, ca=ca, cc=cc, relu=True), w, B, N, K, C, prec, cloud_bias=bias)
+    assert torch.equal(z_mixed, z32)
+
+
+@pytest.mark.parametrize("prec", [1, 3])
+def test_bf16_storage_conv_bwd_data(dev, prec):
+    ops, L = _ops(), _lib()
+    g = torch.Generator().manual_seed(32)
+    B, N, K, C = 2, 200, 128, 64
+    dy = _bf(torch.randn(B * N, K, generator=g)).to(dev); zz = _bf(torch.randn(B * N, K, generator=g)).to(dev)
+    ca, cb, cc = ((torch.randn(K, generator=g) * 0.5).to(dev) for _ in range(3))
+    w = (torch.randn(C, K, generator=g) * 0.2).to(dev)
+    addend = _bf(torch.randn(B * N, C, generator=g)).to(dev); zprev = _bf(torch.randn(B * N, C, generator=g)).to(dev)
+    msc = torch.randn(C, generator=g).to(dev); msh = (torch.randn(C, generator=g) * 0.2).to(dev)
+    o32, p32 = ops.conv_bwd_data(L.operand(dy.float(), ca=ca, cc=cc, s2=zz.float(), cb=cb), w, B, N, K, C, prec, addend=addend.float(),
+                                 zmask=zprev.float(), msc=msc, msh=msh)
+    o16, p16 = ops.conv_bwd_data(L.operand(dy, ca=ca, cc=cc, s2=zz, cb=cb), w, B, N, K, C, prec | L.PN_STORE_BF16, addend=addend,
+                                 zmask=zprev, msc=msc, msh=msh)
+    assert o16.dtype == torch.bfloat16 and torch.equal(o16, _bf(o32)) and torch.equal(p16, p32)
+    with pytest.raises(L.PointNetHipError):      # storage types must match the flag
+        ops.conv_bwd_data(L.operand(dy, ca=ca, cc=cc, s2=zz, cb=cb), w, B, N, K, C, prec | L.PN_STORE_BF16, addend=addend.float())
+
+
+@pytest.mark.parametrize("prec", [1, 3])
+@pytest.mark.parametrize("Ci,Cj", [(64, 64), (64, 128), (128, 128), (64, 512), (512, 256)])
+def test_bf16_storage_conv_wgrad(dev, prec, Ci, Cj):
+    ops, L = _ops(), _lib()
+    g = torch.Generator().manual_seed(33)
+    B, N = 2, 300
+    a = _bf(torch.randn(B * N, Ci, generator=g)).to(dev)
+    dy = _bf(torch.randn(B * N, Cj, generator=g)).to(dev); zz = _bf(torch.randn(B * N, Cj, generator=g)).to(dev)
+    sa, sh = (torch.rand(Ci, generator=g) + 0.5).to(dev), (torch.randn(Ci, generator=g) * 0.2).to(dev)
+    ca, cb, cc = ((torch.randn(Cj, generator=g) * 0.5).to(dev) for _ in range(3))
+    for slab_rows in (128, 64):
+        ref = ops.conv_wgrad(L.operand(a.float(), ca=sa, cc=sh, relu=True), L.operand(dy.float(), ca=ca, cc=cc, s2=zz.float(), cb=cb), B, N, Ci, Cj,
+                             prec, slab_rows=slab_rows)
+        got = ops.conv_wgrad(L.operand(a, ca=sa, cc=sh, relu=True), L.operand(dy, ca=ca, cc=cc, s2=zz, cb=cb), B, N, Ci, Cj, prec,
+                             slab_rows=slab_rows)
+        assert torch.equal(got, ref), float((got - ref).abs().max())
+    # one 16-bit operand, one fp32 operand
+    got = ops.conv_wgrad(L.operand(a, ca=sa, cc=sh, relu=True), L.operand(dy.float(), ca=ca, cc=cc, s2=zz.float(), cb=cb), B, N, Ci, Cj, prec,
+                         slab_rows=64)
+    assert torch.equal(got, ref)
+
+
+def test_bf16_storage_conv3_wgrad_and_seg_out(dev):
+    ops, L = _ops(), _lib()
+    g = torch.Generator().manual_seed(34)
+    B, N, C_ = 3, 257, 64
+    x3 = torch.randn(B * N, 3, generator=g).to(dev)
+    dy = _bf(torch.randn(B * N, C_, generator=g)).to(dev); zz = _bf(torch.randn(B * N, C_, generator=g)).to(dev)
+    ca, cb, cc = ((torch.randn(C_, generator=g) * 0.5).to(dev) for _ in range(3))
+    ref = ops.conv3_wgrad(x3, L.operand(dy.float(), ca=ca, cc=cc, s2=zz.float(), cb=cb), B, N, C_)
+    got = ops.conv3_wgrad(x3, L.operand(dy, ca=ca, cc=cc, s2=zz, cb=cb), B, N, C_)
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-4)      # same values, another summation order (row pairs across the half-waves)
+    # segmentation output layer (K = 128: the MFMA form)
+    K, M, CS = 128, B * N, 12
+    z = _bf(torch.randn(M, K, generator=g)).to(dev)
+    sa, sh = (torch.rand(K, generator=g) + 0.5).to(dev), (torch.randn(K, generator=g) * 0.3).to(dev)
+    w = (torch.randn(K, CS, generator=g) * 0.2).to(dev); bias = torch.randn(CS, generator=g).to(dev)
+    lab = torch.randint(0, CS, (M,), generator=g).int().to(dev)
+    stride, rpb = L.lib().pn_seg_out_part_stride(), L.lib().pn_seg_out_part_rows()
+    nparts = (M + rpb - 1) // rpb
+    res = []
+    for src in (z.float(), z):
+        op = L.operand(src, ca=sa, cc=sh, ld=K, relu=True)
+        p = torch.empty(M, CS, device=dev); d = torch.empty(M, CS, device=dev); part = torch.zeros(nparts * stride, device=dev)
+        L.check(L.lib().pn_seg_out_fwd(C.byref(op), L.ptr(w), L.ptr(bias), M, K, CS, L.ptr(lab), 1.0 / M, L.ptr(p), L.ptr(d), L.ptr(part),
+                                       L.current_stream()), "pn_seg_out_fwd")
+        res.append((p, d, part))
+    for a_, b_ in zip(res[0], res[1]):
+        assert torch.equal(a_, b_)
+
+
+@pytest.mark.parametrize("B,N", [(2, 256), (3, 200), (16, 136), (40, 520)])
+def test_bf16_storage_panel_kernel_and_resolve(dev, B, N):
+    ops, L = _ops(), _lib()
+    g = torch.Generator().manual_seed(35 + N)
+    K, C_ = 128, 1024
+    x = _bf(torch.randn(B * N, K, generator=g)).to(dev)
+    ca = (torch.rand(K, generator=g) + 0.5).to(dev); cc = (torch.randn(K, generator=g) * 0.3).to(dev)
+    w = (torch.randn(K, C_, generator=g) * 0.1).to(dev); gamma = torch.randn(C_, generator=g).to(dev)
+    wf = ops.weights_prep(w, gamma)
+    res = []
+    for src in (x.float(), x):
+        op = L.operand(src, ca=ca, cc=cc, relu=True)
+        pmax, pblk, sumsq, sumz = ops.conv_fwd_max_panel(op, wf, B, N, K, C_, 1)
+        beta = torch.zeros(C_, device=dev); mm = torch.zeros(C_, device=dev); mv = torch.ones(C_, device=dev)
+        fin = ops.panel_finalize(pmax, pblk, sumsq, sumz, B, N, gamma, beta, mm, mv, training=True)
+        arg = ops.max_resolve(op, wf, fin[-1], B, N, K, C_, 1)
+        res.append((pmax, pblk, sumsq, sumz, arg))
+    for a_, b_ in zip(res[0], res[1]):
+        assert torch.equal(a_, b_)
+    with pytest.raises(L.PointNetHipError):      # the panel kernel takes 16-bit sources in the bf16 mode only
+        ops.conv_fwd_max_panel(L.operand(x, ca=ca, cc=cc, relu=True), wf, B, N, K, C_, 3)
