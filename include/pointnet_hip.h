@@ -300,7 +300,9 @@ typedef struct pn_model_io {
   float* grads;             /* flat gradients, same layout (NULL for inference) */
   const uint8_t* trainable; /* HOST array of PN_NUM_BLOCKS flags (layer.trainable, PointNet.py:294-342); NULL = all */
   int32_t training;         /* keras `training` argument */
-  int32_t pad_;
+  /* != 0 (training, grads != NULL): pn_model_forward clears the gradient buffer in its first launch and the pn_model_backward
+   * that follows (same io) does not -- one launch less per step.  0: pn_model_backward clears it itself. */
+  int32_t zero_grads_in_forward;
   const uint8_t* keep1; /* dropout keep masks (B,512) / (B,256), 1 = keep; NULL = no dropout */
   const uint8_t* keep2;
   /* optional fused loss (pointnet_train.py:334-345): labels (B) / (B*N) int32, se3 target (B,3,3) */
@@ -330,6 +332,11 @@ typedef struct pn_model_io {
    * input transform).  Lets a data-parallel caller all-reduce the large first bucket while phase 2 runs.  1 must precede 2. */
   int32_t bwd_phase;
   int32_t pad3_;
+  /* optional (training, keep1 / keep2 given): draw the two keep masks inside pn_model_forward's first launch -- what
+   * pn_dropout_masks(keep1, B*512, keep2, B*256, dropout_rate, dropout_seed, dropout_step) would write, counter increment
+   * included -- instead of taking them as inputs.  dropout_step: device uint32 counter; NULL = the masks are inputs. */
+  uint64_t dropout_seed;
+  uint32_t* dropout_step;
 } pn_model_io;
 
 int pn_model_num_slots(const pn_model_desc* d);

@@ -49,13 +49,13 @@ class pn_slot_info(C.Structure):
 
 class pn_model_io(C.Structure):
     _fields_ = [("pc", C.c_void_p), ("B", C.c_int32), ("N", C.c_int32), ("params", C.c_void_p),
-                ("grads", C.c_void_p), ("trainable", C.c_void_p), ("training", C.c_int32), ("pad_", C.c_int32),
+                ("grads", C.c_void_p), ("trainable", C.c_void_p), ("training", C.c_int32), ("zero_grads_in_forward", C.c_int32),
                 ("keep1", C.c_void_p), ("keep2", C.c_void_p), ("labels_cls", C.c_void_p),
                 ("labels_seg", C.c_void_p), ("se3", C.c_void_p), ("loss_weights", C.c_float * 3),
                 ("pad2_", C.c_float), ("out_cls", C.c_void_p), ("out_seg", C.c_void_p), ("out_R", C.c_void_p),
                 ("scalars", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("prof_events", C.POINTER(C.c_void_p)), ("aux_stream", C.c_void_p),
-                ("bwd_phase", C.c_int32), ("pad3_", C.c_int32)]
+                ("bwd_phase", C.c_int32), ("pad3_", C.c_int32), ("dropout_seed", C.c_uint64), ("dropout_step", C.c_void_p)]
 
 
 # every symbol include/pointnet_hip.h declares: name -> (restype, argtypes)

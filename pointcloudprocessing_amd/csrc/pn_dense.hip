@@ -4,6 +4,7 @@
 // fixed order so results are bitwise reproducible.
 #include "pn_common.h"
 #include "pn_internal.h"
+#include "pn_loss_bodies.h"
 
 namespace pn {
 
@@ -54,8 +55,11 @@ static inline int dl_nsplit(int K) {
 }
 static inline int dl_split_len(int K) { return cdiv(cdiv(K, dl_nsplit(K)), DL_KSTEP) * DL_KSTEP; }
 
+// Two layers of one grid shape (same K and C) may share a launch: blockIdx.z picks the job (pn_model.hip: the classification head's
+// first layer and the global-feature half of seg_l1 both consume the pooled feature vector).
 template <bool TRANS>
-__global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a) {
+__global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a0, const DenseArgs a1) {
+  const DenseArgs& a = blockIdx.z ? a1 : a0;
   // one LDS object (a second one beside a staging array can cost a full vmcnt drain per step)
   __shared__ __attribute__((aligned(16))) float lds[4 * DL_ROWS * DL_COLS + 16 * 32 + 4];
   float* red = lds;                                        // [wave][row][col]
@@ -559,80 +563,12 @@ __global__ __launch_bounds__(256) void transpose2_kernel(const float* __restrict
 // w.r.t. the logits.  Used for the classification head (rows = B).  32 lanes per row (32 rows per pass of the single 1024-thread block);
 // every reduction is a fixed xor-shuffle tree, so the result does not depend on anything but the inputs.
 //   loss_sum[0] = sum_r nll_r ; correct[0] = #(argmax == label)
-__device__ __forceinline__ float grp_sum(float v) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 32);
-  return v;
-}
 __global__ __launch_bounds__(1024) void softmax_xent_rows_kernel(const float* __restrict__ logits, int R, int C,
                                                                 const int* __restrict__ labels, float grad_scale,
                                                                 float* __restrict__ probs, float* __restrict__ dlogits,
                                                                 float* __restrict__ loss_sum, float* __restrict__ correct) {
   __shared__ float rl[32], rc[32];
-  const int lane = threadIdx.x & 31, grp = threadIdx.x >> 5;      // 32 groups of 32 lanes: 32 rows per pass
-  float myloss = 0.f, mycorr = 0.f;       // lane 0 of each group accumulates its rows in row order
-  for (int r0 = 0; r0 < R; r0 += 32) {
-    const int r = r0 + grp;
-    if (r >= R) continue;                 // group-uniform (a group is half a wave; shuffles below use width 32)
-    const float* l = logits + (long long)r * C;
-    float mx = -INFINITY;
-    int am = 0x7fffffff;
-    for (int c = lane; c < C; c += 32)
-      if (l[c] > mx) { mx = l[c]; am = c; }
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {    // max with the lowest index on ties, like the serial scan
-      const float om = __shfl_xor(mx, o, 32);
-      const int oa = __shfl_xor(am, o, 32);
-      if (om > mx || (om == mx && oa < am)) { mx = om; am = oa; }
-    }
-    float sum = 0.f;
-    for (int c = lane; c < C; c += 32) sum += expf(l[c] - mx);
-    sum = grp_sum(sum);
-    const float inv = 1.f / sum;
-    float* p = probs + (long long)r * C;
-    for (int c = lane; c < C; c += 32) p[c] = expf(l[c] - mx) * inv;
-    if (labels) {
-      const int y = labels[r];
-      // keras: q = log(clip(p)), loss = -log_softmax(q)[y]
-      float qs = 0.f;
-      for (int c = lane; c < C; c += 32) qs += clip_nan(expf(l[c] - mx) * inv, 1e-7f, 1.f - 1e-7f);
-      qs = grp_sum(qs);
-      const float pyr = expf(l[y] - mx) * inv;
-      const float py = clip_nan(pyr, 1e-7f, 1.f - 1e-7f);
-      if (lane == 0) {
-        myloss += -(logf(py) - logf(qs));
-        mycorr += (am == y) ? 1.f : 0.f;
-      }
-      if (dlogits) {
-        // dL/dp_i = (s_i - [i==y]) / p_i inside the clip range, 0 outside; s = clip(p)/sum clip(p)
-        float dot = 0.f;
-        for (int c = lane; c < C; c += 32) {
-          const float pc0 = expf(l[c] - mx) * inv;
-          const float pc = clip_nan(pc0, 1e-7f, 1.f - 1e-7f);
-          const bool inr = (pc0 > 1e-7f) && (pc0 < 1.f - 1e-7f);
-          const float dp = inr ? (pc / qs - (c == y ? 1.f : 0.f)) / pc0 : 0.f;
-          dot = fmaf(pc0, dp, dot);
-        }
-        dot = grp_sum(dot);
-        float* d = dlogits + (long long)r * C;
-        for (int c = lane; c < C; c += 32) {
-          const float pc0 = expf(l[c] - mx) * inv;
-          const float pc = clip_nan(pc0, 1e-7f, 1.f - 1e-7f);
-          const bool inr = (pc0 > 1e-7f) && (pc0 < 1.f - 1e-7f);
-          const float dp = inr ? (pc / qs - (c == y ? 1.f : 0.f)) / pc0 : 0.f;
-          d[c] = grad_scale * pc0 * (dp - dot);
-        }
-      }
-    }
-  }
-  if (lane == 0) { rl[grp] = myloss; rc[grp] = mycorr; }
-  __syncthreads();
-  if (threadIdx.x == 0 && labels) {
-    float x = 0.f, y = 0.f;
-    for (int i = 0; i < 32; ++i) { x += rl[i]; y += rc[i]; }
-    if (loss_sum) loss_sum[0] = x;
-    if (correct) correct[0] = y;
-  }
+  softmax_xent_rows_body(logits, R, C, labels, grad_scale, probs, dlogits, loss_sum, correct, rl, rc);
 }
 
 // dlogits from an arbitrary upstream d(probs):  dlogit_j = p_j (dp_j - sum_i p_i dp_i)
@@ -666,23 +602,46 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
 // ---- host wrappers ---------------------------------------------------------------------------------------
 size_t dense_partial_floats(int R, int K, int C) { return (size_t)dl_nsplit(K) * R * C; }
 
-int dense_layer(const float* x, int ldx, const float* w, int ldw, bool trans, int R, int K, int C, float* partial, unsigned* counters,
-                const float* bias, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps, int bn_mode,
-                int act, const unsigned char* keep, float keep_scale, float* z_out, float* a_out, float* mean_o, float* invstd_o,
-                hipStream_t st) {
+static int dense_args(DenseArgs& a, const float* x, int ldx, const float* w, int ldw, int R, int K, int C, float* partial, unsigned* counters,
+                      const float* bias, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps, int bn_mode,
+                      int act, const unsigned char* keep, float keep_scale, float* z_out, float* a_out, float* mean_o, float* invstd_o) {
   PN_CHECK_ARG(x && w && partial && counters && z_out && R > 0 && K > 0 && C > 0, "dense_layer: bad arguments");
   PN_CHECK_ARG(cdiv(C, DL_COLS) <= DENSE_MAX_COUNTERS, "dense_layer: C=%d needs more than %d counters", C, DENSE_MAX_COUNTERS);
   PN_CHECK_ARG(!bn_mode || (gamma && beta && mm && mv), "dense_layer: BatchNormalization needs gamma/beta/moving statistics");
-  DenseArgs a;
   a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.R = R; a.K = K; a.C = C;
   a.nsplit = dl_nsplit(K); a.split_len = dl_split_len(K);
   a.partial = partial; a.counters = counters;
   a.bias = bias; a.gamma = gamma; a.beta = beta; a.mm = mm; a.mv = mv; a.momentum = momentum; a.eps = eps;
   a.bn_mode = bn_mode; a.act = act; a.keep = keep; a.keep_scale = keep_scale;
   a.z_out = z_out; a.a_out = a_out; a.mean_o = mean_o; a.invstd_o = invstd_o;
+  return PN_OK;
+}
+int dense_layer(const float* x, int ldx, const float* w, int ldw, bool trans, int R, int K, int C, float* partial, unsigned* counters,
+                const float* bias, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps, int bn_mode,
+                int act, const unsigned char* keep, float keep_scale, float* z_out, float* a_out, float* mean_o, float* invstd_o,
+                hipStream_t st) {
+  DenseArgs a;
+  PN_TRY(dense_args(a, x, ldx, w, ldw, R, K, C, partial, counters, bias, gamma, beta, mm, mv, momentum, eps, bn_mode, act, keep, keep_scale,
+                    z_out, a_out, mean_o, invstd_o));
   const dim3 grid(cdiv(C, DL_COLS), a.nsplit);
-  if (trans) hipLaunchKernelGGL(dense_layer_kernel<true>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(dense_layer_kernel<false>, grid, dim3(256), 0, st, a);
+  if (trans) hipLaunchKernelGGL(dense_layer_kernel<true>, grid, dim3(256), 0, st, a, a);
+  else hipLaunchKernelGGL(dense_layer_kernel<false>, grid, dim3(256), 0, st, a, a);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+// out2 (R, C) = x . w2 (plain product, no bias) in the launch of a dense layer of the same K and C on the same input: the second job
+// uses the upper halves of `partial` (2 * dense_partial_floats) and of the counters
+int dense_layer_with_plain(const float* x, int ldx, const float* w, int ldw, int R, int K, int C, float* partial, unsigned* counters,
+                           const float* bias, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps,
+                           int bn_mode, int act, const unsigned char* keep, float keep_scale, float* z_out, float* a_out, float* mean_o,
+                           float* invstd_o, const float* w2, int ldw2, float* out2, hipStream_t st) {
+  PN_CHECK_ARG(2 * cdiv(C, DL_COLS) <= DENSE_MAX_COUNTERS, "dense_layer_with_plain: C=%d needs more than %d counters", C, DENSE_MAX_COUNTERS);
+  DenseArgs a, b;
+  PN_TRY(dense_args(a, x, ldx, w, ldw, R, K, C, partial, counters, bias, gamma, beta, mm, mv, momentum, eps, bn_mode, act, keep, keep_scale,
+                    z_out, a_out, mean_o, invstd_o));
+  PN_TRY(dense_args(b, x, ldx, w2, ldw2, R, K, C, partial + dense_partial_floats(R, K, C), counters + cdiv(C, DL_COLS), nullptr, nullptr, nullptr,
+                    nullptr, nullptr, 0.f, 0.f, 0, 0, nullptr, 1.f, out2, nullptr, nullptr, nullptr));
+  hipLaunchKernelGGL(dense_layer_kernel<false>, dim3(cdiv(C, DL_COLS), a.nsplit, 2), dim3(256), 0, st, a, b);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

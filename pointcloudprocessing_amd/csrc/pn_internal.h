@@ -33,9 +33,20 @@ int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const f
                    const float* beta, float* mm, float* mv, float momentum, float eps, int use_batch, int update, float* mean, float* invstd,
                    float* scale, float* shift, float* g, float* zstar, int* argq, hipStream_t st);
 
-// pn_pointwise.hip
+// pn_prologue.hip
 int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st);
-int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st, int store16 = 0);
+// normalisation + fragment-ordered copies of three kernels (+ zero_u cleared) + optionally the gradient buffer cleared (grads) and the
+// dropout masks drawn (step): one launch
+int fwd_prologue(const float* xyz, int B, int N, float* out, float* centroid, float* scale, const float* const* w, const float* const* sgn,
+                 const int* K, const int* C, void* const* hi, void* const* lo, unsigned* zero_u, int zero_u_n, float* grads, long long n_grads,
+                 unsigned char* k1, long long n1, unsigned char* k2, long long n2, float rate, unsigned long long seed, unsigned* step,
+                 hipStream_t st);
+
+// pn_pointwise.hip
+// Rm: optional per-cloud 3x3 matrices folded into the (shared, wcs = 0) kernel on the fly, w_eff[b] = Rm[b] @ w, also written to
+// weff_out (B, 3, C) and Rm copied to r_copy (B, 9) when given
+int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st, int store16 = 0,
+              const float* Rm = nullptr, float* weff_out = nullptr, float* r_copy = nullptr);
 int conv3_wgrad(const float* x3, const pn_operand* dz, int B, int N, int C, float* slabs, hipStream_t st);
 int slab_reduce(const float* slabs, int n_slabs, int per_group, long long elems, float* out, hipStream_t st);
 // several whole-range slab reductions (out_j = sum over the n_slabs_j slabs of job j, same summation order as slab_reduce) in one launch
@@ -65,6 +76,10 @@ int dense_layer(const float* x, int ldx, const float* w, int ldw, bool trans, in
                 const float* bias, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps, int bn_mode,
                 int act, const unsigned char* keep, float keep_scale, float* z_out, float* a_out, float* mean_o, float* invstd_o,
                 hipStream_t st);
+int dense_layer_with_plain(const float* x, int ldx, const float* w, int ldw, int R, int K, int C, float* partial, unsigned* counters,
+                           const float* bias, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps,
+                           int bn_mode, int act, const unsigned char* keep, float keep_scale, float* z_out, float* a_out, float* mean_o,
+                           float* invstd_o, const float* w2, int ldw2, float* out2, hipStream_t st);
 int dense_bwd_fused(const float* da, const float* z, const float* x, int ldx, int R, int K, int C, const float* gamma, const float* beta,
                     const float* mean, const float* invstd, int bn_mode, int act, const unsigned char* keep, float keep_scale, float* dz,
                     float* dgamma, float* dbeta, float* dbias, float* dw, hipStream_t st);
@@ -73,8 +88,6 @@ int dense_bwd_pre(const float* da, const float* z, int R, int C, const float* ga
                   float* dbeta, float* dbias, hipStream_t st);
 int dense_wgrad(const float* x, int ldx, const float* dz, int R, int K, int C, float* dw, hipStream_t st, float* db = nullptr);   // db: column sums of dz
 int transpose(const float* in, int R, int C, float* out, hipStream_t st);
-int weights_prep3(const float* const* w, const float* const* sgn, const int* K, const int* C, void* const* hi, void* const* lo,
-                  unsigned* zero_p, int zero_n, hipStream_t st);
 int transpose2(const float* in, int R, int C, const float* rowscale, float* out, float* out2, hipStream_t st);
 int softmax_xent_rows(const float* logits, int R, int C, const int* labels, float grad_scale, float* probs, float* dlogits,
                       float* loss_sum, float* correct, hipStream_t st);
@@ -91,6 +104,10 @@ int seg_out_part_rows();
 int seg_out_bwd(const pn_operand* x, const float* w, const float* dlogits, int B, int N, int K, int C, float* dyhat, float* stat_part,
                 float* wslab, hipStream_t st, int store16 = 0);
 int sum_partials(const float* part, int n, int stride, int elems, float* out, hipStream_t st);
+// softmax_xent_rows + sum_partials (n_sum elements; 0: none) + the forward value of mse (mse_out NULL: none) in one launch
+int loss_tail(const float* logits, int R, int C, const int* labels, float grad_scale, float* probs, float* dlogits, float* loss_sum,
+              float* correct, const float* part, int n, int stride, int n_sum, float* sum_out, const float* Rm, const float* T, int n_mse,
+              float* mse_out, hipStream_t st);
 
 // pn_maxbwd.hip
 int maxbwd_prep(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean, const float* invstd,

@@ -537,13 +537,20 @@ struct Run {
       void* his[3] = {d.vanilla ? nullptr : w.iT.m3.wb_hi, d.vanilla ? nullptr : w.fT.m3.wb_hi, w.mm23.wb_hi};
       void* los[3] = {(x3 && !d.vanilla) ? w.iT.m3.wb_lo : nullptr, (x3 && !d.vanilla) ? w.fT.m3.wb_lo : nullptr, x3 ? w.mm23.wb_lo : nullptr};
       const float* sgs[3] = {d.vanilla ? nullptr : p(L.iT.c3.gamma), d.vanilla ? nullptr : p(L.fT.c3.gamma), p(L.m23.gamma)};
-      PN_TRY(weights_prep3(ws, sgs, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS, st));   // copies carry sign(gamma): max(sgn*z) needs no multiply
+      // copies carry sign(gamma): max(sgn*z) needs no multiply.  The same launch normalises the clouds and, when the caller asks,
+      // clears the gradient buffer and draws the dropout masks (pn_prologue.hip)
+      const bool zg = training && G && io.zero_grads_in_forward;
+      const bool dm = training && io.dropout_step && io.keep1 && io.keep2 && d.dropout_rate > 0.f;
+      PN_TRY(fwd_prologue(io.pc, B, N, w.pcn, w.cent, w.scl, ws, sgs, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS, zg ? G : nullptr,
+                          zg ? L.total : 0, dm ? const_cast<unsigned char*>(io.keep1) : nullptr, dm ? (long long)B * 512 : 0,
+                          dm ? const_cast<unsigned char*>(io.keep2) : nullptr, dm ? (long long)B * 256 : 0, d.dropout_rate, io.dropout_seed,
+                          dm ? io.dropout_step : nullptr, st));
     }
-    PN_TRY(normalize(io.pc, B, N, w.pcn, w.cent, w.scl, st));
     if (!d.vanilla) {
       PN_TRY(fwd_tnet(w.iT, L.iT, nullptr));
-      PN_TRY(fold3_fwd(w.iT.R, p(L.m11.kernel), B, 64, w.Weff1, st, io.out_R));   // also copies R to the third output
-      PN_TRY(conv3_fwd(w.pcn, w.Weff1, 192, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st, s16));
+      // tf.matmul(pc, R) (PointNet.py:207) folded into mlp_1_1's kernel inside the launch; it also leaves W_eff and the third output
+      PN_TRY(conv3_fwd(w.pcn, p(L.m11.kernel), 0, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st, s16, w.iT.R, w.Weff1,
+                       io.out_R));
     } else {
       PN_TRY(conv3_fwd(w.pcn, p(L.m11.kernel), 0, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st, s16));
     }
@@ -561,17 +568,20 @@ struct Run {
     const float* Gf = w.mm23.g;
 
     // classification head (PointNet.py:252-263)
-    PN_TRY(fwd_dense(w.c1, L.c1, Gf, 1, training ? io.keep1 : nullptr));
+    {   // + in the same launch the global-feature half of seg_l1's kernel applied to the pooled vector (PointNet.py:268-275): w.gb
+      const LRef& r = L.c1;
+      const int mode = r.has_bn ? (bn_batch(r.block) ? 1 : 2) : 0;
+      PN_TRY(dense_layer_with_plain(Gf, r.cin, p(r.kernel), r.cout, B, r.cin, r.cout, w.dense_part, w.dcount, p(r.bias), p(r.gamma), p(r.beta),
+                                    p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, mode, 1, training ? io.keep1 : nullptr,
+                                    1.f / (1.f - d.dropout_rate), w.c1.z, w.c1.a, w.c1.mean, w.c1.invstd, p(L.s1.kernel) + 64 * 512, 512, w.gb,
+                                    st));
+    }
     PN_TRY(fwd_dense(w.c2, L.c2, w.c1.a, 1, training ? io.keep2 : nullptr));
     PN_TRY(dense_plain(w.c2.a, 256, p(L.c3.kernel), d.ccls, false, 256, d.ccls, p(L.c3.bias), w.cls_logits));
-    const bool fused = io.labels_cls != nullptr;
-    PN_TRY(softmax_xent_rows(w.cls_logits, B, d.ccls, io.labels_cls, fused ? io.loss_weights[0] / (float)B : 0.f, io.out_cls,
-                             (fused && training) ? w.cls_dlogits : nullptr, io.scalars ? io.scalars + 0 : nullptr,
-                             io.scalars ? io.scalars + 1 : nullptr, st));
+    const bool fused = io.labels_cls != nullptr;     // the softmax + loss of these logits: in the pass's last launch, below
 
     // segmentation head (PointNet.py:268-290)
     const float* Ws1 = p(L.s1.kernel);
-    PN_TRY(dense_plain(Gf, 1024, Ws1 + 64 * 512, 512, false, 1024, 512, nullptr, w.gb));
     // seg_l1 always emits its forward partials: the backward needs the per-cloud sums of z
     PN_TRY(conv_fwd(&x64, Ws1, 0, B, N, 64, 512, w.gb, w.s1.Z, w.s1.part, prec, st));
     PN_TRY(bn_fin(w.s1, L.s1));
@@ -582,18 +592,20 @@ struct Run {
     const bool fseg = io.labels_seg != nullptr;
     PN_TRY(seg_out_fwd(&a4, p(L.s5.kernel), p(L.s5.bias), M, 128, d.cseg, io.labels_seg, fseg ? io.loss_weights[1] / (float)M : 0.f,
                        io.out_seg, (fseg && training) ? w.seg_dlogits : nullptr, fseg ? w.seg_part : nullptr, st));
-    if (fseg && io.scalars)
-      PN_TRY(sum_partials(w.seg_part, (int)cdivll(M, seg_out_part_rows()), seg_out_part_stride(), 2, io.scalars + 2, st));
-
     // third output: the input transform (PointNet.py:292); identity for vanilla (:211)
     if (io.out_R) {
       if (d.vanilla) {
         PN_TRY(fill_eye3(io.out_R, B, st));
       }
     }
-    if (io.se3 && io.scalars) {
-      const float* Rp = d.vanilla ? io.out_R : w.iT.R;
-      if (Rp) PN_TRY(mse(Rp, io.se3, B * 9, 0.f, nullptr, io.scalars + 4, st));
+    {   // one launch: classification softmax (+ loss, d logits), the segmentation loss / accuracy sums, the rotation loss value
+      const float* Rp = (io.se3 && io.scalars) ? (d.vanilla ? io.out_R : w.iT.R) : nullptr;
+      const bool sums = fseg && io.scalars;
+      PN_TRY(loss_tail(w.cls_logits, B, d.ccls, io.labels_cls, fused ? io.loss_weights[0] / (float)B : 0.f, io.out_cls,
+                       (fused && training) ? w.cls_dlogits : nullptr, io.scalars ? io.scalars + 0 : nullptr,
+                       io.scalars ? io.scalars + 1 : nullptr, sums ? w.seg_part : nullptr, sums ? (int)cdivll(M, seg_out_part_rows()) : 0,
+                       seg_out_part_stride(), sums ? 2 : 0, sums ? io.scalars + 2 : nullptr, Rp, io.se3, B * 9, Rp ? io.scalars + 4 : nullptr,
+                       st));
     }
     if (io.scalars && !d.vanilla) {
       if (d.reg_in) {
@@ -812,7 +824,7 @@ struct Run {
     // feature_transform.*).  A data-parallel caller all-reduces the first bucket while phase 2 runs (engine.TrainStep).
     const int phase = io.bwd_phase;
     if (phase != 2) {
-    PN_TRY(zero_fill2(G, L.total, reinterpret_cast<float*>(w.dcount), DENSE_MAX_COUNTERS, st));
+    if (!io.zero_grads_in_forward) PN_TRY(zero_fill2(G, L.total, reinterpret_cast<float*>(w.dcount), DENSE_MAX_COUNTERS, st));
 
     // ---- segmentation head ----
     bool have_dx64 = false;     // w.dX64 holds the seg head's contribution to d(X_64)

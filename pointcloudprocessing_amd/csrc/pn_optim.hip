@@ -3,6 +3,7 @@
 // keras.losses.MeanSquaredError on the input transform (pointnet_train.py:339),
 // the orthogonality regulariser 1e-3 * l2_loss(I - R R^T) (pointnet/PointNet.py:447-451).
 #include "pn_common.h"
+#include "pn_loss_bodies.h"
 
 namespace pn {
 
@@ -38,16 +39,40 @@ __global__ void adam_prepare_kernel(const int* __restrict__ iterations, double l
 __global__ __launch_bounds__(1024) void adam_fused_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, long long n, int* __restrict__ iterations, double lr0,
                                                          double decay_rate, double decay_steps, double beta1, double beta2, float eps,
-                                                         float grad_scale, float* __restrict__ scratch) {
+                                                         float grad_scale, float* __restrict__ scratch, int vec) {
   const float alpha = scratch[0];
   const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);      // keras: the Python float 1 - beta, cast to fp32
-  for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < n; i += (long long)gridDim.x * 1024) {
-    const float gi = g[i] * grad_scale;
-    const float mi = m[i] + (gi - m[i]) * omb1;
-    const float vi = v[i] + (gi * gi - v[i]) * omb2;
-    m[i] = mi;
-    v[i] = vi;
-    p[i] -= mi * alpha / (sqrtf(vi) + eps);
+  auto upd = [&](float& pi, float gi0, float& mi0, float& vi0) {
+    const float gi = gi0 * grad_scale;
+    const float mi = mi0 + (gi - mi0) * omb1;
+    const float vi = vi0 + (gi * gi - vi0) * omb2;
+    mi0 = mi;
+    vi0 = vi;
+    pi -= mi * alpha / (sqrtf(vi) + eps);
+  };
+  // 28 bytes of traffic per parameter and nothing else: 16-byte accesses, two quads per thread in flight (the four arrays are
+  // 16-byte aligned: checked by the launcher), a scalar tail for n % 4
+  const long long n4 = vec ? (n >> 2) : 0;
+  const long long stride = (long long)gridDim.x * 1024;
+  float4* p4 = reinterpret_cast<float4*>(p); const float4* g4 = reinterpret_cast<const float4*>(g);
+  float4* m4 = reinterpret_cast<float4*>(m); float4* v4 = reinterpret_cast<float4*>(v);
+  for (long long i = (long long)blockIdx.x * 1024 + threadIdx.x; i < n4; i += 2 * stride) {
+    const long long j = i + stride;
+    const bool two = j < n4;
+    const long long jj = two ? j : i;
+    float4 pa = p4[i], ga = g4[i], ma = m4[i], va = v4[i];
+    float4 pb = p4[jj], gb = g4[jj], mb = m4[jj], vb = v4[jj];
+    upd(pa.x, ga.x, ma.x, va.x); upd(pa.y, ga.y, ma.y, va.y); upd(pa.z, ga.z, ma.z, va.z); upd(pa.w, ga.w, ma.w, va.w);
+    p4[i] = pa; m4[i] = ma; v4[i] = va;
+    if (two) {
+      upd(pb.x, gb.x, mb.x, vb.x); upd(pb.y, gb.y, mb.y, vb.y); upd(pb.z, gb.z, mb.z, vb.z); upd(pb.w, gb.w, mb.w, vb.w);
+      p4[j] = pb; m4[j] = mb; v4[j] = vb;
+    }
+  }
+  for (long long i = (n4 << 2) + (long long)blockIdx.x * 1024 + threadIdx.x; i < n; i += stride) {
+    float pi = p[i], mi = m[i], vi = v[i];
+    upd(pi, g[i], mi, vi);
+    p[i] = pi; m[i] = mi; v[i] = vi;
   }
   __syncthreads();                        // every thread of this block has read scratch[0]
   if (threadIdx.x == 0) {
@@ -79,17 +104,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 // MeanSquaredError over (B,3,3) and its gradient (weight w folded in): out loss_sum = sum (R-T)^2
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ R, const float* __restrict__ T, int n, float gscale,
                                                   float* __restrict__ dR, float* __restrict__ loss_sum) {
-  __shared__ float red[256];
-  float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float d = R[i] - T[i];
-    s = fmaf(d, d, s);
-    if (dR) dR[i] += gscale * d;
-  }
-  s = wave_sum(s);                                   // fixed order: butterfly inside the wave, then the four waves in turn
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0 && loss_sum) *loss_sum = (red[0] + red[1]) + (red[2] + red[3]);
+  __shared__ float red[16];
+  mse_body(R, T, n, gscale, dR, loss_sum, red);
 }
 
 // Orthogonality regulariser per cloud: E = I - R R^T; loss += c/2 * sum E^2; dR += -2c E R.   block per cloud
@@ -228,38 +244,9 @@ int adam_fused(float* p, const float* g, float* m, float* v, long long n, int* i
   // 256 blocks of 1024 threads: one per CU at full occupancy, and only 256 tickets on the counter (a same-address atomic costs
   // ~11 ns: 2048 blocks spent 22 us of a 43 us launch queueing on it)
   const long long blocks = cdivll(n, 1024);
+  const int vec = ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) | reinterpret_cast<uintptr_t>(v)) & 15) == 0;
   hipLaunchKernelGGL(adam_fused_kernel, dim3((unsigned)(blocks < 256 ? blocks : 256)), dim3(1024), 0, st, p, g, m, v, n, iterations, lr0,
-                     decay_rate, decay_steps, beta1, beta2, (float)eps, grad_scale, scratch);
-  PN_CHECK_LAUNCH();
-  return PN_OK;
-}
-
-// Inverted-dropout keep masks for the two classification-head layers from a counter-based generator (no state but a step
-// counter on the device, so a captured graph draws fresh masks at every replay): keep = u(seed, step, index) >= rate.
-// One block; the counter moves once everyone has read it.  (keras draws from TF's stateful generator; there is no stream
-// to be bit-compatible with, so masks are an INPUT of the parity tests.)
-__device__ __forceinline__ unsigned mix32(unsigned x) {      // murmur3 finaliser
-  x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
-  return x;
-}
-__global__ __launch_bounds__(1024) void dropout_masks_kernel(unsigned char* __restrict__ k1, long long n1, unsigned char* __restrict__ k2,
-                                                             long long n2, float rate, unsigned seed_lo, unsigned seed_hi,
-                                                             unsigned* __restrict__ step) {
-  const unsigned st = *step;
-  __syncthreads();
-  const unsigned thr = (unsigned)fminf(rate * 16777216.f, 16777216.f);     // compare on 24 bits
-  const unsigned base = mix32(seed_lo ^ mix32(seed_hi + 0x9e3779b9u * (st + 1u)));
-  for (long long i = threadIdx.x; i < n1 + n2; i += 1024) {
-    const unsigned h = mix32(base + 0x9e3779b9u * (unsigned)i) ^ mix32(seed_hi ^ (unsigned)(i >> 32) ^ (unsigned)i * 0x7feb352du);
-    const unsigned char keep = ((h >> 8) >= thr) ? 1 : 0;
-    if (i < n1) k1[i] = keep; else k2[i - n1] = keep;
-  }
-  if (threadIdx.x == 0) *step = st + 1u;
-}
-int dropout_masks(unsigned char* k1, long long n1, unsigned char* k2, long long n2, float rate, unsigned long long seed, unsigned* step,
-                  hipStream_t st) {
-  PN_CHECK_ARG(step && n1 >= 0 && n2 >= 0 && (n1 == 0 || k1) && (n2 == 0 || k2) && rate >= 0.f && rate < 1.f, "pn_dropout_masks: bad arguments");
-  hipLaunchKernelGGL(dropout_masks_kernel, dim3(1), dim3(1024), 0, st, k1, n1, k2, n2, rate, (unsigned)seed, (unsigned)(seed >> 32), step);
+                     decay_rate, decay_steps, beta1, beta2, (float)eps, grad_scale, scratch, vec);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -298,30 +285,6 @@ int fold3_bwd(const float* dWeff, const float* R, const float* W, int B, int C, 
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
-// Zero fill as an ordinary kernel.  hipMemsetAsync is avoided on purpose: captured into a hipGraph (ROCm 7.2) the
-// 16 MiB memset node of the gradient buffer replayed with a garbage fill pattern once another model had launched
-// work between two replays (tools/graph_hunt.py); a kernel node has no such state.
-__global__ __launch_bounds__(256) void zero_fill_kernel(float* __restrict__ p, long long n, float* __restrict__ p2, int n2) {
-  if (blockIdx.x == 0 && p2)
-    for (int i = threadIdx.x; i < n2; i += 256) p2[i] = 0.f;
-  const long long n4 = n >> 2;
-  float4* p4 = reinterpret_cast<float4*>(p);
-  const long long stride = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) p4[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) p[(n4 << 2) + threadIdx.x] = 0.f;
-}
-
-int zero_fill2(float* p, long long n, float* p2, int n2, hipStream_t st);
-int zero_fill(float* p, long long n, hipStream_t st) { return zero_fill2(p, n, nullptr, 0, st); }
-int zero_fill2(float* p, long long n, float* p2, int n2, hipStream_t st) {
-  PN_CHECK_ARG(p && n >= 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0, "zero_fill: null or unaligned buffer");
-  if (n == 0 && !p2) return PN_OK;
-  const long long blocks = cdivll(cdivll(n, 4), 256);
-  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks < 2048 ? blocks : 2048))), dim3(256), 0, st, p, n, p2, n2);
-  PN_CHECK_LAUNCH();
-  return PN_OK;
-}
-
 // tf.debugging.check_numerics (PointNet.py:199-288, `debugging: true`): *count += number of NaN / Inf elements of x
 __global__ __launch_bounds__(256) void count_nonfinite_kernel(const float* __restrict__ x, long long n, int* __restrict__ count, int h16) {
   int bad = 0;

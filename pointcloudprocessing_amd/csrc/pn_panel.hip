@@ -27,68 +27,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in registers (HIP's uint4 struct does not)
 
-// ---- weight preparation: fragment-ordered bf16 copies ------------------------------------------------------------------------
-//   Wf_hi[((cb * K/16 + ks) * 64 + lane) * 8 + j] = bf16(s_c * W[k][c]),   c = cb * 32 + (lane & 31),  k = ks * 16 + (lane >> 5) * 8 + j
-//   Wf_lo[...] = bf16(s_c * W[k][c] - hi)        s_c = -1 where sgn[c] < 0 (sgn may be gamma itself), else +1: the accumulators of the
-//   panel kernel then hold sgn * z and max(sgn * z) needs no multiply (a sign flip commutes with the rounding, so this is exact).
-struct Prep3Args {
-  const float* sgn[3];
-  const float* w[3];
-  __bf16* hi[3];
-  __bf16* lo[3];
-  int K[3], C[3];
-  unsigned* zero_p;
-  int zero_n;
-};
-__global__ __launch_bounds__(256) void weights_prep3_kernel(const Prep3Args a) {
-  if (blockIdx.x == 0 && blockIdx.y == 0 && a.zero_p)
-    for (int i = threadIdx.x; i < a.zero_n; i += 256) a.zero_p[i] = 0u;
-  const int z = blockIdx.y;
-  const float* __restrict__ w = a.w[z];
-  if (!w) return;
-  const int K = a.K[z], C = a.C[z], KS = K / 16;
-  const long long chunk = (long long)blockIdx.x * 256 + threadIdx.x;      // one 16-byte chunk (8 consecutive k of one channel)
-  if (chunk >= (long long)C * K / 8) return;
-  const int lane = (int)(chunk & 63);
-  const int ks = (int)((chunk >> 6) % KS), cb = (int)((chunk >> 6) / KS);
-  const int c = cb * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
-  const float sg = (a.sgn[z] && a.sgn[z][c] < 0.f) ? -1.f : 1.f;
-  bf16x8 h, l;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const float v = sg * w[(long long)(k0 + j) * C + c];
-    h[j] = (__bf16)v;
-    l[j] = (__bf16)(v - (float)h[j]);
-  }
-  *reinterpret_cast<bf16x8*>(a.hi[z] + chunk * 8) = h;
-  if (a.lo[z]) *reinterpret_cast<bf16x8*>(a.lo[z] + chunk * 8) = l;
-}
-int weights_prep3(const float* const* w, const float* const* sgn, const int* K, const int* C, void* const* hi, void* const* lo,
-                  unsigned* zero_p, int zero_n, hipStream_t st) {
-  Prep3Args a;
-  long long mx = 1;
-  for (int i = 0; i < 3; ++i) {
-    a.w[i] = w[i]; a.sgn[i] = sgn ? sgn[i] : nullptr; a.K[i] = K[i]; a.C[i] = C[i];
-    a.hi[i] = reinterpret_cast<__bf16*>(hi[i]); a.lo[i] = reinterpret_cast<__bf16*>(lo[i]);
-    PN_CHECK_ARG(!w[i] || (hi[i] && K[i] > 0 && K[i] % 16 == 0 && C[i] > 0 && C[i] % 32 == 0), "weights_prep3: bad arguments");
-    if (w[i] && (long long)K[i] * C[i] / 8 > mx) mx = (long long)K[i] * C[i] / 8;
-  }
-  a.zero_p = zero_p; a.zero_n = zero_n;
-  hipLaunchKernelGGL(weights_prep3_kernel, dim3((unsigned)cdivll(mx, 256), 3), dim3(256), 0, st, a);
-  PN_CHECK_LAUNCH();
-  return PN_OK;
-}
-int weights_prep(const float* w, const float* sgn, int K, int C, void* hi, void* lo, hipStream_t st) {
-  PN_CHECK_ARG(w && hi, "pn_weights_prep: null pointer");
-  PN_CHECK_ARG(K > 0 && K % 16 == 0 && C > 0 && C % 32 == 0, "pn_weights_prep: K must be a multiple of 16 and C of 32 (K=%d C=%d)", K, C);
-  const float* ws[3] = {w, nullptr, nullptr};
-  const float* sg[3] = {sgn, nullptr, nullptr};
-  const int Ks[3] = {K, 0, 0}, Cs[3] = {C, 0, 0};
-  void* his[3] = {hi, nullptr, nullptr};
-  void* los[3] = {lo, nullptr, nullptr};
-  return weights_prep3(ws, sg, Ks, Cs, his, los, nullptr, 0, st);
-}
-
 // ---- the panel kernel --------------------------------------------------------------------------------------------------------
 // Work split: every cloud is cut into `spc` (slots per cloud, panel_slots_per_cloud) contiguous runs of 64-row panels, one workgroup
 // per run, about one workgroup per CU in all.  A workgroup = 8 waves (two per SIMD, up to 256 VGPRs each).
@@ -147,23 +85,6 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
   const int tpc = (g.N + BM - 1) / BM;
   const int p_begin = (int)((long long)j * tpc / g.spc), p_end = (int)((long long)(j + 1) * tpc / g.spc);
   const long long cloud_row0 = (long long)cloud * g.N;
-
-  // ---- this wave's columns of the kernel: loaded once, resident for the whole run ----------------------------------------------
-  const u32x4* __restrict__ wfh = reinterpret_cast<const u32x4*>(g.wf_hi);
-  const u32x4* __restrict__ wfl = reinterpret_cast<const u32x4*>(g.wf_lo);
-  u32x4 bw[RB][KS];                                  // block q = i * NT + image (0 hi, 1 lo) of owned column block i
-  int cbs[CBW];
-#pragma unroll
-  for (int i = 0; i < CBW; ++i) cbs[i] = (cg * CBW + i) * 8 + wave;
-#pragma unroll
-  for (int q = 0; q < NBLK; ++q) {
-    const u32x4* __restrict__ src = ((q % NT) ? wfl : wfh) + (long long)cbs[q / NT] * KS * 64 + lane;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      if (q < RB) bw[q][ks] = src[ks * 64];
-      else Bl[wave][(q - RB) * KS + ks][lane] = src[ks * 64];      // read back by this wave only
-    }
-  }
 
   // ---- staging: thread <-> (row rin + 32 p, 8 consecutive k); BN + ReLU coefficients of its 8 columns --------------------------
   const int ch = tid % CH, rin = tid / CH;
@@ -237,7 +158,26 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
       }
     }
   };
+  // the first panel's rows are requested BEFORE the kernel fragments: loads return in issue order, so the conversion below waits for
+  // the rows only and runs (with its LDS writes) while the 96-128 fragment loads of this lane are still in flight
   issue(p_begin);
+  // ---- this wave's columns of the kernel: loaded once, resident for the whole run ----------------------------------------------
+  const u32x4* __restrict__ wfh = reinterpret_cast<const u32x4*>(g.wf_hi);
+  const u32x4* __restrict__ wfl = reinterpret_cast<const u32x4*>(g.wf_lo);
+  u32x4 bw[RB][KS];                                  // block q = i * NT + image (0 hi, 1 lo) of owned column block i
+  int cbs[CBW];
+#pragma unroll
+  for (int i = 0; i < CBW; ++i) cbs[i] = (cg * CBW + i) * 8 + wave;
+#pragma unroll
+  for (int q = 0; q < NBLK; ++q) {
+    const u32x4* __restrict__ src = ((q % NT) ? wfl : wfh) + (long long)cbs[q / NT] * KS * 64 + lane;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (q < RB) bw[q][ks] = src[ks * 64];
+      else Bl[wave][(q - RB) * KS + ks][lane] = src[ks * 64];      // read back by this wave only
+    }
+  }
+
   convert(p_begin, 0);
   __syncthreads();
 

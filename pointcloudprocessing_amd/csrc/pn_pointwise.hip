@@ -6,79 +6,36 @@
 namespace pn {
 
 // ------------------------------------------------------------------------------------------------------
-// PointCloudNormalization (reference: pointnet/PointNet.py:691-706).  One 1024-thread block per cloud:
-// pass 1 centroid (wave shuffle + LDS), pass 2 max radius, pass 3 write.  12 B/point in, 12 B/point out;
-// the cloud (<= a few MB) stays in L2 between passes.
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void normalize_kernel(const float* __restrict__ xyz, int N, float* __restrict__ out,
-                                                         float* __restrict__ centroid, float* __restrict__ scale) {
-  __shared__ float red[16][3];
-  __shared__ float bc[4];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* p = xyz + (long long)b * N * 3;
-  float sx = 0.f, sy = 0.f, sz = 0.f;
-  for (int i = tid; i < N; i += 1024) {
-    sx += p[3 * i]; sy += p[3 * i + 1]; sz += p[3 * i + 2];
-  }
-  sx = wave_sum(sx); sy = wave_sum(sy); sz = wave_sum(sz);
-  if (lane == 0) { red[wave][0] = sx; red[wave][1] = sy; red[wave][2] = sz; }
-  __syncthreads();
-  if (tid < 3) {
-    float s = 0.f;
-    for (int w = 0; w < 16; ++w) s += red[w][tid];
-    bc[tid] = s / (float)N;
-  }
-  __syncthreads();
-  const float cx = bc[0], cy = bc[1], cz = bc[2];
-  float md = 0.f;
-  for (int i = tid; i < N; i += 1024) {
-    const float dx = p[3 * i] - cx, dy = p[3 * i + 1] - cy, dz = p[3 * i + 2] - cz;
-    md = fmaxf(md, sqrtf(dx * dx + dy * dy + dz * dz));
-  }
-  md = wave_max(md);
-  __syncthreads();
-  if (lane == 0) red[wave][0] = md;
-  __syncthreads();
-  if (tid == 0) {
-    float m = 0.f;
-    for (int w = 0; w < 16; ++w) m = fmaxf(m, red[w][0]);
-    bc[3] = fmaxf(m, 1e-7f);
-  }
-  __syncthreads();
-  const float sc = bc[3];
-  float* o = out + (long long)b * N * 3;
-  for (int i = tid; i < N; i += 1024) {
-    o[3 * i] = (p[3 * i] - cx) / sc;
-    o[3 * i + 1] = (p[3 * i + 1] - cy) / sc;
-    o[3 * i + 2] = (p[3 * i + 2] - cz) / sc;
-  }
-  if (tid == 0) {
-    if (centroid) { centroid[3 * b] = cx; centroid[3 * b + 1] = cy; centroid[3 * b + 2] = cz; }
-    if (scale) scale[b] = sc;
-  }
-}
-
-int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st) {
-  PN_CHECK_ARG(xyz && out, "pn_normalize: null pointer");
-  PN_CHECK_ARG(B > 0 && N > 0, "pn_normalize: B and N must be positive (B=%d N=%d)", B, N);
-  hipLaunchKernelGGL(normalize_kernel, dim3(B), dim3(1024), 0, st, xyz, N, out, centroid, scale);
-  PN_CHECK_LAUNCH();
-  return PN_OK;
-}
-
-// ------------------------------------------------------------------------------------------------------
 // ConvLayer with Cin = 3 (PointNet.py:406, 120): lane <-> output channel, a wave walks rows; the 3 inputs
 // of a row are wave-uniform loads.  Tile = 128 rows of one cloud, 4 waves x 32 rows.  C = 64 * CG.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void conv3_fwd_kernel(const float* __restrict__ x3, const float* __restrict__ w,
                                                         long long wcs, int N, int C, int tiles_per_cloud,
-                                                        float* __restrict__ z, float* __restrict__ part, int store16) {
+                                                        float* __restrict__ z, float* __restrict__ part, int store16,
+                                                        const float* __restrict__ Rm, float* __restrict__ weff_out,
+                                                        float* __restrict__ r_copy) {
   __shared__ float red[4][2][64];
   const int bx = blockIdx.x, cloud = bx / tiles_per_cloud, tin = bx - cloud * tiles_per_cloud;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int c = blockIdx.y * 64 + lane;
   const float* wb = w + (long long)cloud * wcs;
-  const float w0 = wb[c], w1 = wb[C + c], w2 = wb[2 * C + c];
+  float w0 = wb[c], w1 = wb[C + c], w2 = wb[2 * C + c];
+  if (Rm) {
+    // the input transform folded into the kernel: Weff[b] (3, C) = R[b] (3, 3) @ W (3, C) -- tf.matmul(pc, R) then the layer,
+    // (pc . R) . W = pc . (R . W); the cloud's first tile also leaves Weff (and a copy of R: the model's third output) in memory
+    const float* r = Rm + (long long)cloud * 9;
+    const float e0 = fmaf(r[2], w2, fmaf(r[1], w1, r[0] * w0));
+    const float e1 = fmaf(r[5], w2, fmaf(r[4], w1, r[3] * w0));
+    const float e2 = fmaf(r[8], w2, fmaf(r[7], w1, r[6] * w0));
+    w0 = e0; w1 = e1; w2 = e2;
+    if (tin == 0 && wave == 0) {
+      if (weff_out) {
+        float* o = weff_out + (long long)cloud * 3 * C;
+        o[c] = w0; o[C + c] = w1; o[2 * C + c] = w2;
+      }
+      if (r_copy && blockIdx.y == 0 && lane < 9) r_copy[(long long)cloud * 9 + lane] = r[lane];
+    }
+  }
   // readfirstlane: the wave index is uniform, but only this tells the compiler -- the three coordinates of a row then arrive through
   // scalar loads instead of three vector loads of one address each
   const int r0 = tin * 128 + __builtin_amdgcn_readfirstlane(wave) * 32;
@@ -108,12 +65,14 @@ __global__ __launch_bounds__(256) void conv3_fwd_kernel(const float* __restrict_
   }
 }
 
-int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st, int store16) {
+int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st, int store16,
+              const float* Rm, float* weff_out, float* r_copy) {
   PN_CHECK_ARG(x3 && w, "pn_conv3_fwd: null pointer");
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv3_fwd: B and N must be positive");
   PN_CHECK_ARG(C >= 64 && C % 64 == 0, "pn_conv3_fwd: C must be a multiple of 64 (C=%d)", C);
   const int tpc = cdiv(N, 128);
-  hipLaunchKernelGGL(conv3_fwd_kernel, dim3(B * tpc, C / 64), dim3(256), 0, st, x3, w, wcs, N, C, tpc, z, part, store16);
+  hipLaunchKernelGGL(conv3_fwd_kernel, dim3(B * tpc, C / 64), dim3(256), 0, st, x3, w, wcs, N, C, tpc, z, part, store16, Rm, weff_out,
+                     r_copy);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -2,6 +2,7 @@
 // fused with keras SparseCategoricalCrossentropy (pointnet_train.py:338) and its gradient.  Cseg is small
 // (12 in the reference configs), so this is vector-ALU work: K*Cseg FMAs per point against 4*K bytes read.
 #include "pn_common.h"
+#include "pn_loss_bodies.h"
 
 namespace pn {
 
@@ -237,26 +238,37 @@ __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, co
   float S1 = 0.f, S2 = 0.f;
   act_switch(x.h16, [&](auto hx) { act_switch(store16, [&](auto hs) {
   constexpr bool HX = decltype(hx)::value, HS = decltype(hs)::value;
-  for (int r = r0; r < r1; ++r) {
-    const long long row = (long long)cloud * N + r;
-    const float z = act_ld<HX>(x.s1, row * x.ld + k);
-    const float pre = fmaf(ca, z, cc);
-    const float a = clamp_lo(pre, lo);
-    // the row is the same for every lane of a wave (stream = threadIdx.x >> 7), but only readfirstlane lets the compiler see it:
-    // the 12 gradient values then come through scalar loads instead of 12 vector loads of one address per row
-    const float* dl = dlogits + ((long long)cloud * N + __builtin_amdgcn_readfirstlane(r)) * C;
-    float d = 0.f;
+  // 8 rows of the layer input in flight per thread (a row at a time the loop ran at the latency of one load per row: 63 us at
+  // B = 32, N = 2048 for 37 MB of traffic)
+  for (int rb = r0; rb < r1; rb += 8) {
+    float zz[8];
 #pragma unroll
-    for (int c = 0; c < SEG_CM; ++c)
-      if (c < C) {
-        const float g = dl[c];
-        d = fmaf(g, wk[c], d);
-        gw[c] = fmaf(a, g, gw[c]);
+    for (int u = 0; u < 8; ++u) zz[u] = act_ld<HX>(x.s1, ((long long)cloud * N + min(rb + u, r1 - 1)) * x.ld + k);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int r = rb + u;
+      if (r < r1) {                 // wave-uniform
+        const long long row = (long long)cloud * N + r;
+        const float z = zz[u];
+        const float pre = fmaf(ca, z, cc);
+        const float a = clamp_lo(pre, lo);
+        // the row is the same for every lane of a wave (stream = threadIdx.x >> 7), but only readfirstlane lets the compiler see it:
+        // the 12 gradient values then come through scalar loads instead of 12 vector loads of one address per row
+        const float* dl = dlogits + ((long long)cloud * N + __builtin_amdgcn_readfirstlane(r)) * C;
+        float d = 0.f;
+#pragma unroll
+        for (int c = 0; c < SEG_CM; ++c)
+          if (c < C) {
+            const float g = dl[c];
+            d = fmaf(g, wk[c], d);
+            gw[c] = fmaf(a, g, gw[c]);
+          }
+        if (!(pre > lo)) d = 0.f;   // relu'(pre) with lo = 0; lo = -inf keeps everything
+        act_st<HS>(dyhat, row * K + k, d);
+        S1 += d;
+        S2 = fmaf(d, z, S2);
       }
-    if (!(pre > lo)) d = 0.f;   // relu'(pre) with lo = 0; lo = -inf keeps everything
-    act_st<HS>(dyhat, row * K + k, d);
-    S1 += d;
-    S2 = fmaf(d, z, S2);
+    }
   }
   }); });
   if (stream == 1) {
@@ -286,19 +298,37 @@ __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, co
 __global__ __launch_bounds__(1024) void sum_partials_kernel(const float* __restrict__ part, int n, int stride, int elems,
                                                             float* __restrict__ out) {
   __shared__ double wsum[16];
-  const int e = blockIdx.x;
-  if (e >= elems) return;
-  double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 1024) acc += (double)part[(long long)i * stride + e];
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = acc;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double t = 0.0;
-    for (int w = 0; w < 16; ++w) t += wsum[w];
-    out[e] = (float)t;
-  }
+  if ((int)blockIdx.x < elems) sum_partials_body(part, n, stride, blockIdx.x, out, wsum);
+}
+
+// The tail of a forward pass with fused losses, one launch: the classification softmax + loss (workgroup 0: softmax_xent_rows), the
+// segmentation loss / accuracy sums over the output kernel's per-block partials (the next n_sum workgroups) and the rotation loss
+// (one more workgroup, when there is a target).
+struct LossTailArgs {
+  const float* logits; int R, C; const int* labels; float grad_scale; float *probs, *dlogits, *loss_sum, *correct;
+  const float* part; int n, stride, n_sum; float* sum_out;
+  const float *Rm, *T; int n_mse; float* mse_out;
+};
+__global__ __launch_bounds__(1024) void loss_tail_kernel(const LossTailArgs a) {
+  __shared__ float rl[32], rc[32];
+  __shared__ double wsum[16];
+  int bx = blockIdx.x;
+  if (bx == 0) { softmax_xent_rows_body(a.logits, a.R, a.C, a.labels, a.grad_scale, a.probs, a.dlogits, a.loss_sum, a.correct, rl, rc); return; }
+  bx -= 1;
+  if (bx < a.n_sum) { sum_partials_body(a.part, a.n, a.stride, bx, a.sum_out, wsum); return; }
+  bx -= a.n_sum;
+  if (bx == 0 && a.mse_out) mse_body(a.Rm, a.T, a.n_mse, 0.f, nullptr, a.mse_out, rl);
+}
+int loss_tail(const float* logits, int R, int C, const int* labels, float grad_scale, float* probs, float* dlogits, float* loss_sum,
+              float* correct, const float* part, int n, int stride, int n_sum, float* sum_out, const float* Rm, const float* T, int n_mse,
+              float* mse_out, hipStream_t st) {
+  PN_CHECK_ARG(logits && probs && R > 0 && C > 0, "loss_tail: bad arguments");
+  PN_CHECK_ARG(n_sum == 0 || (part && sum_out && n > 0), "loss_tail: bad partial-sum arguments");
+  PN_CHECK_ARG(!mse_out || (Rm && T && n_mse > 0), "loss_tail: bad rotation-loss arguments");
+  LossTailArgs a{logits, R, C, labels, grad_scale, probs, dlogits, loss_sum, correct, part, n, stride, n_sum, sum_out, Rm, T, n_mse, mse_out};
+  hipLaunchKernelGGL(loss_tail_kernel, dim3(1 + n_sum + (mse_out ? 1 : 0)), dim3(1024), 0, st, a);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
 }
 
 int seg_out_fwd(const pn_operand* x, const float* w, const float* bias, long long M, int K, int C, const int* labels,

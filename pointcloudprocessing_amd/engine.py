@@ -81,13 +81,13 @@ class TrainStep:
     # -- pieces ---------------------------------------------------------------------------------------------
     def _fwd_bwd(self, phase: int = 0):
         rate = self.model._dropout_rate
-        if rate > 0 and self.on_gpu:        # one native launch; the step counter lives on the device, so graph replays draw fresh masks
-            check(lib().pn_dropout_masks(ptr(self.keep[0]), self.keep[0].numel(), ptr(self.keep[1]), self.keep[1].numel(), rate,
-                                         self._mask_seed, ptr(self._mask_step), current_stream()), "pn_dropout_masks")
+        # the dropout masks are drawn by the forward pass's first launch (pn_model_io.dropout_step): the step counter lives on the
+        # device, so graph replays draw fresh masks
         self.model._aux_stream = self.aux_stream
         try:
             self.model.fused_loss_step(self.pc, self.y_cls, self.y_seg, self.se3, self.lw, keep=self.keep if rate > 0 else None,
-                                       backward_phase=phase)
+                                       backward_phase=phase,
+                                       dropout_rng=(self._mask_seed, self._mask_step) if (rate > 0 and self.on_gpu) else None)
         finally:
             self.model._aux_stream = None
 
@@ -144,6 +144,14 @@ class TrainStep:
         # (c10::DistBackendError "operation not permitted when stream is capturing" -- seen 2 times in 14 data-parallel rehearsals).
         try:
             torch.cuda.synchronize()
+            if self.reduce:
+                # The collectives of the eager warm-up steps are complete (synchronize above), but RCCL's watchdog thread retires their
+                # Work objects on its own clock (a sweep every 100 ms) and, until it has, keeps calling hipEventQuery on their end
+                # events.  An end event recorded on THIS stream (synchronous collectives run on the current stream) is refused by HIP
+                # with hipErrorCapturedEvent once the stream is capturing -- even though the record itself preceded the capture --
+                # and the watchdog aborts the process (seen once in ~10 runs of the world-size-1 RCCL test).  Let it sweep first.
+                import time
+                time.sleep(0.5)
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, stream=self._capture_stream, capture_error_mode="thread_local"):
                 self._fwd_bwd(1 if self.split else 0)

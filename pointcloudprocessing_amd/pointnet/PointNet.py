@@ -653,6 +653,11 @@ class PointNet(torch.nn.Module):
                 keep = ((torch.rand(B, 512, device=dev) >= self._dropout_rate).to(torch.uint8),
                         (torch.rand(B, 256, device=dev) >= self._dropout_rate).to(torch.uint8))
             io.keep1, io.keep2 = keep[0].data_ptr(), keep[1].data_ptr()
+            rng = None if fused is None else fused.get("dropout_rng")
+            if rng is not None:        # (seed, device uint32 step counter): the forward's first launch draws the masks into `keep`
+                io.dropout_seed, io.dropout_step = int(rng[0]), rng[1].data_ptr()
+        if fused is not None and fused.get("zero_grads_in_forward"):
+            io.zero_grads_in_forward = 1
         if fused is not None and fused.get("labels_cls") is not None:
             _lib.require_gpu_tensor(fused["labels_cls"], "labels_cls", torch.int32)
             _lib.require_gpu_tensor(fused["labels_seg"], "labels_seg", torch.int32)
@@ -763,10 +768,13 @@ class PointNet(torch.nn.Module):
                 return int(s["offset"])
         raise PointNetHipError("parameter layout has no feature_transform / mlp_2_1 slot")
 
-    def fused_loss_step(self, pc, labels_cls, labels_seg, se3, loss_weights, keep=None, backward_phase: int = 0):
+    def fused_loss_step(self, pc, labels_cls, labels_seg, se3, loss_weights, keep=None, backward_phase: int = 0, dropout_rng=None):
         """forward + the three keras losses of pointnet_train.py:334-345 + backward, all native.  Leaves the
-        gradients in ``grads_flat`` and the loss / metric sums in ``self.scalars`` (see pn_model_io)."""
-        fused = dict(labels_cls=labels_cls, labels_seg=labels_seg.reshape(-1), se3=se3, loss_weights=loss_weights, keep=keep)
+        gradients in ``grads_flat`` and the loss / metric sums in ``self.scalars`` (see pn_model_io).
+        ``keep``: the two dropout keep masks (uint8 tensors) -- inputs, or, with ``dropout_rng=(seed, step_counter_tensor)``, buffers
+        the forward pass fills from its counter-based generator (pn_model_io.dropout_step)."""
+        fused = dict(labels_cls=labels_cls, labels_seg=labels_seg.reshape(-1), se3=se3, loss_weights=loss_weights, keep=keep,
+                     dropout_rng=dropout_rng, zero_grads_in_forward=True)      # the backward pass follows: one clearing launch less
         outs = self._run_forward(pc, True, fused)
         self._run_backward(None, None, None, backward_phase)
         return outs

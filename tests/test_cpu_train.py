@@ -299,7 +299,7 @@ SCHEDULE_SCRIPT = textwrap.dedent("""
             self.calls = []
         def grad_bucket_boundary(self):
             return CUT
-        def fused_loss_step(self, pc, y_cls, y_seg, se3, lw, keep=None, backward_phase=0):
+        def fused_loss_step(self, pc, y_cls, y_seg, se3, lw, keep=None, backward_phase=0, dropout_rng=None):
             self.calls.append(("fwd+bwd", backward_phase))
             self.grads_flat.fill_(float("nan"))            # anything the schedule forgets to produce or reduce stays visible
             self.grads_flat[CUT:] = base[CUT:] * (rank + 1)

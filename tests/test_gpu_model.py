@@ -287,3 +287,38 @@ def test_free_standing_dense_layer_and_tnet(dev):
             gmax = torch.relu(gmax @ l.kernel.double().cpu() * inv)
         ref = (gmax @ t.w.double().cpu() + t.b.double().cpu().reshape(-1)).reshape(2, K, K)
         assert torch.allclose(R2, ref, rtol=1e-3, atol=1e-4), float((R2 - ref).abs().max())
+
+
+def test_forward_prologue_draws_masks_and_clears_gradients(dev):
+    """pn_model_io.dropout_step / zero_grads_in_forward: the forward pass's first launch draws the masks pn_dropout_masks would
+    (counter increment included) and clears the gradient buffer; a step run that way equals a step with those masks as inputs."""
+    from pointcloudprocessing_amd import _lib as L
+    from pointcloudprocessing_amd.pointnet.PointNet import PointNet
+    B, N, seed = 5, 300, 0x1234567811
+    g = torch.Generator().manual_seed(77)
+    pc = (torch.rand(B, N, 3, generator=g) * 10).to(dev)
+    y_cls = torch.randint(0, 23, (B,), generator=g, dtype=torch.int32).to(dev)
+    y_seg = torch.randint(0, 12, (B, N), generator=g, dtype=torch.int32).to(dev)
+    se3 = torch.eye(3).expand(B, 3, 3).contiguous().to(dev)
+    # what pn_dropout_masks writes for (seed, step 5)
+    step = torch.full((1,), 5, dtype=torch.int32, device=dev)
+    k1 = torch.empty(B, 512, dtype=torch.uint8, device=dev); k2 = torch.empty(B, 256, dtype=torch.uint8, device=dev)
+    L.check(L.lib().pn_dropout_masks(L.ptr(k1), k1.numel(), L.ptr(k2), k2.numel(), 0.3, seed, L.ptr(step), L.current_stream()), "pn_dropout_masks")
+    assert int(step.item()) == 6 and 0.6 < float(k1.float().mean()) < 0.8
+    params = O.init_params(23, 12, seed=3, randomize_bn=True)
+    res = []
+    for mode in ("inputs", "drawn"):
+        m = PointNet(23, 12, 0.3, 42, precision="bf16", device=dev)
+        m.set_weights(params)
+        m.grads_flat.fill_(1e30)                       # stale gradients: the forward pass must clear them
+        if mode == "inputs":
+            m.fused_loss_step(pc, y_cls, y_seg, se3, (1.0, 1.0, 1.0), keep=(k1, k2))
+        else:
+            step2 = torch.full((1,), 5, dtype=torch.int32, device=dev)
+            b1 = torch.zeros_like(k1); b2 = torch.zeros_like(k2)
+            m.fused_loss_step(pc, y_cls, y_seg, se3, (1.0, 1.0, 1.0), keep=(b1, b2), dropout_rng=(seed, step2))
+            assert torch.equal(b1, k1) and torch.equal(b2, k2) and int(step2.item()) == 6
+        torch.cuda.synchronize()
+        res.append((m.grads_flat.clone(), m.scalars.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert float(res[0][0].abs().max()) < 1e6        # nothing of the stale fill survived

@@ -20,9 +20,10 @@ for B, N in (((32, 1024), (32, 4096)) if ABLATE else ((32, 1024), (32, 4096), (8
     w = (torch.randn(K, C_, generator=g) / 11).to(dev)
     gamma = torch.randn(C_, generator=g).to(dev)
     sc, sh = (torch.rand(K, generator=g) + 0.5).to(dev), (torch.randn(K, generator=g) * 0.3).to(dev)
-    op = _lib.operand(x, ca=sc, cc=sh, relu=True)
     wf = ops.weights_prep(w, gamma)
-    for prec in ((1,) if ABLATE else (1, 3)):
+    for prec, h16 in (((1, 0),) if ABLATE else ((1, 1), (1, 0), (3, 0))):     # h16: the activations are stored as bf16 (the step's 'bf16' mode)
+      op = _lib.operand(x.to(torch.bfloat16) if h16 else x, ca=sc, cc=sh, relu=True)
+      if True:
         for rows in (64,):
             for stats, dbg in ([(True, d) for d in (0, 1, 4, 8, 9, 13)] if ABLATE else [(True, 0), (False, 0)]):
                 os.environ["PN_PANEL_DBG"] = str(dbg)
@@ -42,6 +43,6 @@ for B, N in (((32, 1024), (32, 4096)) if ABLATE else ((32, 1024), (32, 4096), (8
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / 50
                 tf = 2.0 * K * C_ * B * N / (us * 1e-6) / 1e12
-                print(json.dumps({"B": B, "N": N, "prec": prec, "panel_rows": rows, "stats": stats, "dbg": dbg, "tiles": T, "us": round(us, 2),
+                print(json.dumps({"B": B, "N": N, "prec": prec, "bf16_source": h16, "panel_rows": rows, "stats": stats, "dbg": dbg, "tiles": T, "us": round(us, 2),
                                   "TFLOPs": round(tf, 1), "frac_of_2.5PF": round(tf / 2500 / (3 if prec == 3 else 1), 4)}), flush=True)
 os.environ.pop("PN_PANEL_DBG", None)
