@@ -54,6 +54,7 @@ struct GemmArgs {
   float* pmax;              // MAX [tiles][C]
   int* pidx;                // MAX [tiles][C]
   int store16;              // STORE: out, addend and zmask are bf16 arrays (PN_STORE_BF16)
+  int ncol;                 // FWD/BWD: column tiles per row tile (the grid is 1-D: row tiles x ncol, see gemm_kernel)
   int colsum;               // WGRAD: also emit sum_rows a[row][i] as an extra row after each slab (slab stride Ci*C + Ci)
   int dbg;                  // PN_GEMM_DBG ablations (tools/gemm_probe.py): 1 no output stores, 2 no statistics, 4 no A loads, 8 no W loads
 };
@@ -484,16 +485,32 @@ __global__ __launch_bounds__(256) void wgrad_batch_kernel(const WgradBatch wb) {
   __shared__ __attribute__((aligned(16))) unsigned char lds_raw[GemmLds<BM, BN, NS>::BYTES];
   int j = 0;
   while (j + 1 < wb.n && (int)blockIdx.x >= wb.blk_end[j]) ++j;      // block-uniform
-  const int local = (int)blockIdx.x - (j ? wb.blk_end[j - 1] : 0);
+  const int first = j ? wb.blk_end[j - 1] : 0;
+  const int local = (int)blockIdx.x - first;
   const int nslab = wb.nslab[j], ny = wb.ny[j];
-  const int bx = local % nslab, rest = local / nslab;
-  wgrad_tile<BM, BN, NS, false, B2>(wb.g[j], bx, rest % ny, rest / ny, lds_raw);
+  const int n_out = (wb.blk_end[j] - first) / nslab;          // output tiles per slab
+  // Block -> (slab, output tile).  The n_out tiles of a slab read the same rows of both operands; workgroups are dealt round-robin
+  // over the 8 XCDs (observed, never relied on for correctness: MI355X_MICROARCH.md, Workgroup dispatch), so inside a group of 8
+  // slabs the block id walks tile-major with the slab in its low 3 bits: one slab's tiles land on one XCD, next to each other in
+  // time, and its re-reads are served by that XCD's L2 instead of the fabric.  Slabs beyond the last full group: slab-fastest.
+  int bx, tile;
+  const int full = (nslab / 8) * 8 * n_out;
+  if (local < full) {
+    const int grp = local / (8 * n_out), r = local - grp * 8 * n_out;
+    tile = r >> 3;
+    bx = grp * 8 + (r & 7);
+  } else {
+    const int l2 = local - full, rem = nslab - (nslab / 8) * 8;
+    bx = (nslab / 8) * 8 + l2 % rem;
+    tile = l2 / rem;
+  }
+  wgrad_tile<BM, BN, NS, false, B2>(wb.g[j], bx, tile % ny, tile / ny, lds_raw);
 }
 
 // ---- the kernel ----------------------------------------------------------------------------------------
 // 256 threads = 4 waves arranged 2 (rows) x 2 (cols); wave tile (BM/2) x (BN/2) = MT x NT MFMA tiles.
 template <int BM, int BN, int NS, int MODE, bool A2, int EPI, bool ADD, bool MASK, bool AH, bool S16>
-__device__ __forceinline__ void rows_tile_t(const GemmArgs& g, unsigned char* lds_raw) {
+__device__ __forceinline__ void rows_tile_t(const GemmArgs& g, const int bx, const int by, unsigned char* lds_raw) {
   constexpr int BK = (NS == 3) ? 32 : 64;
   constexpr int PITCH = Geo<BK>::PITCH;
   constexpr int MT = BM / 64, NT = BN / 64;
@@ -516,13 +533,12 @@ __device__ __forceinline__ void rows_tile_t(const GemmArgs& g, unsigned char* ld
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[m][n][e] = 0.f;
 
-  const int bx = blockIdx.x;
   const int cloud = bx / g.tiles_per_cloud, tin = bx - cloud * g.tiles_per_cloud;
 
   const int row_in_cloud0 = tin * BM;
   const int nrows = min(BM, g.N - row_in_cloud0);
   const long long row0 = (long long)cloud * g.N + row_in_cloud0;
-  const int col0 = blockIdx.y * BN;
+  const int col0 = by * BN;
   const long long wbase = (long long)cloud * g.w_cloud_stride;
   pn_operand wop;
   wop.s1 = g.w; wop.s2 = nullptr; wop.ca = nullptr; wop.cb = nullptr; wop.cc = nullptr;
@@ -671,13 +687,31 @@ __global__ __launch_bounds__(256, (MODE == MODE_FWD && EPI == EPI_STORE) ? 2 : 1
   if constexpr (MODE == MODE_WGRAD) {
     wgrad_tile<BM, BN, NS, A2, B2>(g, blockIdx.x, blockIdx.y, blockIdx.z, lds_raw);
   } else {
+    // Block -> (row tile, column tile), 1-D grid of n_row * ncol.  The ncol column tiles of a row tile read the same activation rows;
+    // workgroups are dealt round-robin over the 8 XCDs (observed, for speed only), so inside a group of 8 row tiles the id walks
+    // column-tile-major with the row tile in its low 3 bits: a row tile's column tiles run on one XCD one after the other and the
+    // re-reads of its rows hit that XCD's L2 (with grid (row, col) they were n_row dispatches apart, on any XCD)
+    int bx = blockIdx.x, by = 0;
+    const int ncol = g.ncol;
+    if (ncol > 1) {
+      const int lin = blockIdx.x, nrow = (int)gridDim.x / ncol, full = (nrow / 8) * 8 * ncol;
+      if (lin < full) {
+        const int grp = lin / (8 * ncol), r = lin - grp * 8 * ncol;
+        by = r >> 3;
+        bx = grp * 8 + (r & 7);
+      } else {
+        const int l2 = lin - full, rem = nrow - (nrow / 8) * 8;
+        bx = (nrow / 8) * 8 + l2 % rem;
+        by = l2 / rem;
+      }
+    }
     // the storage types of the operand and of the epilogue's tensors are block-uniform: one switch, outside every loop
     if (g.a.h16) {
-      if (EPI == EPI_STORE && g.store16) rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, true, EPI == EPI_STORE>(g, lds_raw);
-      else rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, true, false>(g, lds_raw);
+      if (EPI == EPI_STORE && g.store16) rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, true, EPI == EPI_STORE>(g, bx, by, lds_raw);
+      else rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, true, false>(g, bx, by, lds_raw);
     } else {
-      if (EPI == EPI_STORE && g.store16) rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, false, EPI == EPI_STORE>(g, lds_raw);
-      else rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, false, false>(g, lds_raw);
+      if (EPI == EPI_STORE && g.store16) rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, false, EPI == EPI_STORE>(g, bx, by, lds_raw);
+      else rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, false, false>(g, bx, by, lds_raw);
     }
   }
 }
@@ -703,22 +737,26 @@ static int check_operand(const pn_operand* o, const char* name) {
 }
 
 template <int MODE, bool A2, int EPI, bool ADD = false, bool MASK = false>
-static int dispatch_rows(const GemmArgs& g, int prec, hipStream_t st) {
+static int dispatch_rows(const GemmArgs& g_in, int prec, hipStream_t st) {
+  GemmArgs g = g_in;
   static const bool narrow = getenv("PN_GEMM_NARROW") != nullptr;   // experiment: 128x64 tiles everywhere (2x the blocks)
   const bool wide = (g.C % 128 == 0) && !narrow;
   if (EPI == EPI_MAX) {
-    dim3 grid(g.B * g.tiles_per_cloud, cdiv(g.C, 128));
+    g.ncol = cdiv(g.C, 128);
+    dim3 grid(g.B * g.tiles_per_cloud * g.ncol);
     if (prec == PN_PREC_BF16X3) return launch<128, 128, 3, MODE, A2, false, EPI>(g, grid, st);
     return launch<128, 128, 1, MODE, A2, false, EPI>(g, grid, st);
   }
   // a handful of row tiles (the Gram-sized products of the max-pool backward: 128 rows): 64-wide column tiles double the workgroups
   const bool few = (long long)g.B * g.tiles_per_cloud * (g.C / 128) < 64;
   if (wide && !few) {
-    dim3 grid(g.B * g.tiles_per_cloud, g.C / 128);
+    g.ncol = g.C / 128;
+    dim3 grid(g.B * g.tiles_per_cloud * g.ncol);
     if (prec == PN_PREC_BF16X3) return launch<128, 128, 3, MODE, A2, false, EPI, ADD, MASK>(g, grid, st);
     return launch<128, 128, 1, MODE, A2, false, EPI, ADD, MASK>(g, grid, st);
   }
-  dim3 grid(g.B * g.tiles_per_cloud, cdiv(g.C, 64));
+  g.ncol = cdiv(g.C, 64);
+  dim3 grid(g.B * g.tiles_per_cloud * g.ncol);
   if (prec == PN_PREC_BF16X3) return launch<128, 64, 3, MODE, A2, false, EPI, ADD, MASK>(g, grid, st);
   return launch<128, 64, 1, MODE, A2, false, EPI, ADD, MASK>(g, grid, st);
 }

@@ -158,9 +158,6 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
       }
     }
   };
-  // the first panel's rows are requested BEFORE the kernel fragments: loads return in issue order, so the conversion below waits for
-  // the rows only and runs (with its LDS writes) while the 96-128 fragment loads of this lane are still in flight
-  issue(p_begin);
   // ---- this wave's columns of the kernel: loaded once, resident for the whole run ----------------------------------------------
   const u32x4* __restrict__ wfh = reinterpret_cast<const u32x4*>(g.wf_hi);
   const u32x4* __restrict__ wfl = reinterpret_cast<const u32x4*>(g.wf_lo);
@@ -178,6 +175,7 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
     }
   }
 
+  issue(p_begin);
   convert(p_begin, 0);
   __syncthreads();
 

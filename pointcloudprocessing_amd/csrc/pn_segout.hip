@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, co
                                                           float* __restrict__ wslab, int store16) {
   constexpr int K = 128;
   __shared__ float red[128][2 + SEG_CM];
-  __shared__ float out_s[128 * SEG_CM];
+  __shared__ __attribute__((aligned(16))) float out_s[128 * SEG_CM];
   const int bx = blockIdx.x, cloud = bx / tiles_per_cloud, tin = bx - cloud * tiles_per_cloud;
   const int k = threadIdx.x & 127, stream = threadIdx.x >> 7;
   float wk[SEG_CM], gw[SEG_CM];
@@ -236,6 +236,17 @@ __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, co
   const float ca = x.ca ? x.ca[k] : 1.f, cc = x.cc ? x.cc[k] : 0.f, lo = x.lo;
   const int r0 = tin * 128 + stream * 64, r1 = min(N, r0 + 64);
   float S1 = 0.f, S2 = 0.f;
+  // the tile's rows of d(logits) (128 x C floats, contiguous) go through LDS once, coalesced: every lane of a wave needs the same C
+  // values per row, and fetching them row by row through scalar loads cost one memory round trip per row
+  {
+    const long long gbase = ((long long)cloud * N + tin * 128) * C;
+    const int nvalid = (min(N, tin * 128 + 128) - tin * 128) * C;
+    // LDS rows are SEG_CM floats apart (zero padded): a row is then four 16-byte broadcast reads whatever C is
+    for (int i = threadIdx.x; i < 128 * SEG_CM; i += 256) out_s[i] = 0.f;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nvalid; i += 256) out_s[(i / C) * SEG_CM + (i % C)] = dlogits[gbase + i];
+    __syncthreads();
+  }
   act_switch(x.h16, [&](auto hx) { act_switch(store16, [&](auto hs) {
   constexpr bool HX = decltype(hx)::value, HS = decltype(hs)::value;
   // 8 rows of the layer input in flight per thread (a row at a time the loop ran at the latency of one load per row: 63 us at
@@ -252,17 +263,19 @@ __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, co
         const float z = zz[u];
         const float pre = fmaf(ca, z, cc);
         const float a = clamp_lo(pre, lo);
-        // the row is the same for every lane of a wave (stream = threadIdx.x >> 7), but only readfirstlane lets the compiler see it:
-        // the 12 gradient values then come through scalar loads instead of 12 vector loads of one address per row
-        const float* dl = dlogits + ((long long)cloud * N + __builtin_amdgcn_readfirstlane(r)) * C;
+        const float4* dl4 = reinterpret_cast<const float4*>(out_s + (r - tin * 128) * SEG_CM);      // LDS broadcast reads
+        float gv[SEG_CM];
+#pragma unroll
+        for (int q = 0; q < SEG_CM / 4; ++q) {
+          const float4 t = dl4[q];
+          gv[4 * q] = t.x; gv[4 * q + 1] = t.y; gv[4 * q + 2] = t.z; gv[4 * q + 3] = t.w;
+        }
         float d = 0.f;
 #pragma unroll
-        for (int c = 0; c < SEG_CM; ++c)
-          if (c < C) {
-            const float g = dl[c];
-            d = fmaf(g, wk[c], d);
-            gw[c] = fmaf(a, g, gw[c]);
-          }
+        for (int c = 0; c < SEG_CM; ++c) {       // classes >= C: zero gradient, zero weight
+          d = fmaf(gv[c], wk[c], d);
+          gw[c] = fmaf(a, gv[c], gw[c]);
+        }
         if (!(pre > lo)) d = 0.f;   // relu'(pre) with lo = 0; lo = -inf keeps everything
         act_st<HS>(dyhat, row * K + k, d);
         S1 += d;
@@ -271,6 +284,7 @@ __global__ __launch_bounds__(256) void seg_out_bwd_kernel(const pn_operand x, co
     }
   }
   }); });
+  __syncthreads();                 // out_s (the d(logits) tile) is reused for the weight-gradient slab below
   if (stream == 1) {
     red[k][0] = S1; red[k][1] = S2;
 #pragma unroll
