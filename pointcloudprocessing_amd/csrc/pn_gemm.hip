@@ -23,7 +23,6 @@
 #include <vector>
 #include "pn_common.h"
 #include "pn_internal.h"
-#include "pn_bnfold.h"
 
 namespace pn {
 
@@ -56,7 +55,6 @@ struct GemmArgs {
   int* pidx;                // MAX [tiles][C]
   int store16;              // STORE: out, addend and zmask are bf16 arrays (PN_STORE_BF16)
   int ncol;                 // FWD/BWD: column tiles per row tile (the grid is 1-D: row tiles x ncol, see gemm_kernel)
-  BnFin fin;                // FWD/BWD: kind != 0: the finaliser of operand a's coefficients runs at the head of this launch
   int colsum;               // WGRAD: also emit sum_rows a[row][i] as an extra row after each slab (slab stride Ci*C + Ci)
   int dbg;                  // PN_GEMM_DBG ablations (tools/gemm_probe.py): 1 no output stores, 2 no statistics, 4 no A loads, 8 no W loads
 };
@@ -127,24 +125,15 @@ struct NatStage {
         if (HAS2) asm volatile("" : "+v"(y[p][q].x), "+v"(y[p][q].y), "+v"(y[p][q].z), "+v"(y[p][q].w));
       }
   }
-  // vol: the coefficients were written by other workgroups of THIS launch (pn_bnfold.h): read them past the caches
   template <int NS>
   __device__ __forceinline__ void finish(__bf16* __restrict__ Thi, __bf16* __restrict__ Tlo, const pn_operand& op,
-                                         int nvalid_rows, int k0, int tid, bool vol = false) {
+                                         int nvalid_rows, int k0, int tid) {
     constexpr int PITCH = Geo<BK>::PITCH;
     const int ch = tid % CH, rin = tid / CH;
     const int k = k0 + ch * 8;
     float ca[8], cb[8], cc[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { ca[e] = 1.f; cb[e] = 0.f; cc[e] = 0.f; }
-    if (vol) {                            // workgroup-uniform
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        if (op.ca) ca[e] = ld_coef(op.ca + k + e);
-        if (HAS2 && op.cb) cb[e] = ld_coef(op.cb + k + e);
-        if (op.cc) cc[e] = ld_coef(op.cc + k + e);
-      }
-    } else {
     if (op.ca) {
       const float4 t0 = *reinterpret_cast<const float4*>(op.ca + k), t1 = *reinterpret_cast<const float4*>(op.ca + k + 4);
       ca[0] = t0.x; ca[1] = t0.y; ca[2] = t0.z; ca[3] = t0.w; ca[4] = t1.x; ca[5] = t1.y; ca[6] = t1.z; ca[7] = t1.w;
@@ -156,7 +145,6 @@ struct NatStage {
     if (op.cc) {
       const float4 t0 = *reinterpret_cast<const float4*>(op.cc + k), t1 = *reinterpret_cast<const float4*>(op.cc + k + 4);
       cc[0] = t0.x; cc[1] = t0.y; cc[2] = t0.z; cc[3] = t0.w; cc[4] = t1.x; cc[5] = t1.y; cc[6] = t1.z; cc[7] = t1.w;
-    }
     }
     const float lo = op.lo;
 #pragma unroll
@@ -537,10 +525,6 @@ __device__ __forceinline__ void rows_tile_t(const GemmArgs& g, const int bx, con
   const int wm = wave >> 1, wn = wave & 1;
   const int wrow0 = wm * WTM, wcol0 = wn * WTN;
 
-  // the finaliser of operand a's coefficients, folded into this launch (pn_bnfold.h); the tiles' LDS is free until the first chunk
-  const bool fold = g.fin.kind != 0;                         // launch-uniform
-  if (fold) bn_fold_head(g.fin, blockIdx.x, gridDim.x, reinterpret_cast<double(*)[2][16]>(lds_raw), reinterpret_cast<unsigned*>(lds_raw + 16 * 2 * 16 * 8));
-
   f32x16 acc[MT][NT];
 #pragma unroll
   for (int m = 0; m < MT; ++m)
@@ -574,10 +558,9 @@ __device__ __forceinline__ void rows_tile_t(const GemmArgs& g, const int bx, con
     }
   };
   if (g.K > 0) issue_chunk(0);
-  if (fold) bn_fold_wait(g.fin, gridDim.x);                           // under the latency of the loads just issued
   for (int k0 = 0; k0 < g.K; k0 += BK) {
     sa.pin();
-    sa.template finish<NS>(Ahi, Alo, g.a, nrows, k0, tid, fold);
+    sa.template finish<NS>(Ahi, Alo, g.a, nrows, k0, tid);
     if (MODE == MODE_FWD) {
       sbT.pin();
       sbT.template finish<NS>(Bhi, Blo, wop, BK, g.C - col0, 0, tid);
@@ -788,7 +771,7 @@ static int dispatch_bwd(const GemmArgs& g, int prec, hipStream_t st) {
 }
 
 int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, int K, int C, const float* cloud_bias,
-             float* z, float* stat_partials, int prec, hipStream_t st, const BnFin* fin) {
+             float* z, float* stat_partials, int prec, hipStream_t st) {
   PN_TRY(check_operand(x, "pn_conv_fwd.x"));
   PN_CHECK_ARG(!x->s2, "pn_conv_fwd: the forward operand has no second source");
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_fwd: B and N must be positive (B=%d N=%d)", B, N);
@@ -805,10 +788,6 @@ int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, i
   g.a = *x; g.w = w; g.w_cloud_stride = wcs; g.B = B; g.N = N; g.K = K; g.C = C;
   g.tiles_per_cloud = cdiv(N, 128);
   g.out = z; g.cloud_bias = cloud_bias; g.stat_partials = stat_partials;
-  if (fin && fin->kind) {
-    PN_CHECK_ARG(fin->sync != nullptr, "pn_conv_fwd: a folded finaliser needs its three sync words");
-    g.fin = *fin;
-  }
   static const int dbg = getenv("PN_GEMM_DBG") ? atoi(getenv("PN_GEMM_DBG")) : 0;
   g.dbg = dbg;
   return dispatch_rows<MODE_FWD, false, EPI_STORE>(g, prec, st);
@@ -834,7 +813,7 @@ int conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C
 
 int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, int N, int K, int C, const float* addend,
                   const float* zmask, const float* msc, const float* msh, float* out, float* stat_partials, int prec,
-                  hipStream_t st, const BnFin* fin) {
+                  hipStream_t st) {
   PN_TRY(check_operand(dz, "pn_conv_bwd_data.dz"));
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_bwd_data: B and N must be positive");
   PN_CHECK_ARG(K >= 64 && K % 64 == 0, "pn_conv_bwd_data: K must be a multiple of 64 (K=%d)", K);
@@ -851,10 +830,6 @@ int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, in
   g.a = *dz; g.w = w; g.w_cloud_stride = wcs; g.B = B; g.N = N; g.K = K; g.C = C;
   g.tiles_per_cloud = cdiv(N, 128);
   g.out = out; g.addend = addend; g.zmask = zmask; g.msc = msc; g.msh = msh; g.stat_partials = stat_partials;
-  if (fin && fin->kind) {
-    PN_CHECK_ARG(fin->sync != nullptr, "pn_conv_bwd_data: a folded finaliser needs its three sync words");
-    g.fin = *fin;
-  }
   if (dz->s2) return dispatch_bwd<true>(g, prec, st);
   return dispatch_bwd<false>(g, prec, st);
 }

@@ -4,17 +4,14 @@
 
 namespace pn {
 
-struct BnFin;     // pn_bnfold.h
-
 // pn_gemm.hip
-// fin (optional, kind != 0): the finaliser of the coefficients operand x / dz reads, run at the head of this launch (pn_bnfold.h)
 int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, int K, int C, const float* cloud_bias, float* z,
-             float* stat_partials, int prec, hipStream_t st, const BnFin* fin = nullptr);
+             float* stat_partials, int prec, hipStream_t st);
 int conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C, const float* sgn, float* pmax, int* pidx,
                  float* stat_partials, int prec, hipStream_t st);
 int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, int N, int K, int C, const float* addend,
                   const float* zmask, const float* msc, const float* msh, float* out, float* stat_partials, int prec,
-                  hipStream_t st, const BnFin* fin = nullptr);
+                  hipStream_t st);
 // weight-gradient jobs whose launches are grouped by tile shape (pn_gemm.hip: conv_wgrad_batch)
 struct WgradDesc {
   pn_operand a, b;
@@ -62,12 +59,6 @@ struct SlabJob {
 int slab_reduce_batch(const SlabJob* jobs, int n_jobs, hipStream_t st);
 int slab_reduce_q(const float* slabs, int n_slabs, long long elems, float* out, const float* w, const float* f, int K, int C, float* q,
                   hipStream_t st);
-// a finaliser as a value: launched on its own (bn_fin_launch) or handed to the row GEMM that consumes its coefficients (pn_bnfold.h)
-int bn_fin_make(BnFin& f, const float* part, int n_tiles, int C, long long count, const float* gamma, const float* beta, float* mm, float* mv,
-                float momentum, float eps, int use_batch, int update, float* mean, float* invstd, float* scale, float* shift);
-int bn_bwd_fin_make(BnFin& f, const float* part, int n_tiles, int C, long long count, const float* gamma, const float* mean,
-                    const float* invstd, int batch_stats, float* dgamma, float* dbeta, float* ca, float* cb, float* cc);
-int bn_fin_launch(const BnFin& f, hipStream_t st);
 int bn_finalize(const float* part, int n_tiles, int C, long long count, const float* gamma, const float* beta, float* mm,
                 float* mv, float momentum, float eps, int use_batch, int update, float* mean, float* invstd, float* scale,
                 float* shift, hipStream_t st);

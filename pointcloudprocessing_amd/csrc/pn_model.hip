@@ -19,7 +19,6 @@
 #include <string>
 #include <vector>
 #include "pn_internal.h"
-#include "pn_bnfold.h"
 
 namespace pn {
 
@@ -157,7 +156,6 @@ struct WS {
   float* slab_pool;          // slabs of the parameter-gradient jobs whose reduction is deferred to the end of the (phase of the) pass
   size_t slab_pool_floats;
   unsigned* dcount;
-  unsigned* bnsync;          // sync words of the finalisers folded into their consumers (pn_bnfold.h)
 };
 
 static long long wgrad_slab_rows(int B, int N, int Ci, int Cj, int* spc_out, int target_override = 0) {
@@ -297,8 +295,7 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
   w.cls_logits = A.get<float>("cls_logits", (size_t)B * d.ccls);
   w.seg_part = A.get<float>("seg_part", (size_t)cdivll(M, seg_out_part_rows()) * seg_out_part_stride());
   w.dense_part = A.get<float>("dense_part", (size_t)8 * B * 4096);          // split-K tiles of the dense layers (<= 8 splits)
-  w.dcount = A.get<unsigned>("dcount", DENSE_MAX_COUNTERS + BNFOLD_SITES * BNFOLD_SET_WORDS);   // their in-launch arrival counters + the words of pn_bnfold.h
-  w.bnsync = w.dcount + DENSE_MAX_COUNTERS;
+  w.dcount = A.get<unsigned>("dcount", DENSE_MAX_COUNTERS);                 // their in-launch arrival counters
   w.R3eye = A.get<float>("R3eye", (size_t)B * 9);
   w.regpart = A.get<float>("regpart", (size_t)2 * B);
   w.slab_floats = w.slab_main_floats = w.slab_pool_floats = 0;
@@ -484,57 +481,19 @@ struct Run {
     return o;
   }
 
-  // ---------------- BatchNormalization finalisers ----------------
-  // A finaliser is not launched when it is made: it waits for the next launch.  If that is a row GEMM (conv_fwd / conv_bwd_data --
-  // the consumer of the coefficients in most places) the finaliser runs at its head (pn_bnfold.h) and costs no launch; before any
-  // other kernel it is launched on its own (flush_pending).  PN_BN_FOLD=0: always its own launch.
-  BnFin pend;
-  bool have_pend = false;
-  int fold_site = 0, fold_site_end = 16;     // the set of sync words the next folded launch uses: forward 0-15, backward 16-31 / 32-47
-  bool fold_on() const {
-    static const bool on = !(getenv("PN_BN_FOLD") && atoi(getenv("PN_BN_FOLD")) == 0);
-    return on && !aux;
-  }
-  int flush_pending() {
-    if (!have_pend) return PN_OK;
-    have_pend = false;
-    return bn_fin_launch(pend, st);
-  }
-  int set_pending(const BnFin& f) {
-    PN_TRY(flush_pending());
-    if (!fold_on()) return bn_fin_launch(f, st);
-    pend = f;
-    have_pend = true;
-    return PN_OK;
-  }
-  const BnFin* take_pending() {          // for the launcher of a row GEMM; the object stays valid until the next set_pending
-    if (!have_pend) return nullptr;
-    if (fold_site >= fold_site_end) {                    // out of sync-word sets: its own launch after all
-      (void)flush_pending();
-      return nullptr;
-    }
-    have_pend = false;
-    pend.sync = w.bnsync + (size_t)fold_site * BNFOLD_SET_WORDS;
-    ++fold_site;
-    return &pend;
-  }
-
   // ---------------- forward pieces ----------------
   int bn_fin(const CL& l, const LRef& r, int n_tiles = -1) {
     const int ub = bn_batch(r.block) ? 1 : 0;
-    BnFin f;
-    PN_TRY(bn_fin_make(f, l.part, n_tiles < 0 ? T : n_tiles, r.cout, M, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub, ub,
-                       l.mean, l.invstd, l.scale, l.shift));
-    return set_pending(f);
+    return bn_finalize(l.part, n_tiles < 0 ? T : n_tiles, r.cout, M, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub, ub, l.mean,
+                       l.invstd, l.scale, l.shift, st);
   }
   int fwd_conv(CL& l, const LRef& r, const pn_operand& x, const float* W, long long wcs, const float* cloud_bias) {
     PN_TRY(conv_fwd(&x, W, wcs, B, N, r.cin, r.cout, cloud_bias, l.Z, bn_batch(r.block) ? l.part : nullptr, prec,
-                    st, take_pending()));
+                    st));
     return bn_fin(l, r);
   }
   int fwd_max(CL& l, ML& m, const LRef& r, const pn_operand& x, int prof_slot) {
     const int ub = bn_batch(r.block) ? 1 : 0;
-    PN_TRY(flush_pending());
     void** ev = io.prof_events;
     if (ev && ev[2 * prof_slot]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot]), st);
     PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.pmax, m.pq, ub ? m.sumsq : nullptr, ub ? m.pa1 : nullptr, prec, st));
@@ -571,11 +530,6 @@ struct Run {
   pn_operand x64op() const { return d.vanilla ? lazy(w.m12) : plain_act(w.X64, 64); }
 
   int forward() {
-    const int rc = forward_body();
-    if (rc != PN_OK) return rc;
-    return flush_pending();
-  }
-  int forward_body() {
     {   // bf16 channel-major copies of the three 128->1024 kernels (they only change in the optimizer) + the dense layers' arrival counters
       const bool x3 = prec == PN_PREC_BF16X3;
       const float* ws[3] = {d.vanilla ? nullptr : p(L.iT.c3.kernel), d.vanilla ? nullptr : p(L.fT.c3.kernel), p(L.m23.kernel)};
@@ -587,7 +541,7 @@ struct Run {
       // clears the gradient buffer and draws the dropout masks (pn_prologue.hip)
       const bool zg = training && G && io.zero_grads_in_forward;
       const bool dm = training && io.dropout_step && io.keep1 && io.keep2 && d.dropout_rate > 0.f;
-      PN_TRY(fwd_prologue(io.pc, B, N, w.pcn, w.cent, w.scl, ws, sgs, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS + BNFOLD_SITES * BNFOLD_SET_WORDS, zg ? G : nullptr,
+      PN_TRY(fwd_prologue(io.pc, B, N, w.pcn, w.cent, w.scl, ws, sgs, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS, zg ? G : nullptr,
                           zg ? L.total : 0, dm ? const_cast<unsigned char*>(io.keep1) : nullptr, dm ? (long long)B * 512 : 0,
                           dm ? const_cast<unsigned char*>(io.keep2) : nullptr, dm ? (long long)B * 256 : 0, d.dropout_rate, io.dropout_seed,
                           dm ? io.dropout_step : nullptr, st));
@@ -605,7 +559,7 @@ struct Run {
     if (!d.vanilla) {
       const pn_operand a12 = lazy(w.m12);
       PN_TRY(fwd_tnet(w.fT, L.fT, &a12));
-      PN_TRY(conv_fwd(&a12, w.fT.R, 4096, B, N, 64, 64, nullptr, w.X64, nullptr, prec, st, take_pending()));
+      PN_TRY(conv_fwd(&a12, w.fT.R, 4096, B, N, 64, 64, nullptr, w.X64, nullptr, prec, st));
     }
     const pn_operand x64 = x64op();
     PN_TRY(fwd_conv(w.m21, L.m21, x64, p(L.m21.kernel), 0, nullptr));
@@ -629,14 +583,13 @@ struct Run {
     // segmentation head (PointNet.py:268-290)
     const float* Ws1 = p(L.s1.kernel);
     // seg_l1 always emits its forward partials: the backward needs the per-cloud sums of z
-    PN_TRY(conv_fwd(&x64, Ws1, 0, B, N, 64, 512, w.gb, w.s1.Z, w.s1.part, prec, st, take_pending()));
+    PN_TRY(conv_fwd(&x64, Ws1, 0, B, N, 64, 512, w.gb, w.s1.Z, w.s1.part, prec, st));
     PN_TRY(bn_fin(w.s1, L.s1));
     PN_TRY(fwd_conv(w.s2, L.s2, lazy(w.s1), p(L.s2.kernel), 0, nullptr));
     PN_TRY(fwd_conv(w.s3, L.s3, lazy(w.s2), p(L.s3.kernel), 0, nullptr));
     PN_TRY(fwd_conv(w.s4, L.s4, lazy(w.s3), p(L.s4.kernel), 0, nullptr));
     const pn_operand a4 = lazy(w.s4);
     const bool fseg = io.labels_seg != nullptr;
-    PN_TRY(flush_pending());
     PN_TRY(seg_out_fwd(&a4, p(L.s5.kernel), p(L.s5.bias), M, 128, d.cseg, io.labels_seg, fseg ? io.loss_weights[1] / (float)M : 0.f,
                        io.out_seg, (fseg && training) ? w.seg_dlogits : nullptr, fseg ? w.seg_part : nullptr, st));
     // third output: the input transform (PointNet.py:292); identity for vanilla (:211)
@@ -673,7 +626,6 @@ struct Run {
   }
   // parameter gradient of a Cin = 3 layer from T row-tile slabs
   int wgrad3_to(const pn_operand& dz, float* out) {
-    PN_TRY(flush_pending());               // conv3_wgrad reads dz's coefficients now
     float* sl = pool_take((size_t)T * 3 * 64);
     if (sl) {
       PN_TRY(conv3_wgrad(w.pcn, &dz, B, N, 64, sl, st));
@@ -699,16 +651,12 @@ struct Run {
       if (float* ps = pool_take((size_t)Bq * spc * elems)) {
         static const bool batch_gemm = !(getenv("PN_WGRAD_BATCH") && atoi(getenv("PN_WGRAD_BATCH")) == 0);
         if (batch_gemm) wg_jobs.push_back(WgradDesc{a, b, Bq, Nq, Ci, Cj, rows, ps, pr, colsum ? 1 : 0, 0});
-        else {
-          PN_TRY(flush_pending());
-          PN_TRY(conv_wgrad(&a, &b, Bq, Nq, Ci, Cj, rows, ps, pr, st, colsum ? 1 : 0));
-        }
+        else PN_TRY(conv_wgrad(&a, &b, Bq, Nq, Ci, Cj, rows, ps, pr, st, colsum ? 1 : 0));
         jobs.push_back(SlabJob{ps, out, (long long)elems, Bq * spc});
         last_deferred = true;
         return PN_OK;
       }
     }
-    PN_TRY(flush_pending());               // launched here and now: it may read a pending finaliser's coefficients
     float* sl = cur_slabs();
     if ((size_t)Bq * spc * elems > (sl == w.slabs ? w.slab_floats : w.slab_main_floats)) {
       set_error("wgrad: slab scratch too small");
@@ -719,10 +667,8 @@ struct Run {
   }
   int bn_bwd_fin(const CL& l, const LRef& r, const float* part) {
     const int bs = bn_batch(r.block) ? 1 : 0;
-    BnFin f;
-    PN_TRY(bn_bwd_fin_make(f, part, T, r.cout, M, p(r.gamma), l.mean, l.invstd, bs, bs ? gr(r.gamma) : nullptr, bs ? gr(r.beta) : nullptr, l.ca,
-                           l.cb, l.cc));
-    return set_pending(f);
+    return bn_bwd_finalize(part, T, r.cout, M, p(r.gamma), l.mean, l.invstd, bs, bs ? gr(r.gamma) : nullptr, bs ? gr(r.beta) : nullptr,
+                           l.ca, l.cb, l.cc, st);
   }
   // standard interior step: given cur.dy (+ w.bpart holding its stats) produce prev.dy and cur's weight gradient
   int bwd_step(CL& cur, const LRef& rc, CL& prev, const pn_operand& prev_act) {
@@ -734,12 +680,10 @@ struct Run {
       PN_TRY(side([=] { return wgrad_to(prev_act, dz, ci, cj, out, false, true); }));
       PN_TRY(flush());
     }
-    return conv_bwd_data(&dz, p(rc.kernel), 0, B, N, rc.cout, rc.cin, nullptr, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st,
-                         take_pending());
+    return conv_bwd_data(&dz, p(rc.kernel), 0, B, N, rc.cout, rc.cin, nullptr, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st);
   }
   // backward of a max-pooled layer: dG (B,C) -> prev.dy (+stats in w.bpart), this layer's parameter gradients
   int bwd_max(CL& l, ML& m, const LRef& r, const pn_operand& xop, CL& prev, const float* dG, const float* dG2 = nullptr) {
-    PN_TRY(flush_pending());
     const int K = r.cin, C = r.cout;
     const int bs = bn_batch(r.block) ? 1 : 0;
     const bool wg = tr(r.block) && G;
@@ -858,11 +802,8 @@ struct Run {
   }
 
   int backward(const float* d_cls, const float* d_seg, const float* d_R) {
-    fold_site = io.bwd_phase == 2 ? 32 : 16;
-    fold_site_end = fold_site + 16;
     const int rc = backward_body(d_cls, d_seg, d_R);
     if (rc != PN_OK) return rc;
-    PN_TRY(flush_pending());
     return flush_jobs();                       // every deferred parameter gradient of this pass (or phase of it) is final after this
   }
   int backward_body(const float* d_cls, const float* d_seg, const float* d_R) {
@@ -883,9 +824,7 @@ struct Run {
     // feature_transform.*).  A data-parallel caller all-reduces the first bucket while phase 2 runs (engine.TrainStep).
     const int phase = io.bwd_phase;
     if (phase != 2) {
-    // (+ the dense layers' counters and every set of fold sync words: a backward pass that is not the one its forward pass announced)
-    if (!io.zero_grads_in_forward)
-      PN_TRY(zero_fill2(G, L.total, reinterpret_cast<float*>(w.dcount), DENSE_MAX_COUNTERS + BNFOLD_SITES * BNFOLD_SET_WORDS, st));
+    if (!io.zero_grads_in_forward) PN_TRY(zero_fill2(G, L.total, reinterpret_cast<float*>(w.dcount), DENSE_MAX_COUNTERS, st));
 
     // ---- segmentation head ----
     bool have_dx64 = false;     // w.dX64 holds the seg head's contribution to d(X_64)
@@ -909,7 +848,6 @@ struct Run {
       PN_TRY(bwd_step(w.s2, L.s2, w.s1, lazy(w.s1)));
       PN_TRY(bn_bwd_fin(w.s1, L.s1, w.bpart));
       const pn_operand dz1 = dzop(w.s1);
-      PN_TRY(flush_pending());             // cloud_bias_grad and the products below read s1's dz coefficients
       PN_TRY(cloud_bias_grad(w.bpart, w.s1.part, B, tpc, N, 512, w.s1.ca, w.s1.cb, w.s1.cc, w.dgb, st));
       if (tr(BLK_S1)) {
         PN_TRY(side([=] {
@@ -920,7 +858,7 @@ struct Run {
       }
       PN_TRY(dense_plain(w.dgb, 512, Ws1 + 64 * 512, 512, true, 512, 1024, nullptr, w.dGseg));
       have_dGseg = true;
-      PN_TRY(conv_bwd_data(&dz1, Ws1, 0, B, N, 512, 64, nullptr, nullptr, nullptr, nullptr, w.dX64, nullptr, prec, st, take_pending()));
+      PN_TRY(conv_bwd_data(&dz1, Ws1, 0, B, N, 512, 64, nullptr, nullptr, nullptr, nullptr, w.dX64, nullptr, prec, st));
       have_dx64 = true;
     }
 
@@ -951,10 +889,10 @@ struct Run {
       }
       if (d.vanilla) {
         PN_TRY(conv_bwd_data(&dz21, p(L.m21.kernel), 0, B, N, 64, 64, have_dx64 ? w.dX64 : nullptr, w.m12.Z, w.m12.scale, w.m12.shift,
-                             w.m12.dy, w.bpart, prec, st, take_pending()));
+                             w.m12.dy, w.bpart, prec, st));
       } else {
         PN_TRY(conv_bwd_data(&dz21, p(L.m21.kernel), 0, B, N, 64, 64, have_dx64 ? w.dX64 : nullptr, nullptr, nullptr, nullptr, w.dX64,
-                             nullptr, prec, st, take_pending()));
+                             nullptr, prec, st));
       }
     }
     if (!d.vanilla) {
@@ -965,13 +903,13 @@ struct Run {
       if (have_dx) {
         const pn_operand dx = plain_act(w.dX64, 64);
         PN_TRY(wgrad_to(a12, dx, 64, 64, w.fT.dR, true));
-        PN_TRY(conv_bwd_data(&dx, w.fT.R, 4096, B, N, 64, 64, nullptr, nullptr, nullptr, nullptr, w.tmpA12, nullptr, prec, st, take_pending()));
+        PN_TRY(conv_bwd_data(&dx, w.fT.R, 4096, B, N, 64, 64, nullptr, nullptr, nullptr, nullptr, w.tmpA12, nullptr, prec, st));
       }
       if (d.reg_feat) PN_TRY(orth_reg(w.fT.R, B, 64, 1e-3f, w.fT.dR, nullptr, st));
       PN_TRY(bwd_tnet(w.fT, L.fT, &a12));
       const pn_operand dzf1 = dzop(w.fT.c1);
       PN_TRY(conv_bwd_data(&dzf1, p(L.fT.c1.kernel), 0, B, N, 64, 64, have_dx ? w.tmpA12 : nullptr, w.m12.Z, w.m12.scale, w.m12.shift,
-                           w.m12.dy, w.bpart, prec, st, take_pending()));
+                           w.m12.dy, w.bpart, prec, st));
     }
     }   // phase != 2
     if (phase == 1) return PN_OK;
@@ -984,7 +922,6 @@ struct Run {
       if (tr(BLK_M11)) PN_TRY(wgrad3_to(dz11, gr(L.m11.kernel)));
       return PN_OK;
     }
-    PN_TRY(flush_pending());
     PN_TRY(conv3_wgrad(w.pcn, &dz11, B, N, 64, cur_slabs(), st));
     PN_TRY(slab_reduce(cur_slabs(), T, tpc, 3 * 64, w.dWeff1, st));
     PN_TRY(fold3_bwd(w.dWeff1, w.iT.R, p(L.m11.kernel), B, 64, w.iT.dR, tr(BLK_M11) ? gr(L.m11.kernel) : nullptr, st));

@@ -2,7 +2,6 @@
 #include <cstring>
 #include "pn_common.h"
 #include "pn_internal.h"
-#include "pn_bnfold.h"
 
 namespace pn {
 
@@ -283,51 +282,119 @@ int slab_reduce_batch(const SlabJob* jobs, int n_jobs, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------------
 // BatchNormalization coefficient finalisers (keras BatchNormalization semantics, see pointnet_hip.h)
 // ------------------------------------------------------------------------------------------------------
-// the bodies live in pn_bnfold.h (they also run at the head of the row GEMMs that consume the coefficients)
-__global__ __launch_bounds__(256) void bn_fin_kernel(const BnFin f) {
+// block = 16 channels x 16 partitions of the tile range, 4 tiles in flight per thread; fp64 combine in a fixed order
+__device__ __forceinline__ void reduce_tiles_2(const float* __restrict__ part, int n_tiles, int C, int c, int ty, double (*red)[2][16],
+                                               int tx, double& s1, double& s2) {
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    const float* p = part + c;
+    // sixteen tiles (32 independent loads) in flight per thread: the kernel is one memory round trip per batch, and at the usual
+    // 256 tiles a thread has exactly one batch.  The summation order (tiles ascending per thread, then the 16 threads) is unchanged.
+    for (int t = ty; t < n_tiles; t += 16 * 16) {
+      float x[16], y[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int tt = t + 16 * u;
+        const long long o = (long long)(tt < n_tiles ? tt : t) * 2 * C;
+        x[u] = p[o];
+        y[u] = p[o + C];
+      }
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (t + 16 * u < n_tiles) { a += (double)x[u]; b += (double)y[u]; }
+    }
+  }
+  red[ty][0][tx] = a;
+  red[ty][1][tx] = b;
+  __syncthreads();
+  s1 = 0.0; s2 = 0.0;
+  for (int q = 0; q < 16; ++q) { s1 += red[q][0][tx]; s2 += red[q][1][tx]; }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int n_tiles, int C, double inv_count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ mm, float* __restrict__ mv, float momentum,
+                                                          float eps, int use_batch, int update, float* __restrict__ mean_o,
+                                                          float* __restrict__ invstd_o, float* __restrict__ scale_o,
+                                                          float* __restrict__ shift_o) {
   __shared__ double red[16][2][16];
-  bn_fin_body(f, blockIdx.x, red);
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + tx;
+  double s1 = 0.0, s2 = 0.0;
+  if (use_batch) reduce_tiles_2(part, n_tiles, C, c, ty, red, tx, s1, s2);
+  if (ty != 0 || c >= C) return;
+  float mean, var;
+  if (use_batch) {
+    const double m = s1 * inv_count;
+    double v = s2 * inv_count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m;
+    var = (float)v;
+    if (update) {
+      mm[c] = mm[c] * momentum + mean * (1.f - momentum);
+      mv[c] = mv[c] * momentum + var * (1.f - momentum);
+    }
+  } else {
+    mean = mm[c];
+    var = mv[c];
+  }
+  const float invstd = 1.0f / sqrtf(var + eps);
+  const float sc = gamma[c] * invstd;
+  if (mean_o) mean_o[c] = mean;
+  if (invstd_o) invstd_o[c] = invstd;
+  scale_o[c] = sc;
+  shift_o[c] = beta[c] - mean * sc;
 }
-int bn_fin_launch(const BnFin& f, hipStream_t st) {
-  PN_CHECK_ARG(f.kind == 1 || f.kind == 2, "bn_fin_launch: bad kind");
-  hipLaunchKernelGGL(bn_fin_kernel, dim3(cdiv(f.C, 16)), dim3(256), 0, st, f);
-  PN_CHECK_LAUNCH();
-  return PN_OK;
-}
-int bn_fin_make(BnFin& f, const float* part, int n_tiles, int C, long long count, const float* gamma, const float* beta, float* mm, float* mv,
-                float momentum, float eps, int use_batch, int update, float* mean, float* invstd, float* scale, float* shift) {
-  PN_CHECK_ARG(gamma && beta && mm && mv && scale && shift, "pn_bn_finalize: null pointer");
-  PN_CHECK_ARG(C > 0, "pn_bn_finalize: C must be positive");
-  PN_CHECK_ARG(!use_batch || (part && n_tiles > 0 && count > 0), "pn_bn_finalize: batch statistics need partials");
-  memset(&f, 0, sizeof(f));
-  f.kind = 1; f.part = part; f.n_tiles = n_tiles; f.C = C; f.inv_count = 1.0 / (double)(count > 0 ? count : 1);
-  f.gamma = gamma; f.beta = beta; f.mm = mm; f.mv = mv; f.momentum = momentum; f.eps = eps; f.use_batch = use_batch; f.update = update;
-  f.mean = mean; f.invstd = invstd; f.scale = scale; f.shift = shift;
-  return PN_OK;
-}
-int bn_bwd_fin_make(BnFin& f, const float* part, int n_tiles, int C, long long count, const float* gamma, const float* mean,
-                    const float* invstd, int batch_stats, float* dgamma, float* dbeta, float* ca, float* cb, float* cc) {
-  PN_CHECK_ARG(gamma && invstd && ca && cb && cc, "pn_bn_bwd_finalize: null pointer");
-  PN_CHECK_ARG(!batch_stats || (part && mean && n_tiles > 0 && count > 0), "pn_bn_bwd_finalize: batch statistics need partials");
-  memset(&f, 0, sizeof(f));
-  f.kind = 2; f.part = part; f.n_tiles = n_tiles; f.C = C; f.inv_count = 1.0 / (double)(count > 0 ? count : 1);
-  f.gamma = gamma; f.mean = const_cast<float*>(mean); f.invstd = const_cast<float*>(invstd); f.use_batch = batch_stats;
-  f.dgamma = dgamma; f.dbeta = dbeta; f.ca = ca; f.cb = cb; f.cc = cc;
-  return PN_OK;
-}
+
 int bn_finalize(const float* part, int n_tiles, int C, long long count, const float* gamma, const float* beta, float* mm,
                 float* mv, float momentum, float eps, int use_batch, int update, float* mean, float* invstd, float* scale,
                 float* shift, hipStream_t st) {
-  BnFin f;
-  PN_TRY(bn_fin_make(f, part, n_tiles, C, count, gamma, beta, mm, mv, momentum, eps, use_batch, update, mean, invstd, scale, shift));
-  return bn_fin_launch(f, st);
+  PN_CHECK_ARG(gamma && beta && mm && mv && scale && shift, "pn_bn_finalize: null pointer");
+  PN_CHECK_ARG(C > 0, "pn_bn_finalize: C must be positive");
+  PN_CHECK_ARG(!use_batch || (part && n_tiles > 0 && count > 0), "pn_bn_finalize: batch statistics need partials");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, part, n_tiles, C, 1.0 / (double)(count > 0 ? count : 1),
+                     gamma, beta, mm, mv, momentum, eps, use_batch, update, mean, invstd, scale, shift);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
 }
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int n_tiles, int C,
+                                                              double inv_count, const float* __restrict__ gamma,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              int batch_stats, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, float* __restrict__ ca,
+                                                              float* __restrict__ cb, float* __restrict__ cc) {
+  __shared__ double red[16][2][16];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + tx;
+  double s1 = 0.0, s2 = 0.0;
+  if (batch_stats) reduce_tiles_2(part, n_tiles, C, c, ty, red, tx, s1, s2);
+  if (ty != 0 || c >= C) return;
+  const float a = gamma[c] * invstd[c];
+  if (!batch_stats) {
+    ca[c] = a; cb[c] = 0.f; cc[c] = 0.f;
+    return;
+  }
+  // S1 = sum dy_hat ; S2 = sum dy_hat * zhat, zhat = (z - mean) * invstd
+  const double S1 = s1;
+  const double S2 = (s2 - (double)mean[c] * s1) * (double)invstd[c];
+  if (dgamma) dgamma[c] = (float)S2;
+  if (dbeta) dbeta[c] = (float)S1;
+  const double b = -(double)a * (double)invstd[c] * S2 * inv_count;
+  ca[c] = a;
+  cb[c] = (float)b;
+  cc[c] = (float)(-(double)a * S1 * inv_count - b * (double)mean[c]);
+}
+
 int bn_bwd_finalize(const float* part, int n_tiles, int C, long long count, const float* gamma, const float* mean,
                     const float* invstd, int batch_stats, float* dgamma, float* dbeta, float* ca, float* cb, float* cc,
                     hipStream_t st) {
-  BnFin f;
-  PN_TRY(bn_bwd_fin_make(f, part, n_tiles, C, count, gamma, mean, invstd, batch_stats, dgamma, dbeta, ca, cb, cc));
-  return bn_fin_launch(f, st);
+  PN_CHECK_ARG(gamma && invstd && ca && cb && cc, "pn_bn_bwd_finalize: null pointer");
+  PN_CHECK_ARG(!batch_stats || (part && mean && n_tiles > 0 && count > 0), "pn_bn_bwd_finalize: batch statistics need partials");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, part, n_tiles, C,
+                     1.0 / (double)(count > 0 ? count : 1), gamma, mean, invstd, batch_stats, dgamma, dbeta, ca, cb, cc);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
 }
 
 // sgn[c] = +1 if gamma[c] >= 0 else -1 (the sign of the BN scale, known before the statistics are)
