@@ -390,27 +390,35 @@ __device__ __forceinline__ void wgrad_tile_t(const GemmArgs& g, const int bx, co
   // hidden behind the matrix cores
   TrnStage<BM, BK, A2, AH> sa;
   TrnStage<BN, BK, B2, BH> sb;
+  // a diagonal tile of a Gram matrix (both operands the same tensor through the same coefficients, i0 == j0): the B image IS the A
+  // image -- one operand is loaded, converted and written to LDS instead of two
+  const bool same = (BM == BN) && !A2 && !B2 && (AH == BH) && i0 == j0 && g.Ci == g.C && g.a.s1 == g.b.s1 && g.a.ld == g.b.ld &&
+                    g.a.ca == g.b.ca && g.a.cc == g.b.cc && g.a.lo == g.b.lo;      // block-uniform
+  const __bf16* Bh = same ? Ahi : Bhi;
+  const __bf16* Bl = same ? Alo : Blo;
   if (rbeg < rend) {
     const long long rowbase = (long long)cloud * g.N + rbeg;
     const int nk = min(BK, rend - rbeg);
     sa.issue(g.a, rowbase * g.a.ld + i0, nk, g.Ci - i0, tid);
-    sb.issue(g.b, rowbase * g.b.ld + j0, nk, g.C - j0, tid);
+    if (!same) sb.issue(g.b, rowbase * g.b.ld + j0, nk, g.C - j0, tid);
   }
   for (int r0 = rbeg; r0 < rend; r0 += BK) {
     const int nk = min(BK, rend - r0);
     sa.pin();
     const float2 csp = sa.template finish<NS>(Ahi, Alo, g.a, nk, g.Ci - i0, i0, tid, want_cs);
     cs += csp.x; cs2 += csp.y;
-    sb.pin();
-    sb.template finish<NS>(Bhi, Blo, g.b, nk, g.C - j0, j0, tid);
+    if (!same) {
+      sb.pin();
+      sb.template finish<NS>(Bhi, Blo, g.b, nk, g.C - j0, j0, tid);
+    }
     __syncthreads();
     if (r0 + BK < rend) {
       const long long rowbase = (long long)cloud * g.N + r0 + BK;
       const int nk2 = min(BK, rend - (r0 + BK));
       sa.issue(g.a, rowbase * g.a.ld + i0, nk2, g.Ci - i0, tid);
-      sb.issue(g.b, rowbase * g.b.ld + j0, nk2, g.C - j0, tid);
+      if (!same) sb.issue(g.b, rowbase * g.b.ld + j0, nk2, g.C - j0, tid);
     }
-    mma_chunk<MT, NT, BK, NS>(acc, Ahi, Alo, Bhi, Blo, wrow0, wcol0, lane);
+    mma_chunk<MT, NT, BK, NS>(acc, Ahi, Alo, Bh, Bl, wrow0, wcol0, lane);
     __syncthreads();
   }
   // slab store
