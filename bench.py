@@ -12,8 +12,10 @@ One JSON line is printed by rank 0.  Extra objects:
   roofline     the dominant kernel = fused ConvLayer(128->1024)+BN-stats+reduce_max (3 launches per step), timed live with
                HIP events on the launch stream (20 back-to-back launches of each layer on the step's own operands);
                achieved = 2*128*1024 FLOP/point * points per launch / mean launch time, against the dense bf16 MFMA peak
-               (2.5 PFLOP/s).  bound = "mfma": with 512 B/point of compulsory input this kernel is compute bound (512 FLOP/B
-               against a ridge of 312).
+               (2.5 PFLOP/s).  bound = "mfma": with 256 B/point of compulsory input (128 channels stored as bf16; 512 B with
+               fp32 storage) this kernel is compute bound (1024 FLOP/B against a ridge of 312).
+               traffic = HBM bytes per launch from the rocprofv3 PMC passes under profiles/round2 (FETCH_SIZE x 2 + WRITE_SIZE,
+               MI355X_MICROARCH.md), reported only while pn_panel.hip is the source they were collected on, else null.
   cpu_baseline the CPU oracle (torch-CPU restatement of the reference model; the TF reference itself cannot run
                here) timed on this host for a bounded number of steps of the same workload.
 """

@@ -49,7 +49,7 @@ struct DenseArgs {
 // (measured: K=1024 unsplit 35 us, split 8 ways 12.5 us; K=256, C=9 unsplit 11.6 us, split in two 10.4 us): one step per block
 // up to 8 splits, pipelined steps beyond that.
 static inline int dl_nsplit(int K) {
-  static const int per_split = getenv("PN_DENSE_KSPLIT") ? atoi(getenv("PN_DENSE_KSPLIT")) : DL_KSTEP;
+  static const int per_split = (getenv("PN_DENSE_KSPLIT") && atoi(getenv("PN_DENSE_KSPLIT")) >= 1) ? atoi(getenv("PN_DENSE_KSPLIT")) : DL_KSTEP;
   const int s = cdiv(K, per_split);
   return s < 1 ? 1 : (s > DL_MAX_SPLITS ? DL_MAX_SPLITS : s);
 }
