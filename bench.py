@@ -146,10 +146,9 @@ def main():
 
     # ---- dominant kernel: the fused ConvLayer(128->1024) + BN statistics + reduce_max panel kernel (3 launches per step) ----
     # Timed live with HIP events on the launch stream: after one eager step has left the three layers' real inputs in the workspace,
-    # each layer's launch -- same entry point, same operands, same outputs as inside the step -- is repeated 20 times back to back
-    # between ONE event pair (an event bracket around a single ~15 us launch reads several us high).  The mean therefore includes the
-    # ~1 us boundary between dependent launches: it can only read LOW against rocprofv3's per-kernel duration of the same command
-    # (profiles/), never high.
+    # the three layers' launches -- same entry point, same operands, same outputs as inside the step -- are repeated in rotation, 20
+    # rounds back to back between ONE event pair (an event bracket around a single ~15 us launch reads several us high).  The mean
+    # includes the boundaries between the launches; rocprofv3's per-kernel average of the same command (profiles/) is the cross-check.
     import ctypes as C
     from pointcloudprocessing_amd import _lib
     step_eager()
@@ -161,21 +160,24 @@ def main():
     def wsf(name, dtype=torch.float32):
         return model.workspace_tensor(name, B, N, True, dtype)
     REPS = 20
-    kt = []
+    calls = []
     for src, ml in layers:
         op = _lib.operand(wsf(src + ".Z", model.activation_dtype).view(B * N, K_), ca=wsf(src + ".scale"), cc=wsf(src + ".shift"), relu=True)
-        a = (C.byref(op), _lib.ptr(wsf(ml + ".wb_hi", torch.bfloat16)), _lib.ptr(wsf(ml + ".wb_lo", torch.bfloat16)), B, N, K_, C_,
-             _lib.ptr(wsf(ml + ".pmax")), _lib.ptr(wsf(ml + ".pq", torch.int32)), _lib.ptr(wsf(ml + ".sumsq")), _lib.ptr(wsf(ml + ".sumz")),
-             prec_id, _lib.current_stream())
-        for _ in range(3):
+        calls.append((op, (C.byref(op), _lib.ptr(wsf(ml + ".wb_hi", torch.bfloat16)), _lib.ptr(wsf(ml + ".wb_lo", torch.bfloat16)), B, N, K_, C_,
+                           _lib.ptr(wsf(ml + ".pmax")), _lib.ptr(wsf(ml + ".pq", torch.int32)), _lib.ptr(wsf(ml + ".sumsq")),
+                           _lib.ptr(wsf(ml + ".sumz")), prec_id, _lib.current_stream())))
+    for _ in range(3):
+        for _, a in calls:
             _lib.check(_lib.lib().pn_conv_fwd_max_panel(*a), "pn_conv_fwd_max_panel")
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(REPS):
+    # the three layers in rotation (as in the step, a launch never finds its own operands of the previous launch in the caches)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(REPS):
+        for _, a in calls:
             _lib.check(_lib.lib().pn_conv_fwd_max_panel(*a), "pn_conv_fwd_max_panel")
-        e1.record()
-        torch.cuda.synchronize()
-        kt.append(e0.elapsed_time(e1) * 1e-3 / REPS)
+    e1.record()
+    torch.cuda.synchronize()
+    kt = [e0.elapsed_time(e1) * 1e-3 / (REPS * len(calls))] * len(calls)
     k_mean = sum(kt) / len(kt)
     flop_per_launch = 2.0 * 128 * 1024 * B * N
     # algorithmic bytes: pre-BN input rows read once (in their storage type) + the bf16 kernel copy + per-(cloud, channel) max / block /
@@ -215,7 +217,7 @@ def main():
                      "achieved": achieved / 1e12, "peak": MFMA_BF16_PEAK / 1e12 / (3 if args.precision == "bf16x3" else 1),
                      "unit": "TFLOP/s", "frac": achieved / (MFMA_BF16_PEAK / (3 if args.precision == "bf16x3" else 1)),
                      "traffic": traffic, "launch_us": k_mean * 1e6, "launches_timed": REPS * len(kt),
-                     "timing": "HIP events around 20 back-to-back launches per layer on the launch stream (includes launch boundaries)",
+                     "timing": "one HIP event pair around 60 back-to-back launches (the step's three layers in rotation, 20 rounds) on the launch stream; includes the launch boundaries",
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "hbm_frac_if_bandwidth_bound": bytes_per_launch / k_mean / HBM_PEAK},
     }
