@@ -36,6 +36,8 @@ struct GemmArgs {
   pn_operand a;       // FWD/BWD: activation-side operand.  WGRAD: operand a (channels Ci)
   pn_operand b;       // WGRAD only: operand b (channels Cj)
   const float* w;     // FWD: W[K][C];  BWD: W[C][K]
+  const unsigned short* w16;   // optional (bf16 operands, shared kernel): a bf16 copy laid out [C][K], k contiguous -- FWD: the transposed
+                               // kernel, BWD: the kernel as it is -- staged without conversion instead of `w`
   long long w_cloud_stride;
   int B, N;           // clouds, points per cloud
   int K;              // contraction length (FWD/BWD);   WGRAD: slab_rows
@@ -283,6 +285,39 @@ struct TrnStage {
   }
 };
 
+// ---- copy stager: rows of a bf16 matrix with k contiguous that is ALREADY in operand precision (the bf16 copies of a layer's kernel
+//      the step's first launch makes, pn_prologue.hip): global -> LDS as is, no conversion -----------------------------------------
+template <int TR, int BK>
+struct CopyStage {
+  static constexpr int CH = BK / 8;     // 16-byte chunks per LDS row
+  static constexpr int RP = 256 / CH;   // rows per pass
+  static constexpr int P = TR / RP;
+  uint4 x[P];
+  __device__ __forceinline__ void issue(const unsigned short* __restrict__ w, long long base, long long ld, int nvalid_rows, int k0, int tid) {
+    const int ch = tid % CH, rin = tid / CH;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int r = p * RP + rin;
+      const long long rr = (r < nvalid_rows) ? r : (nvalid_rows - 1);
+      x[p] = *reinterpret_cast<const uint4*>(w + base + rr * ld + k0 + ch * 8);
+    }
+  }
+  __device__ __forceinline__ void pin() {
+#pragma unroll
+    for (int p = 0; p < P; ++p) asm volatile("" : "+v"(x[p].x), "+v"(x[p].y), "+v"(x[p].z), "+v"(x[p].w));
+  }
+  __device__ __forceinline__ void finish(__bf16* __restrict__ Thi, int nvalid_rows, int tid) {
+    constexpr int PITCH = Geo<BK>::PITCH;
+    const int ch = tid % CH, rin = tid / CH;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+      const int r = p * RP + rin;
+      const uint4 v = (r < nvalid_rows) ? x[p] : make_uint4(0u, 0u, 0u, 0u);
+      *reinterpret_cast<uint4*>(Thi + r * PITCH + ch * 8) = v;
+    }
+  }
+};
+
 // ---- MFMA over one staged chunk ------------------------------------------------------------------------
 template <int MT, int NT, int BK, int NS>
 __device__ __forceinline__ void mma_chunk(f32x16 (&acc)[MT][NT], const __bf16* Ahi, const __bf16* Alo, const __bf16* Bhi,
@@ -517,7 +552,7 @@ __global__ __launch_bounds__(256) void wgrad_batch_kernel(const WgradBatch wb) {
 
 // ---- the kernel ----------------------------------------------------------------------------------------
 // 256 threads = 4 waves arranged 2 (rows) x 2 (cols); wave tile (BM/2) x (BN/2) = MT x NT MFMA tiles.
-template <int BM, int BN, int NS, int MODE, bool A2, int EPI, bool ADD, bool MASK, bool AH, bool S16>
+template <int BM, int BN, int NS, int MODE, bool A2, int EPI, bool ADD, bool MASK, bool AH, bool S16, bool W16 = false>
 __device__ __forceinline__ void rows_tile_t(const GemmArgs& g, const int bx, const int by, unsigned char* lds_raw) {
   constexpr int BK = (NS == 3) ? 32 : 64;
   constexpr int PITCH = Geo<BK>::PITCH;
@@ -557,9 +592,12 @@ __device__ __forceinline__ void rows_tile_t(const GemmArgs& g, const int bx, con
   NatStage<BM, BK, A2, AH> sa;
   TrnStage<BN, BK, false, false> sbT;      // FWD: weights W[k][j], k slow
   NatStage<BN, BK, false, false> sbN;      // BWD: weights W[j][k], k fast
+  CopyStage<BN, BK> sbC;                   // W16: the prepared bf16 copy, rows j, k fast (either direction)
   auto issue_chunk = [&](int k0) {
     if (!(g.dbg & 4)) sa.issue(g.a, row0 * g.a.ld, nrows, k0, tid);
-    if (MODE == MODE_FWD) {
+    if constexpr (W16) {
+      sbC.issue(g.w16, (long long)col0 * g.K, g.K, g.C - col0, k0, tid);
+    } else if (MODE == MODE_FWD) {
       if (!(g.dbg & 8)) sbT.issue(wop, wbase + (long long)k0 * g.C + col0, BK, g.C - col0, tid);
     } else {
       sbN.issue(wop, wbase + (long long)col0 * g.K, g.C - col0, k0, tid);
@@ -569,7 +607,10 @@ __device__ __forceinline__ void rows_tile_t(const GemmArgs& g, const int bx, con
   for (int k0 = 0; k0 < g.K; k0 += BK) {
     sa.pin();
     sa.template finish<NS>(Ahi, Alo, g.a, nrows, k0, tid);
-    if (MODE == MODE_FWD) {
+    if constexpr (W16) {
+      sbC.pin();
+      sbC.finish(Bhi, g.C - col0, tid);
+    } else if (MODE == MODE_FWD) {
       sbT.pin();
       sbT.template finish<NS>(Bhi, Blo, wop, BK, g.C - col0, 0, tid);
     } else {
@@ -715,6 +756,13 @@ __global__ __launch_bounds__(256, (MODE == MODE_FWD && EPI == EPI_STORE) ? 2 : 1
     }
     // the storage types of the operand and of the epilogue's tensors are block-uniform: one switch, outside every loop
     if (g.a.h16) {
+      if constexpr (NS == 1 && EPI == EPI_STORE) {
+        if (g.w16) {                       // bf16 activations and the prepared bf16 kernel copy: the model plan's 'bf16' mode
+          if (g.store16) rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, true, true, true>(g, bx, by, lds_raw);
+          else rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, true, false, true>(g, bx, by, lds_raw);
+          return;
+        }
+      }
       if (EPI == EPI_STORE && g.store16) rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, true, EPI == EPI_STORE>(g, bx, by, lds_raw);
       else rows_tile_t<BM, BN, NS, MODE, A2, EPI, ADD, MASK, true, false>(g, bx, by, lds_raw);
     } else {
@@ -779,7 +827,7 @@ static int dispatch_bwd(const GemmArgs& g, int prec, hipStream_t st) {
 }
 
 int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, int K, int C, const float* cloud_bias,
-             float* z, float* stat_partials, int prec, hipStream_t st) {
+             float* z, float* stat_partials, int prec, hipStream_t st, const void* w16) {
   PN_TRY(check_operand(x, "pn_conv_fwd.x"));
   PN_CHECK_ARG(!x->s2, "pn_conv_fwd: the forward operand has no second source");
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_fwd: B and N must be positive (B=%d N=%d)", B, N);
@@ -796,6 +844,8 @@ int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, i
   g.a = *x; g.w = w; g.w_cloud_stride = wcs; g.B = B; g.N = N; g.K = K; g.C = C;
   g.tiles_per_cloud = cdiv(N, 128);
   g.out = z; g.cloud_bias = cloud_bias; g.stat_partials = stat_partials;
+  if (w16 && wcs == 0 && prec == PN_PREC_BF16 && x->h16 && (reinterpret_cast<uintptr_t>(w16) & 15) == 0 && K % 8 == 0)
+    g.w16 = reinterpret_cast<const unsigned short*>(w16);
   static const int dbg = getenv("PN_GEMM_DBG") ? atoi(getenv("PN_GEMM_DBG")) : 0;
   g.dbg = dbg;
   return dispatch_rows<MODE_FWD, false, EPI_STORE>(g, prec, st);
@@ -821,7 +871,7 @@ int conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C
 
 int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, int N, int K, int C, const float* addend,
                   const float* zmask, const float* msc, const float* msh, float* out, float* stat_partials, int prec,
-                  hipStream_t st) {
+                  hipStream_t st, const void* w16) {
   PN_TRY(check_operand(dz, "pn_conv_bwd_data.dz"));
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_bwd_data: B and N must be positive");
   PN_CHECK_ARG(K >= 64 && K % 64 == 0, "pn_conv_bwd_data: K must be a multiple of 64 (K=%d)", K);
@@ -838,6 +888,8 @@ int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, in
   g.a = *dz; g.w = w; g.w_cloud_stride = wcs; g.B = B; g.N = N; g.K = K; g.C = C;
   g.tiles_per_cloud = cdiv(N, 128);
   g.out = out; g.addend = addend; g.zmask = zmask; g.msc = msc; g.msh = msh; g.stat_partials = stat_partials;
+  if (w16 && wcs == 0 && prec == PN_PREC_BF16 && dz->h16 && (reinterpret_cast<uintptr_t>(w16) & 15) == 0 && K % 8 == 0)
+    g.w16 = reinterpret_cast<const unsigned short*>(w16);
   if (dz->s2) return dispatch_bwd<true>(g, prec, st);
   return dispatch_bwd<false>(g, prec, st);
 }

@@ -5,13 +5,15 @@
 namespace pn {
 
 // pn_gemm.hip
+// w16 (optional; used with bf16 operands, bf16 activations and a shared kernel): a bf16 copy of the kernel laid out [C][K] with k
+// contiguous -- for conv_fwd the TRANSPOSED kernel, for conv_bwd_data the kernel as it is -- staged without conversion (pn_prologue.hip)
 int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, int K, int C, const float* cloud_bias, float* z,
-             float* stat_partials, int prec, hipStream_t st);
+             float* stat_partials, int prec, hipStream_t st, const void* w16 = nullptr);
 int conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C, const float* sgn, float* pmax, int* pidx,
                  float* stat_partials, int prec, hipStream_t st);
 int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, int N, int K, int C, const float* addend,
                   const float* zmask, const float* msc, const float* msh, float* out, float* stat_partials, int prec,
-                  hipStream_t st);
+                  hipStream_t st, const void* w16 = nullptr);
 // weight-gradient jobs whose launches are grouped by tile shape (pn_gemm.hip: conv_wgrad_batch)
 struct WgradDesc {
   pn_operand a, b;
@@ -37,10 +39,17 @@ int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const f
 int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st);
 // normalisation + fragment-ordered copies of three kernels (+ zero_u cleared) + optionally the gradient buffer cleared (grads) and the
 // dropout masks drawn (step): one launch
+// + bf16 copies (as it is / transposed) of up to PN_WCOPY_MAX kernels (K, C) for the row GEMMs' CopyStage
+constexpr int PN_WCOPY_MAX = 12;
+struct WCopyDesc {
+  const float* w;
+  void *nat, *tr;
+  int K, C;
+};
 int fwd_prologue(const float* xyz, int B, int N, float* out, float* centroid, float* scale, const float* const* w, const float* const* sgn,
                  const int* K, const int* C, void* const* hi, void* const* lo, unsigned* zero_u, int zero_u_n, float* grads, long long n_grads,
                  unsigned char* k1, long long n1, unsigned char* k2, long long n2, float rate, unsigned long long seed, unsigned* step,
-                 hipStream_t st);
+                 const WCopyDesc* wcopies, int n_wcopies, hipStream_t st);
 
 // pn_pointwise.hip
 // Rm: optional per-cloud 3x3 matrices folded into the (shared, wcs = 0) kernel on the fly, w_eff[b] = Rm[b] @ w, also written to
@@ -155,6 +164,9 @@ int mse(const float* R, const float* T, int n, float gscale, float* dR, float* l
 int orth_reg(const float* R, int B, int K, float c, float* dR, float* loss_part, hipStream_t st);
 int fold3_fwd(const float* R, const float* W, int B, int C, float* Weff, hipStream_t st, float* R_copy = nullptr);
 int fold3_bwd(const float* dWeff, const float* R, const float* W, int B, int C, float* dR, float* dW, hipStream_t st);
+// the same from the per-tile slabs of conv3_wgrad (n_slabs = B * tpc, cloud-major): slab reduction and both gradients in one launch
+int fold3_bwd_slabs(const float* slabs, int n_slabs, int tpc, const float* R, const float* W, int B, int C, float* dR, float* dW,
+                    hipStream_t st);
 int fill_eye3(float* out, int B, hipStream_t st);
 int axpy(const float* x, float a, float* y, long long n, hipStream_t st);
 int count_nonfinite(const float* x, long long n, int* count, hipStream_t st, int h16 = 0);

@@ -125,7 +125,8 @@ struct Arena {
 struct CL {   // per-point conv layer state
   float *Z = nullptr, *part = nullptr, *mean = nullptr, *invstd = nullptr, *scale = nullptr, *shift = nullptr;
   float *ca = nullptr, *cb = nullptr, *cc = nullptr, *dy = nullptr;
-  int C = 0;
+  unsigned short *w16 = nullptr, *wt16 = nullptr;   // bf16 copies of the layer's (K, C) kernel, as it is / transposed (bf16 mode, K >= 64)
+  int C = 0, K = 0;
 };
 struct ML {   // extra state of a max-pooled layer
   float *pmax, *sumsq, *pa1, *g, *zstar, *hs, *e, *nege, *f, *a1part, *a1, *gram, *GW, *Pm, *q, *D, *Wt, *We, *dG;
@@ -187,9 +188,14 @@ static float* plan_act(Arena& A, const std::string& name, size_t elems, bool s16
   if (s16) return reinterpret_cast<float*>(A.get<unsigned short>(name.c_str(), elems));
   return A.get<float>(name.c_str(), elems);
 }
-static void plan_cl(Arena& A, CL& l, const char* nm, long long M, int T, int C, bool store_z, bool training, bool s16) {
+static void plan_cl(Arena& A, CL& l, const char* nm, long long M, int T, int C, bool store_z, bool training, bool s16, int K = 0) {
   std::string n(nm);
   l.C = C;
+  l.K = K;
+  if (s16 && K >= 64 && store_z) {       // the row GEMMs of this layer stage prepared bf16 copies of its kernel
+    l.w16 = A.get<unsigned short>((n + ".w16").c_str(), (size_t)K * C);
+    l.wt16 = A.get<unsigned short>((n + ".wt16").c_str(), (size_t)K * C);
+  }
   l.Z = store_z ? plan_act(A, n + ".Z", (size_t)M * C, s16) : nullptr;
   l.part = A.get<float>((n + ".part").c_str(), (size_t)T * 2 * C);
   l.mean = A.get<float>((n + ".mean").c_str(), C);
@@ -252,8 +258,8 @@ static void plan_dl(Arena& A, DLs& d, const char* nm, int B, int K, int C, bool 
 static void plan_tn(Arena& A, TN& t, const char* nm, int B, int N, long long M, int T, int K, bool training, int prec) {
   std::string n(nm);
   const bool s16 = (prec & PN_STORE_BF16) != 0;
-  plan_cl(A, t.c1, (n + ".c1").c_str(), M, T, 64, true, training, s16);
-  plan_cl(A, t.c2, (n + ".c2").c_str(), M, T, 128, true, training, s16);
+  plan_cl(A, t.c1, (n + ".c1").c_str(), M, T, 64, true, training, s16, K == 64 ? 64 : 0);
+  plan_cl(A, t.c2, (n + ".c2").c_str(), M, T, 128, true, training, s16, 64);
   plan_cl(A, t.c3, (n + ".c3").c_str(), M, 1, 1024, false, training, s16);            // statistics live in the panel buffers (plan_ml)
   plan_ml(A, t.m3, (n + ".m3").c_str(), B, N, M, T, 128, 1024, training, prec);
   plan_dl(A, t.d1, (n + ".d1").c_str(), B, 1024, 512, training);
@@ -277,15 +283,15 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
     plan_tn(A, w.fT, "fT", B, N, M, T, 64, training, d.prec);
   }
   plan_cl(A, w.m11, "m11", M, T, 64, true, training, s16);
-  plan_cl(A, w.m12, "m12", M, T, 64, true, training, s16);
-  plan_cl(A, w.m21, "m21", M, T, 64, true, training, s16);
-  plan_cl(A, w.m22, "m22", M, T, 128, true, training, s16);
+  plan_cl(A, w.m12, "m12", M, T, 64, true, training, s16, 64);
+  plan_cl(A, w.m21, "m21", M, T, 64, true, training, s16, 64);
+  plan_cl(A, w.m22, "m22", M, T, 128, true, training, s16, 64);
   plan_cl(A, w.m23, "m23", M, 1, 1024, false, training, s16);                            // statistics live in the panel buffers (plan_ml)
   plan_ml(A, w.mm23, "mm23", B, N, M, T, 128, 1024, training, d.prec);
-  plan_cl(A, w.s1, "s1", M, T, 512, true, training, s16);
-  plan_cl(A, w.s2, "s2", M, T, 256, true, training, s16);
-  plan_cl(A, w.s3, "s3", M, T, 128, true, training, s16);
-  plan_cl(A, w.s4, "s4", M, T, 128, true, training, s16);
+  plan_cl(A, w.s1, "s1", M, T, 512, true, training, s16, 64);      // the 64 per-point rows of seg_l1's (1088, 512) kernel
+  plan_cl(A, w.s2, "s2", M, T, 256, true, training, s16, 512);
+  plan_cl(A, w.s3, "s3", M, T, 128, true, training, s16, 256);
+  plan_cl(A, w.s4, "s4", M, T, 128, true, training, s16, 128);
   plan_dl(A, w.c1, "c1", B, 1024, 512, training);
   plan_dl(A, w.c2, "c2", B, 512, 256, training);
   plan_dl(A, w.c3, "c3", B, 256, d.ccls, training);
@@ -489,7 +495,7 @@ struct Run {
   }
   int fwd_conv(CL& l, const LRef& r, const pn_operand& x, const float* W, long long wcs, const float* cloud_bias) {
     PN_TRY(conv_fwd(&x, W, wcs, B, N, r.cin, r.cout, cloud_bias, l.Z, bn_batch(r.block) ? l.part : nullptr, prec,
-                    st));
+                    st, (wcs == 0 && W == p(r.kernel)) ? l.wt16 : nullptr));
     return bn_fin(l, r);
   }
   int fwd_max(CL& l, ML& m, const LRef& r, const pn_operand& x, int prof_slot) {
@@ -539,12 +545,25 @@ struct Run {
       const float* sgs[3] = {d.vanilla ? nullptr : p(L.iT.c3.gamma), d.vanilla ? nullptr : p(L.fT.c3.gamma), p(L.m23.gamma)};
       // copies carry sign(gamma): max(sgn*z) needs no multiply.  The same launch normalises the clouds and, when the caller asks,
       // clears the gradient buffer and draws the dropout masks (pn_prologue.hip)
+      // + the bf16 copies of the other per-point kernels for the row GEMMs (bf16 mode)
+      WCopyDesc wc[PN_WCOPY_MAX];
+      int nwc = 0;
+      auto add_wc = [&](const CL& l, const float* Wk) {
+        if (l.w16 && nwc < PN_WCOPY_MAX) wc[nwc++] = WCopyDesc{Wk, l.w16, l.wt16, l.K, l.C};
+      };
+      if (!d.vanilla) {
+        add_wc(w.iT.c2, p(L.iT.c2.kernel));
+        add_wc(w.fT.c1, p(L.fT.c1.kernel));
+        add_wc(w.fT.c2, p(L.fT.c2.kernel));
+      }
+      add_wc(w.m12, p(L.m12.kernel)); add_wc(w.m21, p(L.m21.kernel)); add_wc(w.m22, p(L.m22.kernel));
+      add_wc(w.s1, p(L.s1.kernel)); add_wc(w.s2, p(L.s2.kernel)); add_wc(w.s3, p(L.s3.kernel)); add_wc(w.s4, p(L.s4.kernel));
       const bool zg = training && G && io.zero_grads_in_forward;
       const bool dm = training && io.dropout_step && io.keep1 && io.keep2 && d.dropout_rate > 0.f;
       PN_TRY(fwd_prologue(io.pc, B, N, w.pcn, w.cent, w.scl, ws, sgs, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS, zg ? G : nullptr,
                           zg ? L.total : 0, dm ? const_cast<unsigned char*>(io.keep1) : nullptr, dm ? (long long)B * 512 : 0,
                           dm ? const_cast<unsigned char*>(io.keep2) : nullptr, dm ? (long long)B * 256 : 0, d.dropout_rate, io.dropout_seed,
-                          dm ? io.dropout_step : nullptr, st));
+                          dm ? io.dropout_step : nullptr, wc, nwc, st));
     }
     if (!d.vanilla) {
       PN_TRY(fwd_tnet(w.iT, L.iT, nullptr));
@@ -583,7 +602,7 @@ struct Run {
     // segmentation head (PointNet.py:268-290)
     const float* Ws1 = p(L.s1.kernel);
     // seg_l1 always emits its forward partials: the backward needs the per-cloud sums of z
-    PN_TRY(conv_fwd(&x64, Ws1, 0, B, N, 64, 512, w.gb, w.s1.Z, w.s1.part, prec, st));
+    PN_TRY(conv_fwd(&x64, Ws1, 0, B, N, 64, 512, w.gb, w.s1.Z, w.s1.part, prec, st, w.s1.wt16));
     PN_TRY(bn_fin(w.s1, L.s1));
     PN_TRY(fwd_conv(w.s2, L.s2, lazy(w.s1), p(L.s2.kernel), 0, nullptr));
     PN_TRY(fwd_conv(w.s3, L.s3, lazy(w.s2), p(L.s3.kernel), 0, nullptr));
@@ -680,7 +699,8 @@ struct Run {
       PN_TRY(side([=] { return wgrad_to(prev_act, dz, ci, cj, out, false, true); }));
       PN_TRY(flush());
     }
-    return conv_bwd_data(&dz, p(rc.kernel), 0, B, N, rc.cout, rc.cin, nullptr, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st);
+    return conv_bwd_data(&dz, p(rc.kernel), 0, B, N, rc.cout, rc.cin, nullptr, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st,
+                         cur.w16);
   }
   // backward of a max-pooled layer: dG (B,C) -> prev.dy (+stats in w.bpart), this layer's parameter gradients
   int bwd_max(CL& l, ML& m, const LRef& r, const pn_operand& xop, CL& prev, const float* dG, const float* dG2 = nullptr) {
@@ -858,7 +878,7 @@ struct Run {
       }
       PN_TRY(dense_plain(w.dgb, 512, Ws1 + 64 * 512, 512, true, 512, 1024, nullptr, w.dGseg));
       have_dGseg = true;
-      PN_TRY(conv_bwd_data(&dz1, Ws1, 0, B, N, 512, 64, nullptr, nullptr, nullptr, nullptr, w.dX64, nullptr, prec, st));
+      PN_TRY(conv_bwd_data(&dz1, Ws1, 0, B, N, 512, 64, nullptr, nullptr, nullptr, nullptr, w.dX64, nullptr, prec, st, w.s1.w16));
       have_dx64 = true;
     }
 
@@ -889,10 +909,10 @@ struct Run {
       }
       if (d.vanilla) {
         PN_TRY(conv_bwd_data(&dz21, p(L.m21.kernel), 0, B, N, 64, 64, have_dx64 ? w.dX64 : nullptr, w.m12.Z, w.m12.scale, w.m12.shift,
-                             w.m12.dy, w.bpart, prec, st));
+                             w.m12.dy, w.bpart, prec, st, w.m21.w16));
       } else {
         PN_TRY(conv_bwd_data(&dz21, p(L.m21.kernel), 0, B, N, 64, 64, have_dx64 ? w.dX64 : nullptr, nullptr, nullptr, nullptr, w.dX64,
-                             nullptr, prec, st));
+                             nullptr, prec, st, w.m21.w16));
       }
     }
     if (!d.vanilla) {
@@ -909,7 +929,7 @@ struct Run {
       PN_TRY(bwd_tnet(w.fT, L.fT, &a12));
       const pn_operand dzf1 = dzop(w.fT.c1);
       PN_TRY(conv_bwd_data(&dzf1, p(L.fT.c1.kernel), 0, B, N, 64, 64, have_dx ? w.tmpA12 : nullptr, w.m12.Z, w.m12.scale, w.m12.shift,
-                           w.m12.dy, w.bpart, prec, st));
+                           w.m12.dy, w.bpart, prec, st, w.fT.c1.w16));
     }
     }   // phase != 2
     if (phase == 1) return PN_OK;
@@ -923,8 +943,8 @@ struct Run {
       return PN_OK;
     }
     PN_TRY(conv3_wgrad(w.pcn, &dz11, B, N, 64, cur_slabs(), st));
-    PN_TRY(slab_reduce(cur_slabs(), T, tpc, 3 * 64, w.dWeff1, st));
-    PN_TRY(fold3_bwd(w.dWeff1, w.iT.R, p(L.m11.kernel), B, 64, w.iT.dR, tr(BLK_M11) ? gr(L.m11.kernel) : nullptr, st));
+    // d(W_eff) per cloud = sum of its tiles' slabs; dR and dW of W_eff[b] = R[b] W follow in the same launch
+    PN_TRY(fold3_bwd_slabs(cur_slabs(), T, tpc, w.iT.R, p(L.m11.kernel), B, 64, w.iT.dR, tr(BLK_M11) ? gr(L.m11.kernel) : nullptr, st));
     // ---- input transform ----
     if (d_R) PN_TRY(axpy(d_R, 1.f, w.iT.dR, (long long)B * 9, st));
     if (io.se3 && io.loss_weights[2] != 0.f && !d_R)

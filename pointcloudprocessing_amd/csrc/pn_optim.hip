@@ -184,6 +184,55 @@ __global__ __launch_bounds__(256) void fold3_bwd_kernel(const float* __restrict_
   dW[t] = s;
 }
 
+// The same two gradients straight from the per-tile slabs conv3_wgrad leaves (slabs[t][i][c], t = cloud * tpc + tile): one launch
+// instead of a slab reduction followed by fold3_bwd.  Blocks [0, B): cloud b's dWeff = sum of its tpc slabs (LDS), then dR[b] as above.
+// Blocks [B, B + 3C): one per dW element (k, c): thread <-> slab, dW[k][c] = sum_t sum_i R[cloud(t)][i][k] slabs[t][i][c], combined in a
+// fixed order (wave butterflies, then the four waves in turn).
+__global__ __launch_bounds__(256) void fold3_bwd_slabs_kernel(const float* __restrict__ slabs, int n_slabs, int tpc, const float* __restrict__ R,
+                                                              const float* __restrict__ W, int B, int C, float* __restrict__ dR,
+                                                              float* __restrict__ dW) {
+  __shared__ float dws[3 * 256];
+  __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x < B) {
+    if (!dR) return;
+    const int b = blockIdx.x;
+    for (int t = threadIdx.x; t < 3 * C; t += 256) {
+      float s = 0.f;
+      for (int t0 = 0; t0 < tpc; t0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = slabs[((long long)b * tpc + min(t0 + u, tpc - 1)) * 3 * C + t];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += (t0 + u < tpc) ? v[u] : 0.f;
+      }
+      dws[t] = s;
+    }
+    __syncthreads();
+    for (int ik = wave; ik < 9; ik += 4) {
+      const int i = ik / 3, k = ik % 3;
+      float s = 0.f;
+      for (int c = lane; c < C; c += 64) s = fmaf(dws[i * C + c], W[k * C + c], s);
+      s = wave_sum(s);
+      if (lane == 0) dR[(long long)b * 9 + ik] = s;
+    }
+    return;
+  }
+  if (!dW) return;
+  const int o = (int)blockIdx.x - B, k = o / C, c = o - k * C;
+  float acc = 0.f;
+  for (int t = threadIdx.x; t < n_slabs; t += 256) {
+    const int b = t / tpc;
+    const float* sl = slabs + (long long)t * 3 * C + c;
+    const float* r = R + (long long)b * 9 + k;
+    acc = fmaf(r[6], sl[2 * C], fmaf(r[3], sl[C], fmaf(r[0], sl[0], acc)));
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) red[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) dW[o] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // y[i] = a*x[i] + y[i] / plain helpers
 __global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ x, float a, float* __restrict__ y, long long n) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -282,6 +331,14 @@ int fold3_fwd(const float* R, const float* W, int B, int C, float* Weff, hipStre
 int fold3_bwd(const float* dWeff, const float* R, const float* W, int B, int C, float* dR, float* dW, hipStream_t st) {
   if (!dR && !dW) return PN_OK;
   hipLaunchKernelGGL(fold3_bwd_kernel, dim3(B + cdiv(3 * C, 256)), dim3(256), 0, st, dWeff, R, W, B, C, dR, dW);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+int fold3_bwd_slabs(const float* slabs, int n_slabs, int tpc, const float* R, const float* W, int B, int C, float* dR, float* dW,
+                    hipStream_t st) {
+  PN_CHECK_ARG(slabs && R && W && n_slabs == B * tpc && C > 0 && 3 * C <= 3 * 256, "fold3_bwd_slabs: bad arguments");
+  if (!dR && !dW) return PN_OK;
+  hipLaunchKernelGGL(fold3_bwd_slabs_kernel, dim3(B + 3 * C), dim3(256), 0, st, slabs, n_slabs, tpc, R, W, B, C, dR, dW);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

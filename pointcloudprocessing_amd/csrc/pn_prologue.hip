@@ -2,10 +2,11 @@
 //   * PointCloudNormalization (pointnet/PointNet.py:691-706),
 //   * the fragment-ordered bf16 copies of the three 128->1024 kernels for the panel kernel (pn_panel.hip),
 //   * the inverted-dropout keep masks of the classification head (PointNet.py:255,260),
-//   * the zero fill of the gradient buffer and of the dense layers' arrival counters.
-// Each exists as an entry point of its own (pn_normalize, pn_weights_prep, pn_dropout_masks, zero_fill) and, for the model plan, as
-// ONE launch whose workgroups take the four roles side by side (fwd_prologue): four dependent launches of ~5 us each, most of it
-// launch latency, become one.  Every body below is written for any workgroup size.
+//   * the zero fill of the gradient buffer and of the dense layers' arrival counters,
+//   * bf16 copies (as they are / transposed) of the other per-point layers' kernels for the row GEMMs (pn_gemm.hip: CopyStage).
+// The first four exist as entry points of their own (pn_normalize, pn_weights_prep, pn_dropout_masks, zero_fill) and, for the model
+// plan, all five are ONE launch whose workgroups take the roles side by side (fwd_prologue): four dependent launches of ~5 us each,
+// most of it launch latency, became one.  Every body below is written for any workgroup size.
 #include "pn_common.h"
 #include "pn_internal.h"
 
@@ -198,7 +199,52 @@ int zero_fill2(float* p, long long n, float* p2, int n2, hipStream_t st) {
   return PN_OK;
 }
 
-// ---- the four roles in one launch ------------------------------------------------------------------------------------------------
+// ---- the roles in one launch -------------------------------------------------------------------------------------------------------
+// bf16 copies of the per-point layers' kernels for the row GEMMs (pn_gemm.hip: CopyStage): `nat` = the kernel as it is, (K, C) with
+// the C outputs contiguous -- what the data-gradient GEMM stages (its contraction runs over the outputs); `tr` = transposed, (C, K)
+// with the K inputs contiguous -- what the forward GEMM stages.  Same round-to-nearest-even the GEMMs apply when they convert the
+// fp32 kernel themselves, so results do not change; a workgroup no longer converts 16-64 KB of kernel per launch.
+struct WCopyJobs {
+  const float* w[PN_WCOPY_MAX];
+  unsigned short* nat[PN_WCOPY_MAX];
+  unsigned short* tr[PN_WCOPY_MAX];
+  int K[PN_WCOPY_MAX], C[PN_WCOPY_MAX];
+  int end[PN_WCOPY_MAX];          // running element count
+  int n;
+};
+// work item = eight consecutive outputs of one of the two copies: items [0, E/8) write `nat` (8 consecutive elements of the kernel:
+// two 16-byte loads, one 16-byte store), items [E/8, E/4) write `tr` (8 consecutive k of one output column c: eight loads that are
+// coalesced across the lanes' columns, one 16-byte store); E = elements of all jobs (every K and C is a multiple of 8)
+__device__ __forceinline__ void wcopy_body(const WCopyJobs& j, int blk) {
+  const int total8 = (j.n ? j.end[j.n - 1] : 0) / 8;
+  const int item = blk * (int)blockDim.x + (int)threadIdx.x;
+  if (item >= 2 * total8) return;
+  const bool tr = item >= total8;
+  const int i8 = tr ? item - total8 : item;
+  int q = 0;
+  while (q + 1 < j.n && i8 * 8 >= j.end[q]) ++q;
+  const int local8 = i8 - (q ? j.end[q - 1] : 0) / 8;
+  const int K = j.K[q], C = j.C[q];
+  const float* __restrict__ w = j.w[q];
+  float v[8];
+  if (!tr) {
+    const float4 a0 = *reinterpret_cast<const float4*>(w + (long long)local8 * 8), a1 = *reinterpret_cast<const float4*>(w + (long long)local8 * 8 + 4);
+    v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+  } else {
+    const int c = local8 % C, k0 = (local8 / C) * 8;       // lanes walk the columns: each of the eight loads is coalesced
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = w[(long long)(k0 + e) * C + c];
+  }
+  pr_bf16x8 h;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) h[e] = (__bf16)v[e];
+  if (!tr) {
+    *reinterpret_cast<pr_bf16x8*>(j.nat[q] + (long long)local8 * 8) = h;
+  } else {
+    const int c = local8 % C, k0 = (local8 / C) * 8;
+    *reinterpret_cast<pr_bf16x8*>(j.tr[q] + (long long)c * K + k0) = h;
+  }
+}
 struct PrologueArgs {
   // normalisation: workgroups [0, B)
   const float* xyz; int B, N; float *out, *centroid, *scale;
@@ -210,6 +256,8 @@ struct PrologueArgs {
   float* grads; long long n_grads; int n_zero;
   // dropout masks: one more workgroup (0: not this launch's job)
   int n_drop; unsigned char *k1, *k2; long long n1, n2; float rate; unsigned seed_lo, seed_hi; unsigned* step;
+  // bf16 kernel copies for the row GEMMs: the last n_wcopy workgroups (1024 items of eight outputs each)
+  int n_wcopy; WCopyJobs wc;
 };
 __global__ __launch_bounds__(1024) void fwd_prologue_kernel(const PrologueArgs a) {
   __shared__ float red[16][3];
@@ -228,13 +276,16 @@ __global__ __launch_bounds__(1024) void fwd_prologue_kernel(const PrologueArgs a
   bx -= a.n_prep;
   if (bx < a.n_zero) { zero_body(a.grads, a.n_grads, bx, a.n_zero); return; }
   bx -= a.n_zero;
-  if (bx < a.n_drop) dropout_body(a.k1, a.n1, a.k2, a.n2, a.rate, a.seed_lo, a.seed_hi, a.step);
+  if (bx < a.n_drop) { dropout_body(a.k1, a.n1, a.k2, a.n2, a.rate, a.seed_lo, a.seed_hi, a.step); return; }
+  bx -= a.n_drop;
+  if (bx < a.n_wcopy) wcopy_body(a.wc, bx);
 }
 int fwd_prologue(const float* xyz, int B, int N, float* out, float* centroid, float* scale, const float* const* w, const float* const* sgn,
                  const int* K, const int* C, void* const* hi, void* const* lo, unsigned* zero_u, int zero_u_n, float* grads, long long n_grads,
                  unsigned char* k1, long long n1, unsigned char* k2, long long n2, float rate, unsigned long long seed, unsigned* step,
-                 hipStream_t st) {
+                 const WCopyDesc* wcopies, int n_wcopies, hipStream_t st) {
   PN_CHECK_ARG(xyz && out && B > 0 && N > 0, "fwd_prologue: bad cloud arguments");
+  PN_CHECK_ARG(n_wcopies >= 0 && n_wcopies <= PN_WCOPY_MAX && (n_wcopies == 0 || wcopies), "fwd_prologue: too many kernel copies");
   PN_CHECK_ARG(!grads || (n_grads >= 0 && (reinterpret_cast<uintptr_t>(grads) & 15) == 0), "fwd_prologue: unaligned gradient buffer");
   PN_CHECK_ARG(!step || ((n1 == 0 || k1) && (n2 == 0 || k2) && rate >= 0.f && rate < 1.f), "fwd_prologue: bad dropout arguments");
   PrologueArgs a;
@@ -254,7 +305,18 @@ int fwd_prologue(const float* xyz, int B, int N, float* out, float* centroid, fl
     a.n_drop = 1; a.k1 = k1; a.k2 = k2; a.n1 = n1; a.n2 = n2; a.rate = rate;
     a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.step = step;
   }
-  hipLaunchKernelGGL(fwd_prologue_kernel, dim3(B + a.n_prep + a.n_zero + a.n_drop), dim3(1024), 0, st, a);
+  int total = 0;
+  for (int i = 0; i < n_wcopies; ++i) {
+    const WCopyDesc& q = wcopies[i];
+    PN_CHECK_ARG(q.w && q.nat && q.tr && q.K > 0 && q.C > 0 && q.K % 8 == 0 && q.C % 8 == 0, "fwd_prologue: bad kernel-copy job");
+    a.wc.w[i] = q.w; a.wc.nat[i] = reinterpret_cast<unsigned short*>(q.nat); a.wc.tr[i] = reinterpret_cast<unsigned short*>(q.tr);
+    a.wc.K[i] = q.K; a.wc.C[i] = q.C;
+    total += q.K * q.C;
+    a.wc.end[i] = total;
+  }
+  a.wc.n = n_wcopies;
+  a.n_wcopy = cdiv(total / 4, 1024);                    // items of eight outputs, two copies: total / 4 items
+  hipLaunchKernelGGL(fwd_prologue_kernel, dim3(B + a.n_prep + a.n_zero + a.n_drop + a.n_wcopy), dim3(1024), 0, st, a);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
