@@ -27,6 +27,12 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in registers (HIP's uint4 struct does not)
 
+__device__ __forceinline__ float vmax3(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
 // ---- the panel kernel --------------------------------------------------------------------------------------------------------
 // Work split: every cloud is cut into `spc` (slots per cloud, panel_slots_per_cloud) contiguous runs of 64-row panels, one workgroup
 // per run, about one workgroup per CU in all.  A workgroup = 8 waves (two per SIMD, up to 256 VGPRs each).
@@ -236,10 +242,12 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
         }
         float mx;
         if (full) {
-          const float t0 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]), t1 = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
-          const float t2 = fmaxf(fmaxf(acc[6], acc[7]), acc[8]), t3 = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
-          const float t4 = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
-          mx = fmaxf(fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)), fmaxf(t4, acc[15]));       // v_max3_f32 tree
+          // eight instructions for sixteen values.  Written as v_max3_f32 by hand: through fmaxf the compiler first quiets every input
+          // (a v_max_f32 x, x per accumulator value -- 128 more vector instructions per panel and wave in a loop that is vector-ALU
+          // bound); the instruction itself already returns the other operand for a NaN, which is all fmaxf promises
+          const float t0 = vmax3(acc[0], acc[1], acc[2]), t1 = vmax3(acc[3], acc[4], acc[5]), t2 = vmax3(acc[6], acc[7], acc[8]);
+          const float t3 = vmax3(acc[9], acc[10], acc[11]), t4 = vmax3(acc[12], acc[13], acc[14]);
+          mx = vmax3(vmax3(t0, t1, t2), vmax3(t3, t4, acc[15]), -INFINITY);
         } else {
           mx = -INFINITY;
 #pragma unroll
