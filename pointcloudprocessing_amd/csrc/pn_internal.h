@@ -39,6 +39,14 @@ int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const f
 int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st);
 // normalisation + fragment-ordered copies of three kernels (+ zero_u cleared) + optionally the gradient buffer cleared (grads) and the
 // dropout masks drawn (step): one launch
+// + the BatchNormalization coefficients of up to PN_FROZEN_MAX layers that normalise with their MOVING statistics (inference, frozen
+//   layers: PointNet.py:585-591) -- they depend on nothing computed in the step, so they need no launch of their own
+constexpr int PN_FROZEN_MAX = 12;
+struct FrozenBnDesc {
+  const float *gamma, *beta, *mm, *mv;
+  float *mean, *invstd, *scale, *shift;
+  int C;
+};
 // + bf16 copies (as it is / transposed) of up to PN_WCOPY_MAX kernels (K, C) for the row GEMMs' CopyStage
 constexpr int PN_WCOPY_MAX = 12;
 struct WCopyDesc {
@@ -49,7 +57,7 @@ struct WCopyDesc {
 int fwd_prologue(const float* xyz, int B, int N, float* out, float* centroid, float* scale, const float* const* w, const float* const* sgn,
                  const int* K, const int* C, void* const* hi, void* const* lo, unsigned* zero_u, int zero_u_n, float* grads, long long n_grads,
                  unsigned char* k1, long long n1, unsigned char* k2, long long n2, float rate, unsigned long long seed, unsigned* step,
-                 const WCopyDesc* wcopies, int n_wcopies, hipStream_t st);
+                 const WCopyDesc* wcopies, int n_wcopies, const FrozenBnDesc* frozen, int n_frozen, float bn_eps, hipStream_t st);
 
 // pn_pointwise.hip
 // Rm: optional per-cloud 3x3 matrices folded into the (shared, wcs = 0) kernel on the fly, w_eff[b] = Rm[b] @ w, also written to

@@ -490,6 +490,7 @@ struct Run {
   // ---------------- forward pieces ----------------
   int bn_fin(const CL& l, const LRef& r, int n_tiles = -1) {
     const int ub = bn_batch(r.block) ? 1 : 0;
+    if (!ub) return PN_OK;       // moving statistics: the coefficients were written by the pass's first launch (fwd_prologue)
     return bn_finalize(l.part, n_tiles < 0 ? T : n_tiles, r.cout, M, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub, ub, l.mean,
                        l.invstd, l.scale, l.shift, st);
   }
@@ -558,12 +559,24 @@ struct Run {
       }
       add_wc(w.m12, p(L.m12.kernel)); add_wc(w.m21, p(L.m21.kernel)); add_wc(w.m22, p(L.m22.kernel));
       add_wc(w.s1, p(L.s1.kernel)); add_wc(w.s2, p(L.s2.kernel)); add_wc(w.s3, p(L.s3.kernel)); add_wc(w.s4, p(L.s4.kernel));
+      // + the coefficients of every per-point layer whose BatchNormalization uses its moving statistics (bn_fin skips those layers)
+      FrozenBnDesc fz[PN_FROZEN_MAX];
+      int nfz = 0;
+      auto add_fz = [&](const CL& l, const LRef& r) {
+        if (!bn_batch(r.block) && nfz < PN_FROZEN_MAX)
+          fz[nfz++] = FrozenBnDesc{p(r.gamma), p(r.beta), p(r.mm), p(r.mv), l.mean, l.invstd, l.scale, l.shift, r.cout};
+      };
+      if (!d.vanilla) {
+        add_fz(w.iT.c1, L.iT.c1); add_fz(w.iT.c2, L.iT.c2); add_fz(w.fT.c1, L.fT.c1); add_fz(w.fT.c2, L.fT.c2);
+      }
+      add_fz(w.m11, L.m11); add_fz(w.m12, L.m12); add_fz(w.m21, L.m21); add_fz(w.m22, L.m22);
+      add_fz(w.s1, L.s1); add_fz(w.s2, L.s2); add_fz(w.s3, L.s3); add_fz(w.s4, L.s4);
       const bool zg = training && G && io.zero_grads_in_forward;
       const bool dm = training && io.dropout_step && io.keep1 && io.keep2 && d.dropout_rate > 0.f;
       PN_TRY(fwd_prologue(io.pc, B, N, w.pcn, w.cent, w.scl, ws, sgs, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS, zg ? G : nullptr,
                           zg ? L.total : 0, dm ? const_cast<unsigned char*>(io.keep1) : nullptr, dm ? (long long)B * 512 : 0,
                           dm ? const_cast<unsigned char*>(io.keep2) : nullptr, dm ? (long long)B * 256 : 0, d.dropout_rate, io.dropout_seed,
-                          dm ? io.dropout_step : nullptr, wc, nwc, st));
+                          dm ? io.dropout_step : nullptr, wc, nwc, fz, nfz, d.bn_eps, st));
     }
     if (!d.vanilla) {
       PN_TRY(fwd_tnet(w.iT, L.iT, nullptr));

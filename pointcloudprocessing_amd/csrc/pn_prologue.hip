@@ -245,6 +245,24 @@ __device__ __forceinline__ void wcopy_body(const WCopyJobs& j, int blk) {
     *reinterpret_cast<pr_bf16x8*>(j.tr[q] + (long long)c * K + k0) = h;
   }
 }
+// coefficients of a layer that normalises with its moving statistics: the arithmetic of pn_bn_finalize with use_batch = 0
+struct FrozenBnJobs {
+  FrozenBnDesc j[PN_FROZEN_MAX];
+  int n;
+  float eps;
+};
+__device__ __forceinline__ void frozen_bn_body(const FrozenBnJobs& f, int q) {
+  const FrozenBnDesc& d = f.j[q];
+  for (int c = threadIdx.x; c < d.C; c += blockDim.x) {
+    const float mean = d.mm[c], var = d.mv[c];
+    const float invstd = 1.0f / sqrtf(var + f.eps);
+    const float sc = d.gamma[c] * invstd;
+    if (d.mean) d.mean[c] = mean;
+    if (d.invstd) d.invstd[c] = invstd;
+    d.scale[c] = sc;
+    d.shift[c] = d.beta[c] - mean * sc;
+  }
+}
 struct PrologueArgs {
   // normalisation: workgroups [0, B)
   const float* xyz; int B, N; float *out, *centroid, *scale;
@@ -256,8 +274,10 @@ struct PrologueArgs {
   float* grads; long long n_grads; int n_zero;
   // dropout masks: one more workgroup (0: not this launch's job)
   int n_drop; unsigned char *k1, *k2; long long n1, n2; float rate; unsigned seed_lo, seed_hi; unsigned* step;
-  // bf16 kernel copies for the row GEMMs: the last n_wcopy workgroups (1024 items of eight outputs each)
+  // bf16 kernel copies for the row GEMMs: the next n_wcopy workgroups (1024 items of eight outputs each)
   int n_wcopy; WCopyJobs wc;
+  // frozen BatchNormalization coefficients: one workgroup per layer
+  FrozenBnJobs fz;
 };
 __global__ __launch_bounds__(1024) void fwd_prologue_kernel(const PrologueArgs a) {
   __shared__ float red[16][3];
@@ -278,12 +298,15 @@ __global__ __launch_bounds__(1024) void fwd_prologue_kernel(const PrologueArgs a
   bx -= a.n_zero;
   if (bx < a.n_drop) { dropout_body(a.k1, a.n1, a.k2, a.n2, a.rate, a.seed_lo, a.seed_hi, a.step); return; }
   bx -= a.n_drop;
-  if (bx < a.n_wcopy) wcopy_body(a.wc, bx);
+  if (bx < a.n_wcopy) { wcopy_body(a.wc, bx); return; }
+  bx -= a.n_wcopy;
+  if (bx < a.fz.n) frozen_bn_body(a.fz, bx);
 }
 int fwd_prologue(const float* xyz, int B, int N, float* out, float* centroid, float* scale, const float* const* w, const float* const* sgn,
                  const int* K, const int* C, void* const* hi, void* const* lo, unsigned* zero_u, int zero_u_n, float* grads, long long n_grads,
                  unsigned char* k1, long long n1, unsigned char* k2, long long n2, float rate, unsigned long long seed, unsigned* step,
-                 const WCopyDesc* wcopies, int n_wcopies, hipStream_t st) {
+                 const WCopyDesc* wcopies, int n_wcopies, const FrozenBnDesc* frozen, int n_frozen, float bn_eps, hipStream_t st) {
+  PN_CHECK_ARG(n_frozen >= 0 && n_frozen <= PN_FROZEN_MAX && (n_frozen == 0 || frozen), "fwd_prologue: too many frozen layers");
   PN_CHECK_ARG(xyz && out && B > 0 && N > 0, "fwd_prologue: bad cloud arguments");
   PN_CHECK_ARG(n_wcopies >= 0 && n_wcopies <= PN_WCOPY_MAX && (n_wcopies == 0 || wcopies), "fwd_prologue: too many kernel copies");
   PN_CHECK_ARG(!grads || (n_grads >= 0 && (reinterpret_cast<uintptr_t>(grads) & 15) == 0), "fwd_prologue: unaligned gradient buffer");
@@ -316,7 +339,13 @@ int fwd_prologue(const float* xyz, int B, int N, float* out, float* centroid, fl
   }
   a.wc.n = n_wcopies;
   a.n_wcopy = cdiv(total / 4, 1024);                    // items of eight outputs, two copies: total / 4 items
-  hipLaunchKernelGGL(fwd_prologue_kernel, dim3(B + a.n_prep + a.n_zero + a.n_drop + a.n_wcopy), dim3(1024), 0, st, a);
+  for (int i = 0; i < n_frozen; ++i) {
+    PN_CHECK_ARG(frozen[i].gamma && frozen[i].beta && frozen[i].mm && frozen[i].mv && frozen[i].scale && frozen[i].shift && frozen[i].C > 0,
+                 "fwd_prologue: bad frozen-layer job");
+    a.fz.j[i] = frozen[i];
+  }
+  a.fz.n = n_frozen; a.fz.eps = bn_eps;
+  hipLaunchKernelGGL(fwd_prologue_kernel, dim3(B + a.n_prep + a.n_zero + a.n_drop + a.n_wcopy + n_frozen), dim3(1024), 0, st, a);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
