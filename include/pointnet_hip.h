@@ -55,6 +55,7 @@ typedef enum {
  * training step are its HBM traffic, and the contraction that consumes them rounds its operands to bf16 anyway under PN_PREC_BF16.
  * Operands say the same about their sources with pn_operand.h16.  Statistics are always taken from the fp32 values before rounding. */
 #define PN_STORE_BF16 0x100
+#define PN_IO_KEEP_ACTIVATIONS 1 /* pn_model_io.flags */
 
 typedef void* pn_stream; /* hipStream_t */
 
@@ -331,7 +332,11 @@ typedef struct pn_model_io {
    * gradient slot from "feature_transform.conv1.kernel" (pn_model_slot_info) to the end of the buffer is final; 2 = the rest (mlp_1,
    * input transform).  Lets a data-parallel caller all-reduce the large first bucket while phase 2 runs.  1 must precede 2. */
   int32_t bwd_phase;
-  int32_t pad3_;
+  /* bit 0 (PN_IO_KEEP_ACTIVATIONS): every layer leaves its stored output in the workspace.  Otherwise a segmentation head whose
+   * BatchNormalization layers all use their moving statistics and through which no gradient will flow (inference; a frozen head with
+   * loss weight 0 under the fused losses) runs as ONE launch that keeps its 512- / 256- / 128-wide activations on chip -- same
+   * outputs bit for bit, but the workspace entries s1..s4 are not written (set the bit to inspect them, e.g. for check_numerics). */
+  int32_t flags;
   /* optional (training, keep1 / keep2 given): draw the two keep masks inside pn_model_forward's first launch -- what
    * pn_dropout_masks(keep1, B*512, keep2, B*256, dropout_rate, dropout_seed, dropout_step) would write, counter increment
    * included -- instead of taking them as inputs.  dropout_step: device uint32 counter; NULL = the masks are inputs. */

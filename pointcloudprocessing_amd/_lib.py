@@ -16,6 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 PN_PREC_BF16 = 1
 PN_PREC_BF16X3 = 3
 PN_STORE_BF16 = 0x100      # or-ed into prec: the per-point layer-boundary tensors are stored as bf16
+PN_IO_KEEP_ACTIVATIONS = 1  # pn_model_io.flags: no vertical fusion of a frozen segmentation head (its activations stay inspectable)
 ABI_VERSION = 4            # PN_ABI_VERSION of include/pointnet_hip.h this binding was written against
 PN_NUM_BLOCKS = 15
 # "bf16": bf16 MFMA operands AND bf16 storage of the layer-boundary tensors (half the HBM traffic of a step);
@@ -55,7 +56,7 @@ class pn_model_io(C.Structure):
                 ("pad2_", C.c_float), ("out_cls", C.c_void_p), ("out_seg", C.c_void_p), ("out_R", C.c_void_p),
                 ("scalars", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("prof_events", C.POINTER(C.c_void_p)), ("aux_stream", C.c_void_p),
-                ("bwd_phase", C.c_int32), ("pad3_", C.c_int32), ("dropout_seed", C.c_uint64), ("dropout_step", C.c_void_p)]
+                ("bwd_phase", C.c_int32), ("flags", C.c_int32), ("dropout_seed", C.c_uint64), ("dropout_step", C.c_void_p)]
 
 
 # every symbol include/pointnet_hip.h declares: name -> (restype, argtypes)

@@ -116,6 +116,13 @@ int bmm3(const float* x, const float* R, int B, int N, float* out, hipStream_t s
 // pn_segout.hip
 int seg_out_fwd(const pn_operand* x, const float* w, const float* bias, long long M, int K, int C, const int* labels,
                 float grad_scale, float* probs, float* dlogits, float* part, hipStream_t st);
+// the whole segmentation head (seg_l1 .. output + softmax + loss) in one launch for a head that normalises with moving statistics;
+// part entries are per seg_head_fused_rows() rows (pn_segout.hip)
+int seg_head_fused_rows();
+int seg_head_fused(const pn_operand* x, const float* gb, const void* w1t, const void* w2t, const void* w3t, const void* w4t, const float* sc1,
+                   const float* sh1, const float* sc2, const float* sh2, const float* sc3, const float* sh3, const float* sc4, const float* sh4,
+                   const float* w5, const float* b5, int B, int N, int C, int s16, const int* labels, float grad_scale, float* probs,
+                   float* dlogits, float* part, hipStream_t st);
 int seg_out_part_stride();
 int seg_out_part_rows();
 int seg_out_bwd(const pn_operand* x, const float* w, const float* dlogits, int B, int N, int K, int C, float* dyhat, float* stat_part,

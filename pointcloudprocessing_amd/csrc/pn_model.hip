@@ -13,6 +13,7 @@
 //     per-cloud-weight contraction on the MFMA engine;
 //   * tile+concat in front of seg_l1 is never formed: seg_l1's kernel is split into its 64 per-point rows and
 //     its 1024 global rows, the latter applied once per cloud and added as a per-cloud bias.
+#include <algorithm>
 #include <cstdlib>
 #include <functional>
 #include <cstring>
@@ -299,7 +300,9 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
   w.X64 = d.vanilla ? nullptr : plan_act(A, "X64", (size_t)M * 64, s16);
   w.gb = A.get<float>("gb", (size_t)B * 512);
   w.cls_logits = A.get<float>("cls_logits", (size_t)B * d.ccls);
-  w.seg_part = A.get<float>("seg_part", (size_t)cdivll(M, seg_out_part_rows()) * seg_out_part_stride());
+  // per 128-row block of seg_out_fwd, or per 64-row tile of the fused frozen head (never straddling clouds)
+  w.seg_part = A.get<float>("seg_part", (size_t)std::max<long long>(cdivll(M, seg_out_part_rows()), (long long)B * cdiv(N, seg_head_fused_rows())) *
+                                            seg_out_part_stride());
   w.dense_part = A.get<float>("dense_part", (size_t)8 * B * 4096);          // split-K tiles of the dense layers (<= 8 splits)
   w.dcount = A.get<unsigned>("dcount", DENSE_MAX_COUNTERS);                 // their in-launch arrival counters
   w.R3eye = A.get<float>("R3eye", (size_t)B * 9);
@@ -459,6 +462,14 @@ struct Run {
   }
 
   bool tr(int block) const { return io.trainable ? io.trainable[block] != 0 : true; }
+  // the segmentation head as one launch (pn_segout.hip: seg_head_fused): its BatchNormalization layers all use moving statistics, no
+  // gradient will be asked through it, the bf16 kernel copies exist, and the caller does not want the layers' outputs kept
+  bool fused_seg_head() const {
+    if ((io.flags & PN_IO_KEEP_ACTIVATIONS) || !w.s1.wt16 || !w.s2.wt16 || !w.s3.wt16 || !w.s4.wt16) return false;
+    if (bn_batch(BLK_S1) || bn_batch(BLK_S2) || bn_batch(BLK_S3) || bn_batch(BLK_S4)) return false;
+    if (!training) return true;
+    return io.labels_seg != nullptr && io.loss_weights[1] == 0.f;
+  }
   bool bn_batch(int block) const { return training && tr(block); }
   float* p(long long off) const { return off >= 0 ? P + off : nullptr; }
   float* gr(long long off) const { return (G && off >= 0) ? G + off : nullptr; }
@@ -613,6 +624,15 @@ struct Run {
     const bool fused = io.labels_cls != nullptr;     // the softmax + loss of these logits: in the pass's last launch, below
 
     // segmentation head (PointNet.py:268-290)
+    const bool fseg = io.labels_seg != nullptr;
+    int seg_parts = (int)cdivll(M, seg_out_part_rows());
+    if (fused_seg_head()) {
+      // frozen head, no gradient through it: one launch, activations stay on chip (pn_segout.hip: seg_head_fused)
+      seg_parts = B * cdiv(N, seg_head_fused_rows());
+      PN_TRY(seg_head_fused(&x64, w.gb, w.s1.wt16, w.s2.wt16, w.s3.wt16, w.s4.wt16, w.s1.scale, w.s1.shift, w.s2.scale, w.s2.shift, w.s3.scale,
+                            w.s3.shift, w.s4.scale, w.s4.shift, p(L.s5.kernel), p(L.s5.bias), B, N, d.cseg, s16, io.labels_seg,
+                            fseg ? io.loss_weights[1] / (float)M : 0.f, io.out_seg, nullptr, fseg ? w.seg_part : nullptr, st));
+    } else {
     const float* Ws1 = p(L.s1.kernel);
     // seg_l1 always emits its forward partials: the backward needs the per-cloud sums of z
     PN_TRY(conv_fwd(&x64, Ws1, 0, B, N, 64, 512, w.gb, w.s1.Z, w.s1.part, prec, st, w.s1.wt16));
@@ -621,9 +641,9 @@ struct Run {
     PN_TRY(fwd_conv(w.s3, L.s3, lazy(w.s2), p(L.s3.kernel), 0, nullptr));
     PN_TRY(fwd_conv(w.s4, L.s4, lazy(w.s3), p(L.s4.kernel), 0, nullptr));
     const pn_operand a4 = lazy(w.s4);
-    const bool fseg = io.labels_seg != nullptr;
     PN_TRY(seg_out_fwd(&a4, p(L.s5.kernel), p(L.s5.bias), M, 128, d.cseg, io.labels_seg, fseg ? io.loss_weights[1] / (float)M : 0.f,
                        io.out_seg, (fseg && training) ? w.seg_dlogits : nullptr, fseg ? w.seg_part : nullptr, st));
+    }
     // third output: the input transform (PointNet.py:292); identity for vanilla (:211)
     if (io.out_R) {
       if (d.vanilla) {
@@ -635,7 +655,7 @@ struct Run {
       const bool sums = fseg && io.scalars;
       PN_TRY(loss_tail(w.cls_logits, B, d.ccls, io.labels_cls, fused ? io.loss_weights[0] / (float)B : 0.f, io.out_cls,
                        (fused && training) ? w.cls_dlogits : nullptr, io.scalars ? io.scalars + 0 : nullptr,
-                       io.scalars ? io.scalars + 1 : nullptr, sums ? w.seg_part : nullptr, sums ? (int)cdivll(M, seg_out_part_rows()) : 0,
+                       io.scalars ? io.scalars + 1 : nullptr, sums ? w.seg_part : nullptr, sums ? seg_parts : 0,
                        seg_out_part_stride(), sums ? 2 : 0, sums ? io.scalars + 2 : nullptr, Rp, io.se3, B * 9, Rp ? io.scalars + 4 : nullptr,
                        st));
     }
@@ -848,6 +868,11 @@ struct Run {
     const float* Ws1 = p(L.s1.kernel);
     const bool fused = io.labels_cls != nullptr || io.labels_seg != nullptr;
     bool has_seg = d_seg != nullptr || (io.labels_seg != nullptr && io.loss_weights[1] != 0.f);
+    if (has_seg && fused_seg_head()) {
+      set_error("pn_model_backward: a gradient through the segmentation head was asked for, but the forward pass ran the head fused "
+                "(frozen, loss weight 0) and kept none of its activations; set PN_IO_KEEP_ACTIVATIONS in pn_model_io.flags");
+      return PN_ERR_INVALID_ARGUMENT;
+    }
     bool has_cls = d_cls != nullptr || (io.labels_cls != nullptr && io.loss_weights[0] != 0.f);
     (void)fused;
     const bool have_R_grad = !d.vanilla && (d_R != nullptr || (io.se3 != nullptr && io.loss_weights[2] != 0.f) || d.reg_in);

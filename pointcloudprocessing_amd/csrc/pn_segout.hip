@@ -18,6 +18,67 @@ typedef __attribute__((ext_vector_type(8))) __bf16 seg_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float seg_f32x16;
 constexpr int SEG_WP = 128 + 8;   // LDS pitch (bf16) of the weight image: conflict-free 16-byte rows
 
+// logits of one point -> softmax, keras SparseCategoricalCrossentropy (probabilities clipped to [1e-7, 1 - 1e-7]), accuracy and
+// d(loss)/d(logits); shared by the stand-alone output kernel and the fused frozen head below
+__device__ __forceinline__ void seg_row_tail(const float (&acc)[SEG_CM], int C, long long row, const int* __restrict__ labels, float grad_scale,
+                                             float* __restrict__ probs, float* __restrict__ dlogits, float& loss, float& corr,
+                                             float (&dl)[SEG_CM]) {
+    float mx = -INFINITY;
+    int am = 0;
+#pragma unroll
+    for (int c = 0; c < SEG_CM; ++c)
+      if (c < C && acc[c] > mx) { mx = acc[c]; am = c; }
+    float p[SEG_CM];
+    float sum = 0.f;
+#pragma unroll
+    for (int c = 0; c < SEG_CM; ++c) {
+      p[c] = c < C ? expf(acc[c] - mx) : 0.f;
+      sum += p[c];
+    }
+    const float inv = 1.f / sum;
+#pragma unroll
+    for (int c = 0; c < SEG_CM; ++c) p[c] *= inv;
+    if (probs) {
+      float* po = probs + row * C;
+#pragma unroll
+      for (int c = 0; c < SEG_CM; ++c)
+        if (c < C) po[c] = p[c];
+    }
+    if (labels) {
+      const int y = labels[row];
+      float qs = 0.f, py = 1.f;
+#pragma unroll
+      for (int c = 0; c < SEG_CM; ++c)
+        if (c < C) {
+          const float pc = clip_nan(p[c], 1e-7f, 1.f - 1e-7f);
+          qs += pc;
+          if (c == y) py = pc;
+        }
+      loss = -(logf(py) - logf(qs));
+      corr = (am == y) ? 1.f : 0.f;
+      float dp[SEG_CM];
+      float dot = 0.f;
+#pragma unroll
+      for (int c = 0; c < SEG_CM; ++c) {
+        dp[c] = 0.f;
+        if (c < C) {
+          const float pc = clip_nan(p[c], 1e-7f, 1.f - 1e-7f);
+          const bool inr = (p[c] > 1e-7f) && (p[c] < 1.f - 1e-7f);
+          dp[c] = inr ? (pc / qs - (c == y ? 1.f : 0.f)) / p[c] : 0.f;
+          dot = fmaf(p[c], dp[c], dot);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < SEG_CM; ++c) dl[c] = c < C ? grad_scale * p[c] * (dp[c] - dot) : 0.f;
+      if (dlogits) {
+        float* d = dlogits + row * C;
+#pragma unroll
+        for (int c = 0; c < SEG_CM; ++c)
+          if (c < C) d[c] = dl[c];
+      }
+    }
+}
+
 template <int MF>
 __global__ __launch_bounds__(SEG_RPB) void seg_out_fwd_kernel(const pn_operand x, const float* __restrict__ w, const float* __restrict__ bias,
                                                           long long M, int K, int C, const int* __restrict__ labels, float grad_scale,
@@ -140,60 +201,7 @@ __global__ __launch_bounds__(SEG_RPB) void seg_out_fwd_kernel(const pn_operand x
         }
       }
     }
-    float mx = -INFINITY;
-    int am = 0;
-#pragma unroll
-    for (int c = 0; c < SEG_CM; ++c)
-      if (c < C && acc[c] > mx) { mx = acc[c]; am = c; }
-    float p[SEG_CM];
-    float sum = 0.f;
-#pragma unroll
-    for (int c = 0; c < SEG_CM; ++c) {
-      p[c] = c < C ? expf(acc[c] - mx) : 0.f;
-      sum += p[c];
-    }
-    const float inv = 1.f / sum;
-#pragma unroll
-    for (int c = 0; c < SEG_CM; ++c) p[c] *= inv;
-    if (probs) {
-      float* po = probs + row * C;
-#pragma unroll
-      for (int c = 0; c < SEG_CM; ++c)
-        if (c < C) po[c] = p[c];
-    }
-    if (labels) {
-      const int y = labels[row];
-      float qs = 0.f, py = 1.f;
-#pragma unroll
-      for (int c = 0; c < SEG_CM; ++c)
-        if (c < C) {
-          const float pc = clip_nan(p[c], 1e-7f, 1.f - 1e-7f);
-          qs += pc;
-          if (c == y) py = pc;
-        }
-      loss = -(logf(py) - logf(qs));
-      corr = (am == y) ? 1.f : 0.f;
-      float dp[SEG_CM];
-      float dot = 0.f;
-#pragma unroll
-      for (int c = 0; c < SEG_CM; ++c) {
-        dp[c] = 0.f;
-        if (c < C) {
-          const float pc = clip_nan(p[c], 1e-7f, 1.f - 1e-7f);
-          const bool inr = (p[c] > 1e-7f) && (p[c] < 1.f - 1e-7f);
-          dp[c] = inr ? (pc / qs - (c == y ? 1.f : 0.f)) / p[c] : 0.f;
-          dot = fmaf(p[c], dp[c], dot);
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < SEG_CM; ++c) dl[c] = c < C ? grad_scale * p[c] * (dp[c] - dot) : 0.f;
-      if (dlogits) {
-        float* d = dlogits + row * C;
-#pragma unroll
-        for (int c = 0; c < SEG_CM; ++c)
-          if (c < C) d[c] = dl[c];
-      }
-    }
+    seg_row_tail(acc, C, row, labels, grad_scale, probs, dlogits, loss, corr, dl);
   }
   if (part) {
     // block partials: loss, correct, sum_rows dlogits[c]
@@ -211,6 +219,282 @@ __global__ __launch_bounds__(SEG_RPB) void seg_out_fwd_kernel(const pn_operand x
       part[(long long)blockIdx.x * (2 + SEG_CM) + threadIdx.x] = redw[0][threadIdx.x] + redw[1][threadIdx.x];
     static_assert(SEG_RPB == 128, "two waves per block");
   }
+}
+
+// ---- the whole segmentation head in ONE launch, for a head whose BatchNormalization layers use their moving statistics -------------
+// (inference, and the reference's `classification_pretrain` profile where the head is frozen and only its loss value and accuracy
+// are reported, f15_lidar_config.json:43-69).  Without batch statistics nothing couples the points between layers, so a workgroup
+// takes a 64-row tile through seg_l1 (64 -> 512, + the per-cloud global-feature bias), seg_l2 (512 -> 256), seg_l3 (256 -> 128),
+// seg_l4 (128 -> 128) and the output layer + softmax + loss without the 512- / 256- / 128-wide tensors ever leaving the CU:
+//   * activations live in LDS as bf16 MFMA operands (seg_l1's output in four 128-channel chunks, each consumed at once as a K-chunk of
+//     seg_l2, whose 64 x 256 accumulators stay in registers); the kernels come straight from global memory as B fragments out of the
+//     transposed bf16 copies the step's first launch makes (one 16-byte load per lane and k-step, each wave its own columns);
+//   * every value is formed exactly as the layer-by-layer plan forms it (same k order per accumulator, bias before the store rounding,
+//     BatchNormalization + ReLU applied to the stored value, hi + lo operands for the output layer), so the two plans agree bit for
+//     bit -- tests/test_gpu_model.py compares them.
+// Five launches and ~67 MB of stored activations (C2) become one launch and none.
+constexpr int SH_ROWS = 64;
+constexpr int SH_P64 = 64 + 8, SH_P128 = 128 + 8, SH_P256 = 256 + 8;     // LDS pitches (bf16 elements): conflict-free 16-byte rows
+constexpr int SH_PF = 128 + 4;                                            // fp32 pitch of the output layer's input
+constexpr int SH_REGION_A = (SH_ROWS * SH_P64 + SH_ROWS * SH_P128) * 2;   // input tile + seg_l1 chunk; later seg_l3's output, then the
+                                                                          // output layer's kernel image and logit tile
+constexpr int SH_REGION_B = SH_ROWS * SH_P256 * 2;                        // seg_l2's output; later the output layer's fp32 input
+static_assert(SH_ROWS * SH_PF * 4 <= SH_REGION_B, "region B holds the fp32 input of the output layer");
+static_assert(2 * 32 * SEG_WP * 2 + SH_ROWS * (SEG_CM + 1) * 4 <= SH_REGION_A, "region A holds the output kernel image and the logit tile");
+struct SegHeadArgs {
+  pn_operand x;                                     // (B*N, 64) lazy operand: X_64 (or relu(bn(mlp_1_2)) for the vanilla model)
+  const float* gb;                                  // (B, 512) global-feature half of seg_l1, per cloud
+  const unsigned short *w1t, *w2t, *w3t, *w4t;      // bf16 transposed kernels [Cout][K]
+  const float *sc1, *sh1, *sc2, *sh2, *sc3, *sh3, *sc4, *sh4;   // BatchNormalization scale / shift (moving statistics)
+  const float *w5, *b5;                             // output layer (128, C) fp32, bias (C)
+  int N, C, tiles_per_cloud, s16;                   // s16: the layer-by-layer plan stores z as bf16 -- round the same way
+  const int* labels; float grad_scale; float *probs, *dlogits, *part;
+};
+__device__ __forceinline__ float sh_bnrelu(float z, float sc, float sh, int s16) {
+  const float zq = s16 ? bf16_bits_f32(f32_bf16_bits(z)) : z;
+  return clamp_lo(fmaf(sc, zq, sh), 0.f);
+}
+__global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char sh_sm[];
+  __bf16* Ain = reinterpret_cast<__bf16*>(sh_sm);
+  __bf16* S1c = Ain + SH_ROWS * SH_P64;
+  __bf16* S3 = reinterpret_cast<__bf16*>(sh_sm);
+  __bf16* S2 = reinterpret_cast<__bf16*>(sh_sm + SH_REGION_A);
+  float* S4f = reinterpret_cast<float*>(sh_sm + SH_REGION_A);
+  __bf16* W5hi = reinterpret_cast<__bf16*>(sh_sm);
+  __bf16* W5lo = W5hi + 32 * SEG_WP;
+  float* lgt = reinterpret_cast<float*>(sh_sm + 2 * 32 * SEG_WP * 2);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int cloud = blockIdx.x / a.tiles_per_cloud, tin = blockIdx.x - cloud * a.tiles_per_cloud;
+  const int r0 = tin * SH_ROWS, nrows = min(SH_ROWS, a.N - r0);
+  const long long row0 = (long long)cloud * a.N + r0;
+
+  // ---- the tile's 64 input channels -> LDS (bf16 operand precision; rows past the cloud are zero rows) ----
+  {
+    const int row = tid >> 2, c0 = (tid & 3) * 16;
+    float v[16];
+    const long long src = (row0 + min(row, nrows - 1)) * a.x.ld + c0;
+    if (a.x.h16) {
+      bf16x8_unpack(act_load8_raw(a.x.s1, src), *reinterpret_cast<float(*)[8]>(v));
+      bf16x8_unpack(act_load8_raw(a.x.s1, src + 8), *reinterpret_cast<float(*)[8]>(v + 8));
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(a.x.s1 + src + 4 * q);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+      }
+    }
+    seg_bf16x8 o0, o1;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float ca = a.x.ca ? a.x.ca[c0 + e] : 1.f, cc = a.x.cc ? a.x.cc[c0 + e] : 0.f;
+      const float t = row < nrows ? clamp_lo(fmaf(ca, v[e], cc), a.x.lo) : 0.f;
+      if (e < 8) o0[e] = (__bf16)t; else o1[e - 8] = (__bf16)t;
+    }
+    *reinterpret_cast<seg_bf16x8*>(Ain + row * SH_P64 + c0) = o0;
+    *reinterpret_cast<seg_bf16x8*>(Ain + row * SH_P64 + c0 + 8) = o1;
+  }
+  __syncthreads();
+
+  auto afrag = [&](const __bf16* img, int pitch, int m, int k0) {
+    return *reinterpret_cast<const seg_bf16x8*>(img + (m * 32 + r) * pitch + k0 + 8 * h);
+  };
+  auto bfrag = [&](const unsigned short* wt, int K, int col, int k0) {
+    return __builtin_bit_cast(seg_bf16x8, *reinterpret_cast<const uint4*>(wt + (long long)col * K + k0 + 8 * h));
+  };
+
+  // ---- seg_l1 in four 128-channel chunks, each at once a K-chunk of seg_l2 ----
+  seg_f32x16 acc2[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc2[m][n][e] = 0.f;
+  for (int j = 0; j < 4; ++j) {
+    seg_f32x16 acc1[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc1[m][e] = 0.f;
+    const int c1 = 128 * j + 32 * wave + r;                 // this lane's seg_l1 channel
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const seg_bf16x8 b = bfrag(a.w1t, 64, c1, ks * 16);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc1[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(Ain, SH_P64, m, ks * 16), b, acc1[m], 0, 0, 0);
+    }
+    {
+      const float bias = a.gb[(long long)cloud * 512 + c1], sc = a.sc1[c1], sh = a.sh1[c1];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int row = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          S1c[row * SH_P128 + 32 * wave + r] = (__bf16)sh_bnrelu(acc1[m][e] + bias, sc, sh, a.s16);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      seg_bf16x8 b[2];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) b[n] = bfrag(a.w2t, 512, 64 * wave + 32 * n + r, 128 * j + ks * 16);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const seg_bf16x8 af = afrag(S1c, SH_P128, m, ks * 16);
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b[n], acc2[m][n], 0, 0, 0);
+      }
+    }
+    __syncthreads();                                        // the chunk image is overwritten by the next chunk
+  }
+  // ---- seg_l2 -> LDS ----
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int c2 = 64 * wave + 32 * n + r;
+    const float sc = a.sc2[c2], sh = a.sh2[c2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        S2[row * SH_P256 + c2] = (__bf16)sh_bnrelu(acc2[m][n][e], sc, sh, a.s16);
+      }
+  }
+  __syncthreads();
+  // ---- seg_l3 (256 -> 128): 32 columns per wave ----
+  const int c3 = 32 * wave + r;
+  {
+    seg_f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 16; ++ks) {
+      const seg_bf16x8 b = bfrag(a.w3t, 256, c3, ks * 16);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(S2, SH_P256, m, ks * 16), b, acc[m], 0, 0, 0);
+    }
+    const float sc = a.sc3[c3], sh = a.sh3[c3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        S3[row * SH_P128 + c3] = (__bf16)sh_bnrelu(acc[m][e], sc, sh, a.s16);       // region A: the input tile and chunk image are dead
+      }
+  }
+  __syncthreads();
+  // ---- seg_l4 (128 -> 128) -> the output layer's input, fp32 (it is split hi + lo there, as in seg_out_fwd) ----
+  {
+    seg_f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const seg_bf16x8 b = bfrag(a.w4t, 128, c3, ks * 16);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(S3, SH_P128, m, ks * 16), b, acc[m], 0, 0, 0);
+    }
+    const float sc = a.sc4[c3], sh = a.sh4[c3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        S4f[row * SH_PF + c3] = sh_bnrelu(acc[m][e], sc, sh, a.s16);                 // region B: seg_l2's image is dead
+      }
+  }
+  __syncthreads();                                          // seg_l3's image (region A) is dead from here
+  // ---- output layer: kernel image (bf16 hi + lo, channel-major) into region A, logits of a 32-row block per wave (waves 0, 1) ----
+  for (int t = tid; t < 32 * 128; t += 256) {
+    const int c = t >> 7, k = t & 127;
+    const float v = c < a.C ? a.w5[(long long)k * a.C + c] : 0.f;
+    const __bf16 hi = (__bf16)v;
+    W5hi[c * SEG_WP + k] = hi;
+    W5lo[c * SEG_WP + k] = (__bf16)(v - (float)hi);
+  }
+  __syncthreads();
+  if (wave < 2) {
+    seg_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int k0 = ks * 16 + 8 * h;
+      const float4 v0 = *reinterpret_cast<const float4*>(S4f + (wave * 32 + r) * SH_PF + k0);
+      const float4 v1 = *reinterpret_cast<const float4*>(S4f + (wave * 32 + r) * SH_PF + k0 + 4);
+      const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      seg_bf16x8 ah, al;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        ah[e] = (__bf16)v[e];
+        al[e] = (__bf16)(v[e] - (float)ah[e]);
+      }
+      const seg_bf16x8 bh = *reinterpret_cast<const seg_bf16x8*>(W5hi + r * SEG_WP + k0);
+      const seg_bf16x8 bl = *reinterpret_cast<const seg_bf16x8*>(W5lo + r * SEG_WP + k0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+    if (r < SEG_CM) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) lgt[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * (SEG_CM + 1) + r] = acc[e];
+    }
+  }
+  __syncthreads();
+  // ---- softmax, loss, accuracy, d(logits): one thread per point (wave 0) ----
+  if (wave == 0) {
+    float loss = 0.f, corr = 0.f;
+    float dl[SEG_CM];
+#pragma unroll
+    for (int c = 0; c < SEG_CM; ++c) dl[c] = 0.f;
+    if (lane < nrows) {
+      float acc[SEG_CM];
+#pragma unroll
+      for (int c = 0; c < SEG_CM; ++c) {
+        acc[c] = (c < a.C && a.b5) ? a.b5[c] : 0.f;
+        acc[c] += lgt[lane * (SEG_CM + 1) + c];
+      }
+      seg_row_tail(acc, a.C, row0 + lane, a.labels, a.grad_scale, a.probs, a.dlogits, loss, corr, dl);
+    }
+    if (a.part) {
+      float* p = a.part + (long long)blockIdx.x * (2 + SEG_CM);
+      const float l = wave_sum(loss), cr = wave_sum(corr);
+      if (lane == 0) { p[0] = l; p[1] = cr; }
+#pragma unroll
+      for (int c = 0; c < SEG_CM; ++c) {
+        const float sdl = wave_sum(dl[c]);
+        if (lane == 0) p[2 + c] = sdl;
+      }
+    }
+  }
+}
+int seg_head_fused_rows() { return SH_ROWS; }
+int seg_head_fused(const pn_operand* x, const float* gb, const void* w1t, const void* w2t, const void* w3t, const void* w4t, const float* sc1,
+                   const float* sh1, const float* sc2, const float* sh2, const float* sc3, const float* sh3, const float* sc4, const float* sh4,
+                   const float* w5, const float* b5, int B, int N, int C, int s16, const int* labels, float grad_scale, float* probs,
+                   float* dlogits, float* part, hipStream_t st) {
+  PN_CHECK_ARG(x && x->s1 && !x->s2 && gb && w1t && w2t && w3t && w4t && sc1 && sh1 && sc2 && sh2 && sc3 && sh3 && sc4 && sh4 && w5,
+               "seg_head_fused: null pointer");
+  PN_CHECK_ARG(B > 0 && N > 0 && C >= 1 && C <= SEG_CM, "seg_head_fused: bad sizes (B=%d N=%d C=%d)", B, N, C);
+  PN_CHECK_ARG(x->ld >= 64 && x->ld % 8 == 0 && (reinterpret_cast<uintptr_t>(x->s1) & 15) == 0, "seg_head_fused: operand alignment");
+  SegHeadArgs a;
+  memset(&a, 0, sizeof(a));
+  a.x = *x; a.gb = gb;
+  a.w1t = reinterpret_cast<const unsigned short*>(w1t); a.w2t = reinterpret_cast<const unsigned short*>(w2t);
+  a.w3t = reinterpret_cast<const unsigned short*>(w3t); a.w4t = reinterpret_cast<const unsigned short*>(w4t);
+  a.sc1 = sc1; a.sh1 = sh1; a.sc2 = sc2; a.sh2 = sh2; a.sc3 = sc3; a.sh3 = sh3; a.sc4 = sc4; a.sh4 = sh4;
+  a.w5 = w5; a.b5 = b5; a.N = N; a.C = C; a.tiles_per_cloud = cdiv(N, SH_ROWS); a.s16 = s16;
+  a.labels = labels; a.grad_scale = grad_scale; a.probs = probs; a.dlogits = dlogits; a.part = part;
+  hipLaunchKernelGGL(seg_head_fused_kernel, dim3(B * a.tiles_per_cloud), dim3(256), SH_REGION_A + SH_REGION_B, st, a);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
 }
 
 // lanes <-> input channel k.  Per 128-row tile of one cloud:

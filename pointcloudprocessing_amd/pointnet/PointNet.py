@@ -642,6 +642,8 @@ class PointNet(torch.nn.Module):
         io.training = int(training)
         io.workspace = ws.data_ptr()
         io.workspace_bytes = ws.numel()
+        if self._debugging or getattr(self, "keep_activations", False):      # check_numerics reads every layer's stored output
+            io.flags = _lib.PN_IO_KEEP_ACTIVATIONS
         io.scalars = self.scalars.data_ptr()
         aux = getattr(self, "_aux_stream", None)       # engine.TrainStep: parameter gradients on a second stream
         io.aux_stream = aux.cuda_stream if (aux is not None and training) else None

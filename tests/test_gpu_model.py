@@ -322,3 +322,40 @@ def test_forward_prologue_draws_masks_and_clears_gradients(dev):
         res.append((m.grads_flat.clone(), m.scalars.clone()))
     assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
     assert float(res[0][0].abs().max()) < 1e6        # nothing of the stale fill survived
+
+
+@pytest.mark.parametrize("vanilla", [False, True])
+@pytest.mark.parametrize("B,N", [(4, 300), (32, 1024)])
+def test_fused_frozen_segmentation_head_equals_layer_by_layer(dev, vanilla, B, N):
+    """A segmentation head that normalises with moving statistics and gets no gradient (inference; `classification_pretrain`) runs as
+    ONE launch with its activations kept on chip (pn_segout.hip: seg_head_fused).  It must reproduce the layer-by-layer plan bit for
+    bit: same probabilities in inference, same outputs and gradients in a training step; the loss / accuracy sums are grouped per
+    64 instead of 128 rows, so they agree to rounding."""
+    from pointcloudprocessing_amd.pointnet.PointNet import PointNet
+    params = O.init_params(CCLS, CSEG, seed=21, vanilla=vanilla, randomize_bn=True)
+    pc, y_cls, y_seg, se3, keep = make_inputs(B, N, 9)
+    kp = (keep["dropout_1"].to(torch.uint8).to(dev), keep["dropout_2"].to(torch.uint8).to(dev))
+    res = []
+    for keep_act in (False, True):
+        m = PointNet(CCLS, CSEG, 0.3, 42, vanilla=vanilla, precision="bf16", device=dev)
+        m.set_weights(params)
+        m.keep_activations = keep_act
+        inf = [t.clone() for t in m(pc.to(dev), training=False)]
+        m.freeze_segmentation_head()
+        tr = m.fused_loss_step(pc.to(dev), y_cls.to(torch.int32).to(dev), y_seg.to(torch.int32).to(dev), se3.to(dev), (1.0, 0.0, 0.0), keep=kp)
+        torch.cuda.synchronize()
+        res.append((inf, [t.clone() for t in tr], m.grads_flat.clone(), m.scalars.clone()))
+    (inf_f, tr_f, g_f, sc_f), (inf_l, tr_l, g_l, sc_l) = res
+    for a_, b_ in zip(inf_f + tr_f, inf_l + tr_l):
+        assert torch.equal(a_, b_)
+    assert torch.equal(g_f, g_l)
+    assert torch.allclose(sc_f, sc_l, rtol=1e-5, atol=1e-5), (sc_f.tolist(), sc_l.tolist())
+    assert float(inf_f[1].sum(-1).sub(1).abs().max()) < 1e-4          # the fused head's softmax rows sum to one
+    # a gradient through a head that kept no activations is refused, not computed from stale buffers
+    m = PointNet(CCLS, CSEG, 0.3, 42, vanilla=vanilla, precision="bf16", device=dev)
+    m.set_weights(params)
+    m.freeze_segmentation_head()
+    m.fused_loss_step(pc.to(dev), y_cls.to(torch.int32).to(dev), y_seg.to(torch.int32).to(dev), se3.to(dev), (1.0, 0.0, 0.0), keep=kp)
+    from pointcloudprocessing_amd._lib import PointNetHipError
+    with pytest.raises(PointNetHipError):
+        m._run_backward(None, torch.zeros(B, N, CSEG, device=dev), None)
