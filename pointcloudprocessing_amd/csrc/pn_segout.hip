@@ -250,10 +250,35 @@ struct SegHeadArgs {
   int N, C, tiles_per_cloud, s16;                   // s16: the layer-by-layer plan stores z as bf16 -- round the same way
   const int* labels; float grad_scale; float *probs, *dlogits, *part;
 };
+// One 32 x 32 accumulator block (lane = column c0 + r, 16 rows) -> bf16 LDS image.  Neighbouring lanes swap half of their values
+// (one DPP move per row pair) so that every lane stores PAIRS of adjacent columns as one dword: 8 ds_write_b32 per lane instead of
+// 16 ds_write_b16 -- sub-dword LDS stores from 64 lanes serialise, and the epilogues of this kernel store 256 values per lane.
+__device__ __forceinline__ void sh_store_block(__bf16* img, int pitch, int m, int col, int h, int lane, const float (&y)[16]) {
+  const bool odd = lane & 1;
+#pragma unroll
+  for (int e = 0; e < 16; e += 2) {
+    const float give = odd ? y[e] : y[e + 1];
+    // the neighbour's value: v_mov_b32_dpp quad_perm:[1,0,3,2] (no LDS crossbar traffic)
+    const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
+    const int ee = odd ? e + 1 : e;                           // the row this lane writes of the pair
+    const int row = m * 32 + (ee & 3) + 8 * (ee >> 2) + 4 * h;
+    const float lo = odd ? got : y[e], hi = odd ? y[e + 1] : got;     // columns (col & ~1, col | 1)
+    const unsigned w = (unsigned)f32_bf16_bits(lo) | ((unsigned)f32_bf16_bits(hi) << 16);
+    *reinterpret_cast<unsigned*>(img + row * pitch + (col & ~1)) = w;
+  }
+}
 __device__ __forceinline__ float sh_bnrelu(float z, float sc, float sh, int s16) {
   const float zq = s16 ? bf16_bits_f32(f32_bf16_bits(z)) : z;
   return clamp_lo(fmaf(sc, zq, sh), 0.f);
 }
+// Kernel fragments are REQUESTED a phase ahead of their use; a compiler-level memory fence (no instruction) after each group of
+// requests keeps the compiler from sinking the loads back to their first use -- a workgroup walks ~80 dependent k-steps, and with
+// the fragment of each step requested at the step the kernel ran at one global-memory round trip per step.  (An empty asm that
+// NAMES the loaded registers would do the opposite: it is a use, so the wait for the load lands right there.)
+#define SH_KEEP_ABOVE() asm volatile("" ::: "memory")
+// Workgroup barrier for LDS hand-offs only: this wave's LDS traffic is drained, the global loads in flight are NOT (__syncthreads
+// waits for vmcnt(0) too, which would land every prefetched fragment at the next barrier: one memory round trip per barrier)
+#define SH_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sh_sm[];
   __bf16* Ain = reinterpret_cast<__bf16*>(sh_sm);
@@ -295,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
     *reinterpret_cast<seg_bf16x8*>(Ain + row * SH_P64 + c0) = o0;
     *reinterpret_cast<seg_bf16x8*>(Ain + row * SH_P64 + c0 + 8) = o1;
   }
-  __syncthreads();
+  SH_BARRIER();
 
   auto afrag = [&](const __bf16* img, int pitch, int m, int k0) {
     return *reinterpret_cast<const seg_bf16x8*>(img + (m * 32 + r) * pitch + k0 + 8 * h);
@@ -312,6 +337,20 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc2[m][n][e] = 0.f;
+  const int c3 = 32 * wave + r;                             // this lane's seg_l3 / seg_l4 channel
+  // Loads return in issue order: a wait for the NEWEST load drains everything requested before it.  So the small per-channel
+  // coefficient loads go out BEFORE the fragment prefetches they would otherwise sit behind.
+  const float sc2v[2] = {a.sc2[64 * wave + r], a.sc2[64 * wave + 32 + r]}, sh2v[2] = {a.sh2[64 * wave + r], a.sh2[64 * wave + 32 + r]};
+  const float sc3v = a.sc3[c3], sh3v = a.sh3[c3], sc4v = a.sc4[c3], sh4v = a.sh4[c3];
+  seg_bf16x8 b1[4], b2[8][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { b1[ks] = bfrag(a.w1t, 64, 32 * wave + r, ks * 16); }
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) b2[ks][n] = bfrag(a.w2t, 512, 64 * wave + 32 * n + r, ks * 16);
+  SH_KEEP_ABOVE();
+#pragma unroll 1
   for (int j = 0; j < 4; ++j) {
     seg_f32x16 acc1[2];
 #pragma unroll
@@ -319,53 +358,62 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc1[m][e] = 0.f;
     const int c1 = 128 * j + 32 * wave + r;                 // this lane's seg_l1 channel
+    const float bias = a.gb[(long long)cloud * 512 + c1], sc = a.sc1[c1], sh = a.sh1[c1];
+    SH_KEEP_ABOVE();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      const seg_bf16x8 b = bfrag(a.w1t, 64, c1, ks * 16);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc1[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(Ain, SH_P64, m, ks * 16), b, acc1[m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m) acc1[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(Ain, SH_P64, m, ks * 16), b1[ks], acc1[m], 0, 0, 0);
     }
-    {
-      const float bias = a.gb[(long long)cloud * 512 + c1], sc = a.sc1[c1], sh = a.sh1[c1];
+    // next chunk's seg_l1 fragments: under this chunk's epilogue and seg_l2 steps.  Unconditional (the last chunk re-requests its
+    // own): behind a branch the compiler must assume at the join that the requests were NOT made and waits for everything
+    const int jn = j < 3 ? j + 1 : 3;
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+    for (int ks = 0; ks < 4; ++ks) b1[ks] = bfrag(a.w1t, 64, 128 * jn + 32 * wave + r, ks * 16);
+    SH_KEEP_ABOVE();
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int row = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-          S1c[row * SH_P128 + 32 * wave + r] = (__bf16)sh_bnrelu(acc1[m][e] + bias, sc, sh, a.s16);
-        }
+    for (int m = 0; m < 2; ++m) {
+      float y[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) y[e] = sh_bnrelu(acc1[m][e] + bias, sc, sh, a.s16);
+      sh_store_block(S1c, SH_P128, m, 32 * wave + r, h, lane, y);
     }
-    __syncthreads();
+    SH_BARRIER();
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      seg_bf16x8 b[2];
-#pragma unroll
-      for (int n = 0; n < 2; ++n) b[n] = bfrag(a.w2t, 512, 64 * wave + 32 * n + r, 128 * j + ks * 16);
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
         const seg_bf16x8 af = afrag(S1c, SH_P128, m, ks * 16);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b[n], acc2[m][n], 0, 0, 0);
+        for (int n = 0; n < 2; ++n) acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2[ks][n], acc2[m][n], 0, 0, 0);
       }
+      // the registers of this step go straight to the same step of the next chunk (unconditional, as above)
+#pragma unroll
+      for (int n = 0; n < 2; ++n) b2[ks][n] = bfrag(a.w2t, 512, 64 * wave + 32 * n + r, 128 * jn + ks * 16);
+      SH_KEEP_ABOVE();
     }
-    __syncthreads();                                        // the chunk image is overwritten by the next chunk
+    SH_BARRIER();                                        // the chunk image is overwritten by the next chunk
   }
+  // seg_l3's first eight fragments and all of seg_l4's: requested now, land under seg_l2's epilogue
+  seg_bf16x8 b3[8], b4[8];
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) { b3[ks] = bfrag(a.w3t, 256, c3, ks * 16); b4[ks] = bfrag(a.w4t, 128, c3, ks * 16); }
+  SH_KEEP_ABOVE();
   // ---- seg_l2 -> LDS ----
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
     const int c2 = 64 * wave + 32 * n + r;
-    const float sc = a.sc2[c2], sh = a.sh2[c2];
+    const float sc = sc2v[n], sh = sh2v[n];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 2; ++m) {
+      float y[16];
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        S2[row * SH_P256 + c2] = (__bf16)sh_bnrelu(acc2[m][n][e], sc, sh, a.s16);
-      }
+      for (int e = 0; e < 16; ++e) y[e] = sh_bnrelu(acc2[m][n][e], sc, sh, a.s16);
+      sh_store_block(S2, SH_P256, m, c2, h, lane, y);
+    }
   }
-  __syncthreads();
+  SH_BARRIER();
   // ---- seg_l3 (256 -> 128): 32 columns per wave ----
-  const int c3 = 32 * wave + r;
   {
     seg_f32x16 acc[2];
 #pragma unroll
@@ -374,20 +422,23 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
       for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
-      const seg_bf16x8 b = bfrag(a.w3t, 256, c3, ks * 16);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(S2, SH_P256, m, ks * 16), b, acc[m], 0, 0, 0);
-    }
-    const float sc = a.sc3[c3], sh = a.sh3[c3];
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        S3[row * SH_P128 + c3] = (__bf16)sh_bnrelu(acc[m][e], sc, sh, a.s16);       // region A: the input tile and chunk image are dead
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(S2, SH_P256, m, ks * 16), b3[ks & 7], acc[m], 0, 0, 0);
+      if (ks < 8) {                                         // steps 8..15 take over the registers of steps 0..7
+        b3[ks] = bfrag(a.w3t, 256, c3, (ks + 8) * 16);
+        SH_KEEP_ABOVE();
       }
+    }
+    const float sc = sc3v, sh = sh3v;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {                             // region A: the input tile and chunk image are dead
+      float y[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) y[e] = sh_bnrelu(acc[m][e], sc, sh, a.s16);
+      sh_store_block(S3, SH_P128, m, c3, h, lane, y);
+    }
   }
-  __syncthreads();
+  SH_BARRIER();
   // ---- seg_l4 (128 -> 128) -> the output layer's input, fp32 (it is split hi + lo there, as in seg_out_fwd) ----
   {
     seg_f32x16 acc[2];
@@ -397,11 +448,10 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
       for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
-      const seg_bf16x8 b = bfrag(a.w4t, 128, c3, ks * 16);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(S3, SH_P128, m, ks * 16), b, acc[m], 0, 0, 0);
+      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(S3, SH_P128, m, ks * 16), b4[ks], acc[m], 0, 0, 0);
     }
-    const float sc = a.sc4[c3], sh = a.sh4[c3];
+    const float sc = sc4v, sh = sh4v;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -410,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
         S4f[row * SH_PF + c3] = sh_bnrelu(acc[m][e], sc, sh, a.s16);                 // region B: seg_l2's image is dead
       }
   }
-  __syncthreads();                                          // seg_l3's image (region A) is dead from here
+  SH_BARRIER();                                          // seg_l3's image (region A) is dead from here
   // ---- output layer: kernel image (bf16 hi + lo, channel-major) into region A, logits of a 32-row block per wave (waves 0, 1) ----
   for (int t = tid; t < 32 * 128; t += 256) {
     const int c = t >> 7, k = t & 127;
@@ -419,7 +469,7 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
     W5hi[c * SEG_WP + k] = hi;
     W5lo[c * SEG_WP + k] = (__bf16)(v - (float)hi);
   }
-  __syncthreads();
+  SH_BARRIER();
   if (wave < 2) {
     seg_f32x16 acc;
 #pragma unroll
@@ -447,7 +497,7 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
       for (int e = 0; e < 16; ++e) lgt[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * (SEG_CM + 1) + r] = acc[e];
     }
   }
-  __syncthreads();
+  SH_BARRIER();
   // ---- softmax, loss, accuracy, d(logits): one thread per point (wave 0) ----
   if (wave == 0) {
     float loss = 0.f, corr = 0.f;
@@ -475,6 +525,8 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
     }
   }
 }
+#undef SH_KEEP_ABOVE
+#undef SH_BARRIER
 int seg_head_fused_rows() { return SH_ROWS; }
 int seg_head_fused(const pn_operand* x, const float* gb, const void* w1t, const void* w2t, const void* w3t, const void* w4t, const float* sc1,
                    const float* sh1, const float* sc2, const float* sh2, const float* sc3, const float* sh3, const float* sc4, const float* sh4,
