@@ -27,10 +27,45 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in registers (HIP's uint4 struct does not)
 
-__device__ __forceinline__ float vmax3(float a, float b, float c) {
-  float r;
-  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+// Maximum of the 16 accumulator values a lane holds, as v_max3_f32 written by hand: through fmaxf the compiler first quiets every
+// input (a v_max_f32 x, x per value -- 128 more vector instructions per panel and wave); the instruction itself already returns the
+// other operand for a NaN, which is all fmaxf promises.
+// HAZARD: nothing pads inline assembly.  An MFMA's result may be read by a vector instruction only 12 wait states after the MFMA
+// issued (8-pass XDL), and the compiler's hazard recognizer supplies them only for instructions it knows.  Two safe forms:
+//   max16_guarded  -- the first two values go through fmaxf (compiler-known reads: they carry the wait states), the rest of the tree
+//                     is ONE statement that depends on that value, so it cannot be scheduled ahead of it;
+//   max16_a/_b     -- two bare halves for the software-pipelined loop, which places them (between scheduling fences) behind
+//                     compiler-known reads of the same accumulator and several MFMAs of the next chain.
+__device__ __forceinline__ float max16_guarded(const f32x16& a) {
+  const float m01 = fmaxf(a[0], a[1]);
+  float r, t;
+  asm("v_max3_f32 %0, %2, %3, %4\n\t"
+      "v_max3_f32 %1, %5, %6, %7\n\t"
+      "v_max3_f32 %0, %0, %1, %8\n\t"
+      "v_max3_f32 %1, %9, %10, %11\n\t"
+      "v_max3_f32 %0, %0, %1, %12\n\t"
+      "v_max3_f32 %1, %13, %14, %15\n\t"
+      "v_max3_f32 %0, %0, %1, %16"
+      : "=&v"(r), "=&v"(t)
+      : "v"(m01), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]), "v"(a[10]), "v"(a[11]),
+        "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]));
   return r;
+}
+__device__ __forceinline__ void max16_a(const f32x16& a, float& r, float& t) {      // values 0..9
+  asm volatile("v_max3_f32 %0, %2, %3, %4\n\t"
+               "v_max3_f32 %1, %5, %6, %7\n\t"
+               "v_max3_f32 %0, %0, %1, %8\n\t"
+               "v_max3_f32 %1, %9, %10, %11"
+               : "=&v"(r), "=&v"(t)
+               : "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]));
+}
+__device__ __forceinline__ void max16_b(const f32x16& a, float& r, float& t) {      // values 10..15 joined to (r, t)
+  asm volatile("v_max3_f32 %0, %0, %1, %2\n\t"
+               "v_max3_f32 %1, %3, %4, %5\n\t"
+               "v_max3_f32 %0, %0, %1, %6\n\t"
+               "v_max_f32 %0, %0, %7"
+               : "+v"(r), "+v"(t)
+               : "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]));
 }
 
 // ---- the panel kernel --------------------------------------------------------------------------------------------------------
@@ -76,7 +111,7 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
   constexpr int RP = THREADS / CH;                   // rows per staging pass
   constexpr int P = BM / RP;                         // passes (2 at K = 128, 1 at K = 64)
   constexpr int NBLK = CBW * NT;                     // B blocks (column block x image) of KS fragments each owned by a wave
-  constexpr int RBMAX = (NS == 3 || STATS) ? 3 : 4;
+  constexpr int RBMAX = (NS == 3 || (STATS && DBG != 0)) ? 3 : 4;
   constexpr int RB = NBLK < RBMAX ? NBLK : RBMAX;    // ... of which this many live in registers (RB * KS * 4 VGPRs) and the rest in LDS:
   constexpr int LB = NBLK - RB;                      // 4 x 32 VGPRs + accumulators + staging do not fit 256 registers without spills
   __shared__ __attribute__((aligned(16))) __bf16 Ap[2][NT][BM * PA];
@@ -195,6 +230,93 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
     const int nrows = min(BM, g.N - pnl * BM);
     const bool full = nrows == BM;                   // block-uniform
     if (pnl + 1 < p_end) issue(pnl + 1);             // flies under this panel's MFMAs
+    if constexpr (NS == 1 && DBG == 0) {
+      if (full) {
+        // ---- software-pipelined form (full panels, one bf16 image) ---------------------------------------------------------------
+        // The panel's 2 x CBW (row block, column block) accumulators are walked as ONE chain of chains: while chain t's MFMAs issue,
+        // the vector instructions of chain t-1's epilogue sit in the gaps between them (an MFMA holds the SIMD's vector issue for 8 of
+        // its 32 cycles; a wave issues in order, so work that is to hide under an MFMA must stand between two MFMAs in program order).
+        // Scheduling fences pin that interleave.  The epilogue's first unit is compiler-known arithmetic on the accumulator (it
+        // carries the MFMA -> VALU wait states), the hand-written max tree comes behind it.  Sums and maxima are taken in the same
+        // association as the plain form below: bit-identical results.
+        constexpr int NB = 2 * CBW;
+        f32x16 acc2[2];
+        bf16x8 af[KS];
+        u32x4 bl_next;                                 // fragment of the LDS-resident column block, read one k-step ahead
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(&Ap[buf][0][r * PA + ks * 16 + h * 8]);
+        float q0 = 0.f, q1 = 0.f, q2 = 0.f, q3 = 0.f, mr = 0.f, mt = 0.f;
+        // unit u (0..6) of the epilogue of block tb, on accumulator a: four sum-of-squares groups, two halves of the max tree, the join
+        // (arithmetic has no place of its own in the compiler's eyes -- it floats to wherever its operands allow -- so every unit is
+        // fenced by empty volatile statements on what it reads and what it leaves)
+        auto unit = [&](int u, f32x16& a, int ib, int blk32) {
+          if (u < 4) {
+            if (STATS) {
+              const int e = 4 * u;
+              if (u == 0) asm volatile("" : "+v"(a));  // not before this gap
+              q0 = fmaf(a[e], a[e], u ? q0 : 0.f);
+              q1 = fmaf(a[e + 1], a[e + 1], u ? q1 : 0.f);
+              q2 = fmaf(a[e + 2], a[e + 2], u ? q2 : 0.f);
+              q3 = fmaf(a[e + 3], a[e + 3], u ? q3 : 0.f);
+              asm volatile("" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3));   // not after it
+            } else if (u == 0) {
+              asm volatile("" : "+v"(a));
+              mr = fmaxf(a[0], a[1]);                  // compiler-known read of the accumulator: carries the wait states
+              asm volatile("" : "+v"(mr));
+            }
+          } else if (u == 4) {
+            max16_a(a, mr, mt);
+          } else if (u == 5) {
+            max16_b(a, mr, mt);
+          } else {
+            if (STATS) ss[ib] += (q0 + q1) + (q2 + q3);
+            const bool better = mr > best[ib];         // panels and blocks ascend: the first maximum wins
+            best[ib] = better ? mr : best[ib];
+            bq[ib] = better ? blk32 : bq[ib];
+            if (STATS) asm volatile("" : "+v"(ss[ib]));
+            asm volatile("" : "+v"(best[ib]), "+v"(bq[ib]));
+          }
+        };
+        auto gap_of = [](int u) { return 1 + (u * (KS - 1)) / 7; };
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+          const int i = t % CBW;
+          f32x16& acc = acc2[t & 1];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+          const bool from_lds = i * NT >= RB;          // this chain's B fragments come from LDS, one k-step ahead of their MFMA
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            u32x4 vbw;
+            if (!from_lds) vbw = bw[i < RB ? i : 0][ks];
+            else vbw = bl_next;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, vbw), acc, 0, 0, 0);
+            // the other row block's A fragments replace this one's as the last chain that needs them passes
+            if (t == CBW - 1) af[ks] = *reinterpret_cast<const bf16x8*>(&Ap[buf][0][(32 + r) * PA + ks * 16 + h * 8]);
+            // next LDS-resident fragment: the next k-step of this chain, or the first of the next chain
+            {
+              const int tn = ks + 1 < KS ? t : t + 1, kn = ks + 1 < KS ? ks + 1 : 0;
+              const int in = tn % CBW;
+              if (tn < NB && in * NT >= RB) bl_next = Bl[wave][(in * NT - RB) * KS + kn][lane];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (t > 0) {
+#pragma unroll
+              for (int u = 0; u < 7; ++u)
+                if (gap_of(u) == ks) unit(u, acc2[(t - 1) & 1], (t - 1) % CBW, pnl * 2 + (t - 1) / CBW);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        // the next panel's conversion stands between the last chain and its epilogue
+        if (pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 7; ++u) unit(u, acc2[(NB - 1) & 1], (NB - 1) % CBW, pnl * 2 + 1);
+        __syncthreads();
+        continue;
+      }
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m) {                    // the panel's two 32-row blocks in turn
       // this wave's A fragments of the block: read from LDS once and used for all its column blocks (KS x 4 VGPRs per image)
@@ -242,12 +364,7 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
         }
         float mx;
         if (full) {
-          // eight instructions for sixteen values.  Written as v_max3_f32 by hand: through fmaxf the compiler first quiets every input
-          // (a v_max_f32 x, x per accumulator value -- 128 more vector instructions per panel and wave in a loop that is vector-ALU
-          // bound); the instruction itself already returns the other operand for a NaN, which is all fmaxf promises
-          const float t0 = vmax3(acc[0], acc[1], acc[2]), t1 = vmax3(acc[3], acc[4], acc[5]), t2 = vmax3(acc[6], acc[7], acc[8]);
-          const float t3 = vmax3(acc[9], acc[10], acc[11]), t4 = vmax3(acc[12], acc[13], acc[14]);
-          mx = vmax3(vmax3(t0, t1, t2), vmax3(t3, t4, acc[15]), -INFINITY);
+          mx = max16_guarded(acc);                 // (the software-pipelined form above takes the full panels of the bf16 mode)
         } else {
           mx = -INFINITY;
 #pragma unroll
@@ -263,6 +380,9 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
         // the last MFMA and keeps 8 x 16 accumulator registers alive for them (spills); the other wave of the SIMD covers the gap
         if (STATS) asm volatile("" : "+v"(ss[i]));
         asm volatile("" : "+v"(best[i]));
+        // bf16 mode: only the ragged last panel of a cloud comes here -- one accumulator at a time, nothing carried across blocks
+        // (registers, not speed: the pipelined form above sets this kernel's register budget)
+        if constexpr (NS == 1 && DBG == 0) __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);    // the other image was last read before the previous barrier
