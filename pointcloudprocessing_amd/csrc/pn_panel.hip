@@ -1,20 +1,18 @@
 // Row-panel kernel for the dominant layer: ConvLayer(K -> C) + BatchNormalization statistics + tf.reduce_max over the points
 // (pointnet/PointNet.py:242-248, 425-429) on bf16 MFMA, its weight preparation and its finaliser.
 //
-// A workgroup (4 waves) owns a PANEL of 128 (or 64) point rows for ALL C channels:
-//   * the activation panel (rows x K, the previous layer's BN + ReLU applied on load, rounded once to bf16 hi [+ lo]) is staged
-//     into LDS once and is the only thing the waves share: one barrier at the start of the kernel, none afterwards;
-//   * every wave owns whole COLUMNS: wave w computes column blocks w, w + 4, ... (32 channels each) for all rows of the panel, so a
-//     column's maximum over the panel never leaves the wave (no cross-wave reduction, no per-tile barrier, no LDS traffic for the
-//     results) and the B operand is private to the wave: it is read from a FRAGMENT-ORDERED bf16 copy of the kernel
-//     (pn_weights_prep: the 16 bytes lane l needs for k-step ks of column block cb sit at ((cb * K/16 + ks) * 64 + l) * 16, so a
-//     wave's load is one coalesced 1 KB transaction straight into the MFMA register layout, prefetched one column block ahead);
+// A workgroup (8 waves) owns a RUN of 64-row panels of one cloud for ALL C channels (kernel-stationary, see panel_max_kernel):
+//   * every wave owns whole COLUMNS: wave w keeps the MFMA B fragments of its column blocks (32 channels each) in registers for the
+//     whole launch, read once from a FRAGMENT-ORDERED bf16 copy of the kernel (pn_weights_prep: the 16 bytes lane l needs for k-step
+//     ks of column block cb sit at ((cb * K/16 + ks) * 64 + l) * 16: one coalesced 1 KB transaction straight into the MFMA register
+//     layout); a column's maximum over the run never leaves the wave (no cross-wave reduction, no LDS traffic for the results);
+//   * the activation panels (64 rows x K, the previous layer's BN + ReLU applied on load, rounded once to bf16 hi [+ lo]) stream through
+//     a double-buffered LDS image and are the only thing the waves share: one barrier per panel;
 //   * the epilogue holds only what cannot be had elsewhere: max over the rows (v_max3: half an instruction per accumulator
-//     element) and sum of squares (packed fma, half an instruction).  The column SUM comes from the panel's column sums of A
-//     (a1 = A^T 1, taken from LDS once per panel): sum_m z[m][c] = a1 . W[:, c], finished per channel by the finaliser.  The ROW
-//     of the maximum is not tracked element by element either (that costs two to three instructions per element): the kernel
-//     records which 32-row block of the panel held the maximum and the backward pass, which is the only consumer of the row, finds
-//     it among those 32 candidates (pn_maxbwd.hip: max_resolve).
+//     element) and sum of squares (one fma per element).  The column SUM comes from the run's column sums of A (a1 = A^T 1):
+//     sum_m z[m][c] = a1 . W[:, c], formed once per slot.  The ROW of the maximum is not tracked element by element either (that
+//     costs two to three instructions per element): the kernel records which 32-row block held the maximum and the backward pass,
+//     the only consumer of the row, finds it among those 32 candidates (pn_maxbwd.hip: max_resolve).
 // Per point: 2 * K * C FLOP against 4 * K bytes of input: MFMA-bound by the roofline.
 #include <cstdlib>
 #include "pn_common.h"
@@ -23,6 +21,7 @@
 namespace pn {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: stays in registers (HIP's uint4 struct does not)
@@ -117,6 +116,7 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
   __shared__ __attribute__((aligned(16))) __bf16 Ap[2][NT][BM * PA];
   __shared__ float red[8][NT * K];
   __shared__ float a1s[NT * K];                      // column sums of the slot's staged rows (hi image, then lo image)
+  __shared__ __attribute__((aligned(16))) float coef[2 * K];   // BN + ReLU coefficients of the operand's K columns: ca, then cc
   __shared__ u32x4 Bl[LB > 0 ? 8 : 1][LB > 0 ? LB * KS : 1][LB > 0 ? 64 : 1];   // [wave][block, k-step][lane]: lane-linear, conflict-free
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -156,19 +156,25 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
   };
   auto convert = [&](int panel, int buf) {
     const int nrows = min(BM, g.N - panel * BM);
-    // the BN + ReLU coefficients of this thread's 8 columns are re-read here (L1 hits) rather than kept in 16 registers across the
-    // MFMA sections: the kernel's fragments already take 128 of the 256
+    // the BN + ReLU coefficients of this thread's 8 columns are re-read here rather than kept in 16 registers across the MFMA
+    // sections: the kernel's fragments already take 128 of the 256
     asm volatile("" ::: "memory");
-    float ca[8], cc[8];
+    // ... and the staged values are made opaque HERE: their unpacking is plain arithmetic, which the compiler otherwise hoists to
+    // the top of the panel (in front of a wait for loads that were issued a moment earlier)
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { ca[e] = 1.f; cc[e] = 0.f; }
-    if (g.a.ca) {
-      const float4 t0 = *reinterpret_cast<const float4*>(g.a.ca + k), t1 = *reinterpret_cast<const float4*>(g.a.ca + k + 4);
+    for (int p = 0; p < P; ++p)
+#pragma unroll
+      for (int q = 0; q < (H16 ? 1 : 2); ++q) {
+        u32x4 t = __builtin_bit_cast(u32x4, x[p][q]);
+        asm volatile("" : "+v"(t));
+        x[p][q] = __builtin_bit_cast(float4, t);
+      }
+    float ca[8], cc[8];
+    {   // from the LDS table (four reads in flight together: one short wait; the global form cost two L1 round trips per panel)
+      const float4 t0 = *reinterpret_cast<const float4*>(&coef[k]), t1 = *reinterpret_cast<const float4*>(&coef[k + 4]);
+      const float4 u0 = *reinterpret_cast<const float4*>(&coef[K + k]), u1 = *reinterpret_cast<const float4*>(&coef[K + k + 4]);
       ca[0] = t0.x; ca[1] = t0.y; ca[2] = t0.z; ca[3] = t0.w; ca[4] = t1.x; ca[5] = t1.y; ca[6] = t1.z; ca[7] = t1.w;
-    }
-    if (g.a.cc) {
-      const float4 t0 = *reinterpret_cast<const float4*>(g.a.cc + k), t1 = *reinterpret_cast<const float4*>(g.a.cc + k + 4);
-      cc[0] = t0.x; cc[1] = t0.y; cc[2] = t0.z; cc[3] = t0.w; cc[4] = t1.x; cc[5] = t1.y; cc[6] = t1.z; cc[7] = t1.w;
+      cc[0] = u0.x; cc[1] = u0.y; cc[2] = u0.z; cc[3] = u0.w; cc[4] = u1.x; cc[5] = u1.y; cc[6] = u1.z; cc[7] = u1.w;
     }
 #pragma unroll
     for (int p = 0; p < P; ++p) {
@@ -180,6 +186,23 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
       } else {
         v[0] = x[p][0].x; v[1] = x[p][0].y; v[2] = x[p][0].z; v[3] = x[p][0].w;
         v[4] = x[p][H16 ? 0 : 1].x; v[5] = x[p][H16 ? 0 : 1].y; v[6] = x[p][H16 ? 0 : 1].z; v[7] = x[p][H16 ? 0 : 1].w;
+      }
+      if constexpr (NS == 1) {
+        // one image: pairs of values are rounded by ONE v_cvt_pk_bf16_f32 straight into the dword the LDS store takes; the row mask
+        // and the column sums work on that dword (its halves ARE the rounded values)
+        u32x4 pk;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const f32x2 tt = {clamp_lo(fmaf(ca[e], v[e], cc[e]), lo), clamp_lo(fmaf(ca[e + 1], v[e + 1], cc[e + 1]), lo)};
+          const unsigned w = rv ? __builtin_bit_cast(unsigned, __builtin_convertvector(tt, bf16x2)) : 0u;   // rows outside the cloud are zero rows
+          pk[e / 2] = w;
+          if (STATS) {
+            a1h[e] += __builtin_bit_cast(float, w << 16);
+            a1h[e + 1] += __builtin_bit_cast(float, w & 0xffff0000u);
+          }
+        }
+        *reinterpret_cast<u32x4*>(&Ap[buf][0][rr * PA + k]) = pk;
+        continue;
       }
       bf16x8 hv, lv;
 #pragma unroll
@@ -200,6 +223,17 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
     }
   };
   // ---- this wave's columns of the kernel: loaded once, resident for the whole run ----------------------------------------------
+  // Order of the prologue's requests = order of their use (loads return in issue order, and a wait for one drains everything
+  // requested before it): the coefficient table, the first panel's rows, THEN the 256 KB of kernel fragments -- the first panel is
+  // converted while the fragments are still arriving, and its chains start as their own fragments land (a CU takes in 64 bytes a
+  // cycle: the fragments alone are ~2 us)
+  float cav = 1.f, ccv = 0.f;
+  if (tid < K) {
+    if (g.a.ca) cav = g.a.ca[tid];
+    if (g.a.cc) ccv = g.a.cc[tid];
+  }
+  issue(p_begin);
+  asm volatile("" ::: "memory");
   const u32x4* __restrict__ wfh = reinterpret_cast<const u32x4*>(g.wf_hi);
   const u32x4* __restrict__ wfl = reinterpret_cast<const u32x4*>(g.wf_lo);
   u32x4 bw[RB][KS];                                  // block q = i * NT + image (0 hi, 1 lo) of owned column block i
@@ -216,7 +250,12 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
     }
   }
 
-  issue(p_begin);
+  asm volatile("" ::: "memory");
+  if (tid < K) {
+    coef[tid] = cav;
+    coef[K + tid] = ccv;
+  }
+  __syncthreads();                                   // the coefficient table
   convert(p_begin, 0);
   __syncthreads();
 
@@ -229,7 +268,9 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
     const int buf = (pnl - p_begin) & 1;
     const int nrows = min(BM, g.N - pnl * BM);
     const bool full = nrows == BM;                   // block-uniform
-    if (pnl + 1 < p_end) issue(pnl + 1);             // flies under this panel's MFMAs
+    // flies under this panel's MFMAs.  Unconditional (the run's last panel requests its own rows again and drops them): behind a
+    // branch the staging registers are loop-carried values, and the compiler waits for everything in flight at the loop head
+    issue(pnl + 1 < p_end ? pnl + 1 : pnl);
     if constexpr (NS == 1 && DBG == 0) {
       if (full) {
         // ---- software-pipelined form (full panels, one bf16 image) ---------------------------------------------------------------
@@ -285,6 +326,13 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[e] = 0.f;
           const bool from_lds = i * NT >= RB;          // this chain's B fragments come from LDS, one k-step ahead of their MFMA
+          // The next panel's conversion is vector-ALU work only.  Waves w and w + 4 share a SIMD: the first four waves convert here, in
+          // the middle of the panel, the other four behind the last chain -- while one wave of a SIMD converts, its partner has the
+          // matrix core to itself (in lockstep both would leave it idle for two conversions per panel)
+          if (NB >= 4 && t == NB / 2) {
+            if (wave < 4 && pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
             u32x4 vbw;
@@ -308,8 +356,8 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        // the next panel's conversion stands between the last chain and its epilogue
-        if (pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);
+        // (the other four waves': between the last chain and its epilogue)
+        if ((NB < 4 || wave >= 4) && pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 7; ++u) unit(u, acc2[(NB - 1) & 1], (NB - 1) % CBW, pnl * 2 + 1);
