@@ -43,6 +43,14 @@ struct DenseArgs {
   int bn_mode, act;           // bn_mode: 0 none, 1 batch statistics (+ moving update), 2 moving statistics; act: 0 none, 1 relu
   const unsigned char* keep; float keep_scale;
   float *z_out, *a_out, *mean_o, *invstd_o;
+  // Backward tail (TRANS launches of a backward chain, R <= 32; bt_dz == NULL: none).  The launch computes dx = dz_above . W_above^T,
+  // which IS d(activation) of the layer below; the workgroup that finishes 32 of its columns goes straight on through that layer's
+  // dropout -> ReLU -> BatchNormalization backward (all per column: nothing crosses the column block) and leaves its dz, dgamma,
+  // dbeta / dbias -- the next launch of the chain is the next TRANS product, with no launch in between (pn_model.hip: bwd_chain)
+  const float *bt_z, *bt_gamma, *bt_beta, *bt_mean, *bt_invstd;
+  const unsigned char* bt_keep; float bt_keep_scale;
+  int bt_mode, bt_act;        // as bn_mode / act, of the layer below
+  float *bt_dz, *bt_dgamma, *bt_dbeta, *bt_dbias;
 };
 
 // One 128-k step of a block costs ~4 us (LDS broadcast reads + 512 FMAs per thread), the in-launch meeting of the K splits ~5 us
@@ -254,6 +262,61 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a0, co
       if (ty == 0) {
         if (a.mean_o) a.mean_o[j] = mean;
         if (a.invstd_o) a.invstd_o[j] = invstd;
+      }
+    }
+  }
+  if (a.bt_dz) {      // block-uniform; small (host-checked): zr[] holds this thread's four rows of d(activation)
+    float bsc = 1.f, bsh = 0.f, mu = 0.f, is = 1.f;
+    if (a.bt_mode) {
+      mu = a.bt_mean[jc]; is = a.bt_invstd[jc];
+      bsc = a.bt_gamma[jc] * is;
+      bsh = a.bt_beta[jc] - mu * bsc;
+    }
+    const float kscale = a.bt_keep ? a.bt_keep_scale : 1.f;
+    float v[DL_ROWS / RP], zh[DL_ROWS / RP], zz[DL_ROWS / RP];
+    unsigned kp = 0xfu;
+#pragma unroll
+    for (int i = 0; i < DL_ROWS / RP; ++i) zz[i] = a.bt_z[(long long)min(ty + RP * i, R - 1) * C + jc];     // unconditional, clamped
+    if (a.bt_keep) {
+      kp = 0u;
+#pragma unroll
+      for (int i = 0; i < DL_ROWS / RP; ++i) kp |= (a.bt_keep[(long long)min(ty + RP * i, R - 1) * C + jc] ? 1u : 0u) << i;
+    }
+    float S1 = 0.f, S2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < DL_ROWS / RP; ++i) {
+      const int r = ty + RP * i;
+      float d = ((kp >> i) & 1u) ? zr[i] * kscale : 0.f;
+      if (a.bt_act == 1 && !(fmaf(bsc, zz[i], bsh) > 0.f)) d = 0.f;
+      if (r >= R || !jv) d = 0.f;
+      zh[i] = (zz[i] - mu) * is;
+      v[i] = d;
+      S1 += d;
+      S2 = fmaf(d, zh[i], S2);
+    }
+    __syncthreads();
+    fin[ty * 32 + tx] = S1;
+    fin[(8 + ty) * 32 + tx] = S2;
+    __syncthreads();
+    S1 = 0.f; S2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < RP; ++q) { S1 += fin[q * 32 + tx]; S2 += fin[(8 + q) * 32 + tx]; }
+    const float invR = 1.f / (float)R;
+    const float m1 = S1 * invR, m2 = S2 * invR;
+#pragma unroll
+    for (int i = 0; i < DL_ROWS / RP; ++i) {
+      const int r = ty + RP * i;
+      float d = v[i];
+      if (a.bt_mode == 1) d = bsc * (d - m1 - zh[i] * m2);
+      else if (a.bt_mode == 2) d *= bsc;
+      if (jv && r < R) a.bt_dz[(long long)r * C + j] = d;
+    }
+    if (ty == 0 && jv) {
+      if (a.bt_mode == 1) {
+        if (a.bt_dgamma) a.bt_dgamma[j] = S2;
+        if (a.bt_dbeta) a.bt_dbeta[j] = S1;
+      } else if (a.bt_mode == 0 && a.bt_dbias) {
+        a.bt_dbias[j] = S1;
       }
     }
   }
@@ -614,6 +677,9 @@ static int dense_args(DenseArgs& a, const float* x, int ldx, const float* w, int
   a.bias = bias; a.gamma = gamma; a.beta = beta; a.mm = mm; a.mv = mv; a.momentum = momentum; a.eps = eps;
   a.bn_mode = bn_mode; a.act = act; a.keep = keep; a.keep_scale = keep_scale;
   a.z_out = z_out; a.a_out = a_out; a.mean_o = mean_o; a.invstd_o = invstd_o;
+  a.bt_z = a.bt_gamma = a.bt_beta = a.bt_mean = a.bt_invstd = nullptr;
+  a.bt_keep = nullptr; a.bt_keep_scale = 1.f; a.bt_mode = 0; a.bt_act = 0;
+  a.bt_dz = a.bt_dgamma = a.bt_dbeta = a.bt_dbias = nullptr;
   return PN_OK;
 }
 int dense_layer(const float* x, int ldx, const float* w, int ldw, bool trans, int R, int K, int C, float* partial, unsigned* counters,
@@ -642,6 +708,95 @@ int dense_layer_with_plain(const float* x, int ldx, const float* w, int ldw, int
   PN_TRY(dense_args(b, x, ldx, w2, ldw2, R, K, C, partial + dense_partial_floats(R, K, C), counters + cdiv(C, DL_COLS), nullptr, nullptr, nullptr,
                     nullptr, nullptr, 0.f, 0.f, 0, 0, nullptr, 1.f, out2, nullptr, nullptr, nullptr));
   hipLaunchKernelGGL(dense_layer_kernel<false>, dim3(cdiv(C, DL_COLS), a.nsplit, 2), dim3(256), 0, st, a, b);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// dx (R, C) = dz (R, K) . W^T from the (C, K)-shaped kernel W (ldw = K), and -- tail != NULL -- the backward of the layer below
+// through its dropout / ReLU / BatchNormalization in the same launch (DenseArgs::bt_*)
+int dense_trans_tail(const float* dz, int lddz, const float* w, int ldw, int R, int K, int C, float* partial, unsigned* counters, float* dx,
+                     const DenseTail* tail, hipStream_t st) {
+  DenseArgs a;
+  PN_TRY(dense_args(a, dz, lddz, w, ldw, R, K, C, partial, counters, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0, nullptr, 1.f,
+                    dx, nullptr, nullptr, nullptr));
+  if (tail) {
+    PN_CHECK_ARG(R <= DL_ROWS, "dense_trans_tail: the backward tail needs R <= %d (R=%d)", DL_ROWS, R);
+    PN_CHECK_ARG(tail->z && tail->dz, "dense_trans_tail: null pointer in the tail");
+    PN_CHECK_ARG(!tail->mode || (tail->gamma && tail->beta && tail->mean && tail->invstd), "dense_trans_tail: BatchNormalization needs gamma/beta/mean/invstd");
+    a.bt_z = tail->z; a.bt_gamma = tail->gamma; a.bt_beta = tail->beta; a.bt_mean = tail->mean; a.bt_invstd = tail->invstd;
+    a.bt_keep = tail->keep; a.bt_keep_scale = tail->keep_scale; a.bt_mode = tail->mode; a.bt_act = tail->act;
+    a.bt_dz = tail->dz; a.bt_dgamma = tail->dgamma; a.bt_dbeta = tail->dbeta; a.bt_dbias = tail->dbias;
+  }
+  hipLaunchKernelGGL(dense_layer_kernel<true>, dim3(cdiv(C, DL_COLS), a.nsplit), dim3(256), 0, st, a, a);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// The weight gradients dw = x^T . dz (+ db = column sums of dz) of several dense layers in ONE launch: nothing reads them before the
+// optimizer, so a backward pass collects them and launches once.  Same arithmetic as dense_wgrad_kernel (fp32 fma chain over the rows).
+struct DenseWgradBatch {
+  DenseWgradJob job[DENSE_WGRAD_MAX_JOBS];
+  int first_block[DENSE_WGRAD_MAX_JOBS + 1];      // 1-D grid: job q owns blocks [first_block[q], first_block[q + 1])
+  int n;
+};
+__global__ __launch_bounds__(256) void dense_wgrad_batch_kernel(const DenseWgradBatch b) {
+  constexpr int KT = 16;
+  constexpr int WRC = 32;
+  __shared__ float xs[KT][WRC];
+  int q = 0;
+  while (q + 1 < b.n && (int)blockIdx.x >= b.first_block[q + 1]) ++q;     // block-uniform
+  const DenseWgradJob& jb = b.job[q];
+  const int lb = blockIdx.x - b.first_block[q];
+  const int ncb = (jb.C + 255) / 256;
+  const int j = (lb % ncb) * 256 + threadIdx.x;
+  const int jc = j < jb.C ? j : jb.C - 1;
+  const int k0 = (lb / ncb) * KT;
+  const int R = jb.R, K = jb.K, C = jb.C;
+  float acc[KT];
+  float colsum = 0.f;
+#pragma unroll
+  for (int k = 0; k < KT; ++k) acc[k] = 0.f;
+  for (int rc = 0; rc < R; rc += WRC) {
+    const int nr = min(WRC, R - rc);
+    float d[WRC];
+#pragma unroll
+    for (int r = 0; r < WRC; ++r) d[r] = jb.dz[(long long)(rc + min(r, nr - 1)) * C + jc];
+#pragma unroll
+    for (int r = 0; r < WRC; ++r) colsum += (r < nr) ? d[r] : 0.f;
+    __syncthreads();
+    for (int t = threadIdx.x; t < KT * WRC; t += 256) {
+      const int k = t / WRC, r = t % WRC;
+      xs[k][r] = (r < nr && k0 + k < K) ? jb.x[(long long)(rc + r) * jb.ldx + k0 + k] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < WRC; ++r) {
+      const float dv = (r < nr) ? d[r] : 0.f;
+#pragma unroll
+      for (int k = 0; k < KT; ++k) acc[k] = fmaf(xs[k][r], dv, acc[k]);
+    }
+  }
+  if (j < C) {
+#pragma unroll
+    for (int k = 0; k < KT; ++k)
+      if (k0 + k < K) jb.dw[(long long)(k0 + k) * C + j] = acc[k];
+    if (jb.db && k0 == 0) jb.db[j] = colsum;
+  }
+}
+int dense_wgrad_batch(const DenseWgradJob* jobs, int n, hipStream_t st) {
+  PN_CHECK_ARG(jobs && n >= 1 && n <= DENSE_WGRAD_MAX_JOBS, "dense_wgrad_batch: 1..%d jobs (n=%d)", DENSE_WGRAD_MAX_JOBS, n);
+  DenseWgradBatch b;
+  memset(&b, 0, sizeof(b));
+  b.n = n;
+  int blocks = 0;
+  for (int q = 0; q < n; ++q) {
+    PN_CHECK_ARG(jobs[q].x && jobs[q].dz && jobs[q].dw && jobs[q].R > 0 && jobs[q].K > 0 && jobs[q].C > 0, "dense_wgrad_batch: bad job %d", q);
+    b.job[q] = jobs[q];
+    b.first_block[q] = blocks;
+    blocks += cdiv(jobs[q].C, 256) * cdiv(jobs[q].K, 16);
+  }
+  b.first_block[n] = blocks;
+  hipLaunchKernelGGL(dense_wgrad_batch_kernel, dim3(blocks), dim3(256), 0, st, b);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -30,10 +30,11 @@ int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, i
 int weights_prep(const float* w, const float* sgn, int K, int C, void* hi, void* lo, hipStream_t st);
 int panel_slots_per_cloud(int B, int N);
 int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo, int B, int N, int K, int C, float* pmax, int* pq,
-                       float* sumsq, float* sumz, int prec, hipStream_t st);
-int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const float* sumz, int B, int N, int C, const float* gamma,
-                   const float* beta, float* mm, float* mv, float momentum, float eps, int use_batch, int update, float* mean, float* invstd,
-                   float* scale, float* shift, float* g, float* zstar, int* argq, hipStream_t st);
+                       float* sumsq, float* colsum, int prec, hipStream_t st);
+int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const float* colsum, const void* wf_hi, const void* wf_lo, int prec,
+                   int B, int N, int K, int C, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps,
+                   int use_batch, int update, float* mean, float* invstd, float* scale, float* shift, float* g, float* zstar, int* argq,
+                   hipStream_t st);
 
 // pn_prologue.hip
 int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st);
@@ -104,6 +105,19 @@ int dense_bwd_pre(const float* da, const float* z, int R, int C, const float* ga
                   const float* invstd, int bn_mode, int act, const unsigned char* keep, float keep_scale, float* dz, float* dgamma,
                   float* dbeta, float* dbias, hipStream_t st);
 int dense_wgrad(const float* x, int ldx, const float* dz, int R, int K, int C, float* dw, hipStream_t st, float* db = nullptr);   // db: column sums of dz
+// the layer below a TRANS product, taken backward in the same launch (pn_dense.hip: DenseArgs::bt_*)
+struct DenseTail {
+  const float *z, *gamma, *beta, *mean, *invstd;
+  const unsigned char* keep; float keep_scale;
+  int mode, act;                       // mode: 0 bias only, 1 batch statistics, 2 moving statistics; act: 1 relu
+  float *dz, *dgamma, *dbeta, *dbias;  // dgamma / dbeta / dbias may be NULL (frozen layer)
+};
+int dense_trans_tail(const float* dz, int lddz, const float* w, int ldw, int R, int K, int C, float* partial, unsigned* counters, float* dx,
+                     const DenseTail* tail, hipStream_t st);
+// dw (K, C) = x^T . dz, db (C) = column sums of dz (or NULL), for several layers in one launch
+constexpr int DENSE_WGRAD_MAX_JOBS = 12;
+struct DenseWgradJob { const float* x; int ldx; const float* dz; int R, K, C; float* dw; float* db; };
+int dense_wgrad_batch(const DenseWgradJob* jobs, int n, hipStream_t st);
 int transpose(const float* in, int R, int C, float* out, hipStream_t st);
 int transpose2(const float* in, int R, int C, const float* rowscale, float* out, float* out2, hipStream_t st);
 int softmax_xent_rows(const float* logits, int R, int C, const int* labels, float grad_scale, float* probs, float* dlogits,

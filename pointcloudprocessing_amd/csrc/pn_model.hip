@@ -220,7 +220,7 @@ static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, 
   m.pmax = A.get<float>((n + ".pmax").c_str(), (size_t)B * cdiv(N, 64) * C);
   m.pq = A.get<int>((n + ".pq").c_str(), (size_t)B * cdiv(N, 64) * C);
   m.sumsq = A.get<float>((n + ".sumsq").c_str(), (size_t)B * cdiv(N, 64) * C);
-  m.pa1 = A.get<float>((n + ".sumz").c_str(), (size_t)B * cdiv(N, 64) * C);
+  m.pa1 = A.get<float>((n + ".colsum").c_str(), (size_t)B * cdiv(N, 64) * 2 * K);      // per slot: column sums of the staged rows (hi, lo)
   m.argq = A.get<int>((n + ".argq").c_str(), (size_t)B * C);
   m.wb_hi = A.get<unsigned short>((n + ".wb_hi").c_str(), (size_t)K * C);
   m.wb_lo = A.get<unsigned short>((n + ".wb_lo").c_str(), (size_t)K * C);
@@ -385,6 +385,7 @@ struct Run {
   std::vector<WgradDesc> gw_jobs;                    // the G W products of the max-pooled layers (consume the reduced Gram matrices)
   std::vector<std::function<int()>> after_jobs;      // launches that consume a deferred reduction (and feed only the optimizer)
   std::vector<DwJob> dw_jobs;                        // ... and the dW kernels of the max-pooled layers behind those, one launch
+  std::vector<DenseWgradJob> dense_jobs;             // the per-cloud dense layers' weight gradients (bwd_chain): one launch per pass
   int dw_K = 0, dw_C = 0;
   bool last_deferred = false;
   size_t pool_used = 0;
@@ -410,6 +411,9 @@ struct Run {
     after_jobs.clear();
     if (rc == PN_OK && !dw_jobs.empty()) rc = maxbwd_dw_batch(dw_jobs.data(), (int)dw_jobs.size(), B, N, dw_K, dw_C, st);
     dw_jobs.clear();
+    for (size_t q = 0; rc == PN_OK && q < dense_jobs.size(); q += DENSE_WGRAD_MAX_JOBS)
+      rc = dense_wgrad_batch(dense_jobs.data() + q, (int)std::min<size_t>(DENSE_WGRAD_MAX_JOBS, dense_jobs.size() - q), st);
+    dense_jobs.clear();
     return rc;
   }
 
@@ -517,7 +521,7 @@ struct Run {
     PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.pmax, m.pq, ub ? m.sumsq : nullptr, ub ? m.pa1 : nullptr, prec, st));
     if (ev && ev[2 * prof_slot + 1]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot + 1]), st);
     // one finaliser: the layer's BatchNormalization coefficients (+ moving statistics) and the reduce_max over each cloud's panels
-    return panel_finalize(m.pmax, m.pq, m.sumsq, m.pa1, B, N, r.cout, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub,
+    return panel_finalize(m.pmax, m.pq, m.sumsq, m.pa1, m.wb_hi, m.wb_lo, prec, B, N, r.cin, r.cout, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub,
                           ub, l.mean, l.invstd, l.scale, l.shift, m.g, m.zstar, m.argq, st);
   }
   // out (B, C) = x (B, K) . W (+ bias): one launch (pn_dense.hip); trans reads W^T from the same (C, K)-major... kernel
@@ -821,10 +825,51 @@ struct Run {
     if (dx_out) PN_TRY(dense_plain(dl.dz, r.cout, p(r.kernel), r.cout, true, r.cout, r.cin, nullptr, dx_out));
     return PN_OK;
   }
+  // ---- a chain of per-cloud dense layers taken backward with ONE launch per layer (rows = B <= 32, no auxiliary stream) ----------
+  // dtop (B, Ctop) is d(output) of the chain's top product, out = a_below . Wtop (+ bias), which has no BatchNormalization / ReLU of
+  // its own (the logits layer, the T-Net's K x K output).  Every launch is a TRANS product dx = dz . W^T whose finishing workgroups go
+  // straight on through the layer below (dropout -> ReLU -> BatchNormalization backward are per column): dz of that layer, dgamma,
+  // dbeta.  The weight gradients x^T . dz (and the top bias gradient) are nobody's input before the optimizer: collected in
+  // dense_jobs, one launch per pass (flush_jobs).  Round 2's form took two launches per layer (dz + dW, then dx).
+  struct ChainLayer { DLs* dl; const LRef* r; const float* xin; int act; const unsigned char* keep; };
+  bool chain_ok() const { return B <= 32; }      // (with or without an auxiliary stream: both step layouts must give the same bits)
+  int bwd_chain(const float* dtop, int Ctop, const float* Wtop, const float* a_below_top, float* dWtop, float* dbtop, float* da_top,
+                ChainLayer* ls, int n, float* dx_out) {
+    // top product: its own weight gradient is a plain job on dtop
+    if (dWtop) dense_jobs.push_back(DenseWgradJob{a_below_top, ls[0].r->cout, dtop, B, ls[0].r->cout, Ctop, dWtop, dbtop});
+    const float* dz_above = dtop;
+    int c_above = Ctop;
+    const float* w_above = Wtop;
+    float* dx_above = da_top;                        // where d(activation) of layer 0 goes (kept: debugging, tests)
+    const float ks = 1.f / (1.f - d.dropout_rate);
+    for (int q = 0; q < n; ++q) {
+      DLs& dl = *ls[q].dl;
+      const LRef& r = *ls[q].r;
+      const int mode = r.has_bn ? (bn_batch(r.block) ? 1 : 2) : 0;
+      const bool wg = tr(r.block) && G;
+      DenseTail t;
+      memset(&t, 0, sizeof(t));
+      t.z = dl.z; t.gamma = p(r.gamma); t.beta = p(r.beta); t.mean = dl.mean; t.invstd = dl.invstd;
+      t.keep = ls[q].keep; t.keep_scale = ks; t.mode = mode; t.act = ls[q].act;
+      t.dz = dl.dz;
+      t.dgamma = (wg && mode == 1) ? gr(r.gamma) : nullptr;
+      t.dbeta = (wg && mode == 1) ? gr(r.beta) : nullptr;
+      t.dbias = (wg && mode == 0) ? gr(r.bias) : nullptr;
+      PN_TRY(dense_trans_tail(dz_above, c_above, w_above, c_above, B, c_above, r.cout, w.dense_part, w.dcount, dx_above, &t, st));
+      if (wg) dense_jobs.push_back(DenseWgradJob{ls[q].xin, r.cin, dl.dz, B, r.cin, r.cout, gr(r.kernel), nullptr});
+      dz_above = dl.dz; c_above = r.cout; w_above = p(r.kernel); dx_above = dl.din;
+    }
+    // below the last layer: a plain product
+    return dense_trans_tail(dz_above, c_above, w_above, c_above, B, c_above, ls[n - 1].r->cin, w.dense_part, w.dcount, dx_out, nullptr, st);
+  }
   // T-Net backward from dR (B,K*K); leaves c1's dz coefficients ready (c1.dy + c1.ca/cb/cc)
   int bwd_tnet(TN& t, const TRef& r, const pn_operand* x) {
     const int KK = r.K * r.K;
     const bool wg = tr(r.c1.block) && G;
+    if (chain_ok()) {
+      ChainLayer ls[2] = {{&t.d2, &r.d2, t.d1.a, 1, nullptr}, {&t.d1, &r.d1, t.m3.g, 1, nullptr}};
+      PN_TRY(bwd_chain(t.dR, KK, p(r.w), t.d2.a, wg ? gr(r.w) : nullptr, wg ? gr(r.b) : nullptr, t.da2, ls, 2, t.m3.dG));
+    } else {
     if (wg) {
       const float *dR = t.dR, *a2 = t.d2.a;
       float *gb = gr(r.b), *gw = gr(r.w);
@@ -836,6 +881,7 @@ struct Run {
     PN_TRY(dense_plain(t.dR, KK, p(r.w), KK, true, KK, 256, nullptr, t.da2));
     PN_TRY(bwd_dense(t.d2, r.d2, t.d1.a, t.da2, 1, nullptr, t.d2.din));
     PN_TRY(bwd_dense(t.d1, r.d1, t.m3.g, t.d2.din, 1, nullptr, t.m3.dG));
+    }
     PN_TRY(bwd_max(t.c3, t.m3, r.c3, lazy(t.c2), t.c2, t.m3.dG));
     // c2 -> c1
     PN_TRY(bwd_step(t.c2, r.c2, t.c1, lazy(t.c1)));
@@ -924,9 +970,17 @@ struct Run {
     bool have_dGcls = false;
     if (has_cls) {
       if (d_cls) PN_TRY(softmax_bwd_rows(io.out_cls, d_cls, B, d.ccls, w.cls_dlogits, st));
+      if (chain_ok()) {
+        // the logits layer is the chain's top product (bias, no BatchNormalization, no activation: dz = d logits)
+        const bool wg3 = tr(BLK_C3) && G;
+        ChainLayer ls[2] = {{&w.c2, &L.c2, w.c1.a, 1, io.keep2}, {&w.c1, &L.c1, w.mm23.g, 1, io.keep1}};
+        PN_TRY(bwd_chain(w.cls_dlogits, d.ccls, p(L.c3.kernel), w.c2.a, wg3 ? gr(L.c3.kernel) : nullptr, wg3 ? gr(L.c3.bias) : nullptr,
+                         w.c3.din, ls, 2, w.dGcls));
+      } else {
       PN_TRY(bwd_dense(w.c3, L.c3, w.c2.a, w.cls_dlogits, 0, nullptr, w.c3.din));
       PN_TRY(bwd_dense(w.c2, L.c2, w.c1.a, w.c3.din, 1, io.keep2, w.c2.din));
       PN_TRY(bwd_dense(w.c1, L.c1, w.mm23.g, w.c2.din, 1, io.keep1, w.dGcls));
+      }
       have_dGcls = true;
     }
     // d(global feature) = classification-head part + segmentation-head part: summed inside maxbwd_prep

@@ -79,10 +79,10 @@ struct PanelArgs {
   float* pmax;                  // [B * spc][C]  max over the slot's rows of the accumulator (= sgn * z with presigned weights)
   int* pq;                      // [B * spc][C]  index inside the cloud of the 32-row block that held it (lowest on ties)
   float* sumsq;                 // [B * spc][C]  sum over the slot's rows of z^2, or NULL
-  float* sumz;                  // [B * spc][C]  sum over the slot's rows of the accumulator (sgn * z), or NULL (comes with sumsq)
+  float* colsum;                // [B * spc][NT * K]  column sums of the slot's staged operand rows (hi image, then lo), or NULL (comes with sumsq)
 };
 // PN_PANEL_DBG (timing ablations of the bf16, K = 128, statistics variant; WRONG results; tools/panel_probe.py): template bit mask DBG:
-// 1 no epilogue, 4 no activation loads, 8 no MFMAs
+// 1 no epilogue, 4 no activation loads, 8 no MFMAs; 16 (bf16 source only) the product kernel + shader-clock stamps in pq
 
 int panel_slots_per_cloud(int B, int N) {
   const int tpc = cdiv(N, 64);
@@ -110,18 +110,27 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
   constexpr int RP = THREADS / CH;                   // rows per staging pass
   constexpr int P = BM / RP;                         // passes (2 at K = 128, 1 at K = 64)
   constexpr int NBLK = CBW * NT;                     // B blocks (column block x image) of KS fragments each owned by a wave
-  constexpr int RBMAX = (NS == 3 || (STATS && DBG != 0)) ? 3 : 4;
+  constexpr int RBMAX = (NS == 3 || (STATS && (DBG & ~16) != 0)) ? 3 : 4;
   constexpr int RB = NBLK < RBMAX ? NBLK : RBMAX;    // ... of which this many live in registers (RB * KS * 4 VGPRs) and the rest in LDS:
   constexpr int LB = NBLK - RB;                      // 4 x 32 VGPRs + accumulators + staging do not fit 256 registers without spills
   __shared__ __attribute__((aligned(16))) __bf16 Ap[2][NT][BM * PA];
   __shared__ float red[8][NT * K];
-  __shared__ float a1s[NT * K];                      // column sums of the slot's staged rows (hi image, then lo image)
   __shared__ __attribute__((aligned(16))) float coef[2 * K];   // BN + ReLU coefficients of the operand's K columns: ca, then cc
   __shared__ u32x4 Bl[LB > 0 ? 8 : 1][LB > 0 ? LB * KS : 1][LB > 0 ? 64 : 1];   // [wave][block, k-step][lane]: lane-linear, conflict-free
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int slot = blockIdx.x, cg = blockIdx.y;
+  // DBG & 16: shader-clock stamps of wave 0 at the kernel's phase boundaries, left in the slot's pq row (tools/panel_probe.py)
+  __shared__ unsigned stamps[(DBG & 16) ? 32 : 1];
+  int n_stamp = 0;
+  auto stamp = [&]() {
+    if constexpr ((DBG & 16) != 0) {
+      if (tid == 0 && n_stamp < 32) stamps[n_stamp] = (unsigned)__builtin_amdgcn_s_memtime();
+      ++n_stamp;
+    }
+  };
+  stamp();                                           // 0: entry
   const int cloud = slot / g.spc, j = slot - cloud * g.spc;
   const int tpc = (g.N + BM - 1) / BM;
   const int p_begin = (int)((long long)j * tpc / g.spc), p_end = (int)((long long)(j + 1) * tpc / g.spc);
@@ -240,9 +249,13 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
   int cbs[CBW];
 #pragma unroll
   for (int i = 0; i < CBW; ++i) cbs[i] = (cg * CBW + i) * 8 + wave;
+  // peeled first panel (do_panel): bf16 mode, four register-resident blocks, a full first panel
+  constexpr bool CAN_PEEL = NS == 1 && (DBG & ~16) == 0 && CBW == 4 && RB == 4;
+  const bool peel = CAN_PEEL && g.N - p_begin * BM >= BM && p_begin < p_end;
 #pragma unroll
   for (int q = 0; q < NBLK; ++q) {
     const u32x4* __restrict__ src = ((q % NT) ? wfl : wfh) + (long long)cbs[q / NT] * KS * 64 + lane;
+    if (CAN_PEEL && q >= 2 && peel) continue;        // block-uniform
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       if (q < RB) bw[q][ks] = src[ks * 64];
@@ -255,23 +268,30 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
     coef[tid] = cav;
     coef[K + tid] = ccv;
   }
+  stamp();                                           // 1: every request of the prologue issued
   __syncthreads();                                   // the coefficient table
+  stamp();                                           // 2
   convert(p_begin, 0);
   __syncthreads();
+  stamp();                                           // 3: first panel staged
 
   // ---- the run's panels ------------------------------------------------------------------------------------------------------
   float best[CBW], ss[CBW];
   int bq[CBW];
 #pragma unroll
   for (int i = 0; i < CBW; ++i) { best[i] = -INFINITY; ss[i] = 0.f; bq[i] = 0; }
-  for (int pnl = p_begin; pnl < p_end; ++pnl) {
+  // The body of one panel.  FIRST (compile-time) = the run's first panel in the PEELED form: the prologue requested only the kernel
+  // fragments of column blocks 0 and 1; blocks 2 and 3 are requested from the gaps of chains 0 and 1, so the 256 KB of fragments
+  // (a CU takes in 64 bytes a cycle: ~4,400 cycles) arrive while the first panel is already being multiplied.
+  auto do_panel = [&](const int pnl, auto first_tag) {
+    constexpr bool FIRST = decltype(first_tag)::value;
     const int buf = (pnl - p_begin) & 1;
     const int nrows = min(BM, g.N - pnl * BM);
     const bool full = nrows == BM;                   // block-uniform
     // flies under this panel's MFMAs.  Unconditional (the run's last panel requests its own rows again and drops them): behind a
     // branch the staging registers are loop-carried values, and the compiler waits for everything in flight at the loop head
     issue(pnl + 1 < p_end ? pnl + 1 : pnl);
-    if constexpr (NS == 1 && DBG == 0) {
+    if constexpr (NS == 1 && (DBG & ~16) == 0) {
       if (full) {
         // ---- software-pipelined form (full panels, one bf16 image) ---------------------------------------------------------------
         // The panel's 2 x CBW (row block, column block) accumulators are walked as ONE chain of chains: while chain t's MFMAs issue,
@@ -281,6 +301,7 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
         // carries the MFMA -> VALU wait states), the hand-written max tree comes behind it.  Sums and maxima are taken in the same
         // association as the plain form below: bit-identical results.
         constexpr int NB = 2 * CBW;
+        constexpr int T_A = NB >= 4 ? NB / 2 : NB - 1, T_B = (3 * NB) / 4;     // where the two wave groups convert the next panel
         f32x16 acc2[2];
         bf16x8 af[KS];
         u32x4 bl_next;                                 // fragment of the LDS-resident column block, read one k-step ahead
@@ -326,11 +347,17 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
 #pragma unroll
           for (int e = 0; e < 16; ++e) acc[e] = 0.f;
           const bool from_lds = i * NT >= RB;          // this chain's B fragments come from LDS, one k-step ahead of their MFMA
-          // The next panel's conversion is vector-ALU work only.  Waves w and w + 4 share a SIMD: the first four waves convert here, in
-          // the middle of the panel, the other four behind the last chain -- while one wave of a SIMD converts, its partner has the
-          // matrix core to itself (in lockstep both would leave it idle for two conversions per panel)
-          if (NB >= 4 && t == NB / 2) {
-            if (wave < 4 && pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);
+          // The next panel's conversion is vector-ALU work only.  Waves w and w + 4 share a SIMD: the first four waves convert in the
+          // middle of the panel, the other four three quarters through -- while one wave of a SIMD converts, its partner has the
+          // matrix core to itself (in lockstep both would leave it idle for two conversions per panel).
+          // (Tried and dropped: the panel's barrier in front of its last chain, whose gaps then request the next panel's first A
+          // fragments -- the fragments become live across the panel boundary, 32 registers the kernel does not have: spills in the loop.)
+          if (t == T_A) {
+            if ((NB < 4 || wave < 4) && pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (NB >= 4 && t == T_B) {
+            if (wave >= 4 && pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
           }
 #pragma unroll
@@ -339,6 +366,9 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
             if (!from_lds) vbw = bw[i < RB ? i : 0][ks];
             else vbw = bl_next;
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, vbw), acc, 0, 0, 0);
+            if constexpr (FIRST && CAN_PEEL) {            // this k-step's fragment of the block two chains ahead
+              if (t < 2) bw[(t + 2) < RB ? t + 2 : 0][ks] = (wfh + (long long)cbs[(t + 2) < CBW ? t + 2 : 0] * KS * 64 + lane)[ks * 64];
+            }
             // the other row block's A fragments replace this one's as the last chain that needs them passes
             if (t == CBW - 1) af[ks] = *reinterpret_cast<const bf16x8*>(&Ap[buf][0][(32 + r) * PA + ks * 16 + h * 8]);
             // next LDS-resident fragment: the next k-step of this chain, or the first of the next chain
@@ -356,13 +386,12 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
             __builtin_amdgcn_sched_barrier(0);
           }
         }
-        // (the other four waves': between the last chain and its epilogue)
-        if ((NB < 4 || wave >= 4) && pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 7; ++u) unit(u, acc2[(NB - 1) & 1], (NB - 1) % CBW, pnl * 2 + 1);
         __syncthreads();
-        continue;
+        stamp();                                       // 4..: a panel done
+        return;
       }
     }
 #pragma unroll
@@ -430,11 +459,19 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
         asm volatile("" : "+v"(best[i]));
         // bf16 mode: only the ragged last panel of a cloud comes here -- one accumulator at a time, nothing carried across blocks
         // (registers, not speed: the pipelined form above sets this kernel's register budget)
-        if constexpr (NS == 1 && DBG == 0) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NS == 1 && (DBG & ~16) == 0) __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);    // the other image was last read before the previous barrier
     __syncthreads();
+  };
+  {
+    int pnl = p_begin;
+    if (peel) {
+      do_panel(pnl, BoolTag<true>{});
+      ++pnl;
+    }
+    for (; pnl < p_end; ++pnl) do_panel(pnl, BoolTag<false>{});
   }
 
   // ---- flush the run: one value per (slot, channel) --------------------------------------------------------------------------
@@ -454,10 +491,12 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
       if (STATS && g.sumsq) g.sumsq[o] = sv;
     }
   }
-  if (STATS && g.sumz) {
-    // sum over the slot's rows of z = (column sums of the staged rows) . W: the column sums a1 are gathered from the eight waves
-    // (lanes l, l + CH, ... of a wave hold the same 8 columns -> butterfly, one slot per (wave, column) in LDS, 8-way sum), then every
-    // lane dots them with the kernel fragments it still holds -- half of k per half-wave
+  stamp();                                           // maxima and sums of squares written
+  if (STATS && g.colsum) {
+    // Column sums a1 = A^T 1 of the slot's staged rows, gathered from the eight waves (lanes l, l + CH, ... of a wave hold the same 8
+    // columns -> butterfly, one slot per (wave, column) in LDS, 8-way sum).  The finaliser turns them into the channel sums of z:
+    // sum over ALL rows of z[:, c] = (sum over the slots of a1) . W[:, c] -- K*C multiply-adds per LAUNCH.  (Round 2 formed a1 . W
+    // here, per slot: K*C multiply-adds per workgroup, 5,200 cycles of an 11,000-cycle run at N = 1024.)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       for (int o = CH; o < 64; o <<= 1) {
@@ -477,28 +516,14 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) t += red[w][col];
-      a1s[col] = t;
+      g.colsum[(long long)slot * (NT * K) + col] = t;
     }
+  }
+  if constexpr ((DBG & 16) != 0) {
+    stamp();                                         // end
     __syncthreads();
-#pragma unroll
-    for (int i = 0; i < CBW; ++i) {
-      float sz = 0.f;
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const bf16x8 vh = __builtin_bit_cast(bf16x8, (i * NT < RB) ? bw[i * NT < RB ? i * NT : 0][ks] : Bl[wave][(i * NT - RB) * KS + ks][lane]);
-        bf16x8 vl;
-        if (NS == 3) vl = __builtin_bit_cast(bf16x8, (i * NT + 1 < RB) ? bw[i * NT + 1 < RB ? i * NT + 1 : 0][ks] : Bl[wave][(i * NT + 1 - RB) * KS + ks][lane]);
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-          const int kk = ks * 16 + h * 8 + jj;
-          const float wh = (float)vh[jj];
-          sz = fmaf(a1s[kk], wh, sz);                                   // a_hi . b_hi
-          if (NS == 3) sz = fmaf(a1s[K + kk], wh, fmaf(a1s[kk], (float)vl[jj], sz));     // + a_lo . b_hi + a_hi . b_lo
-        }
-      }
-      sz += __shfl_xor(sz, 32, 64);
-      if (h == 0) g.sumz[(long long)slot * g.C + cbs[i] * 32 + r] = sz;
-    }
+    if (tid < 32) g.pq[(long long)slot * g.C + tid] = tid < n_stamp ? (int)stamps[tid] : 0;
+    if (tid == 32) g.pq[(long long)slot * g.C + 32] = n_stamp;
   }
 }
 
@@ -514,6 +539,10 @@ static void launch_panel(const PanelArgs& g, dim3 grid, bool stats, hipStream_t 
   }
       PN_PANEL_DBG_CASE(1) PN_PANEL_DBG_CASE(4) PN_PANEL_DBG_CASE(8) PN_PANEL_DBG_CASE(9) PN_PANEL_DBG_CASE(13)
 #undef PN_PANEL_DBG_CASE
+      if (dbg == 16 && g.a.h16) {
+        hipLaunchKernelGGL((panel_max_kernel<1, 128, true, 4, 16, true>), grid, dim3(512), 0, st, g);
+        return;
+      }
     }
   }
   if constexpr (NS == 1) {
@@ -538,14 +567,14 @@ static void launch_panel_cbw(const PanelArgs& g, int C, bool stats, hipStream_t 
 }
 
 int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo, int B, int N, int K, int C, float* pmax, int* pq,
-                       float* sumsq, float* sumz, int prec, hipStream_t st) {
+                       float* sumsq, float* colsum, int prec, hipStream_t st) {
   PN_CHECK_ARG(x && x->s1 && !x->s2, "pn_conv_fwd_max_panel: bad operand");
   PN_CHECK_ARG((reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && x->ld % 4 == 0 && x->ld >= K, "pn_conv_fwd_max_panel: operand alignment");
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_fwd_max_panel: B and N must be positive");
   PN_CHECK_ARG(K == 64 || K == 128, "pn_conv_fwd_max_panel: K must be 64 or 128 (K=%d)", K);
   PN_CHECK_ARG(C >= 256 && C % 256 == 0 && (C / 256 == 1 || C / 256 == 2 || C % 1024 == 0), "pn_conv_fwd_max_panel: C must be 256, 512 or a multiple of 1024 (C=%d)", C);
   PN_CHECK_ARG(wf_hi && pmax && pq, "pn_conv_fwd_max_panel: null pointer");
-  PN_CHECK_ARG((sumsq == nullptr) == (sumz == nullptr), "pn_conv_fwd_max_panel: sumsq and sumz come together (both or neither)");
+  PN_CHECK_ARG((sumsq == nullptr) == (colsum == nullptr), "pn_conv_fwd_max_panel: sumsq and colsum come together (both or neither)");
   prec &= ~PN_STORE_BF16;
   PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && wf_lo), "pn_conv_fwd_max_panel: bad prec / missing lo weights");
   PN_CHECK_ARG(x->h16 == 0 || (x->h16 == 1 && prec == PN_PREC_BF16 && x->ld % 8 == 0),
@@ -555,7 +584,7 @@ int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo
   g.a = *x; g.wf_hi = reinterpret_cast<const __bf16*>(wf_hi); g.wf_lo = reinterpret_cast<const __bf16*>(wf_lo);
   g.B = B; g.N = N; g.C = C;
   g.spc = panel_slots_per_cloud(B, N);
-  g.pmax = pmax; g.pq = pq; g.sumsq = sumsq; g.sumz = sumz;
+  g.pmax = pmax; g.pq = pq; g.sumsq = sumsq; g.colsum = colsum;
   const bool st_ = sumsq != nullptr;
   if (prec == PN_PREC_BF16X3) {
     if (K == 128) launch_panel_cbw<3, 128>(g, C, st_, st);
@@ -569,14 +598,17 @@ int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo
 }
 
 // ---- finaliser: BatchNormalization statistics of the layer + reduce_max over each cloud's slots ------------------------------------
-// One workgroup per (32 channels, slice of the clouds).  Training statistics (use_batch): per channel the sums of sumz and sumsq over
-// all slots, combined in fp64 -> mean (times the channel's sign: the panel kernel works on sgn * z), invstd, scale, shift, moving
-// statistics (only the workgroups of the first cloud slice write them); otherwise the coefficients come from the moving statistics
-// (inference / frozen layer, PointNet.py:585-591).  Then per cloud: the largest pmax over its slots (lowest slot on ties: rows ascend
-// with the slot index), zstar = s_c * max, g = relu(scale * zstar + shift), and the 32-row block that holds the row.
+// One workgroup per (32 channels, slice of the clouds).  Training statistics (use_batch): the slots' column sums of the staged operand
+// are added up (fp64) into A1 = A^T 1 over ALL rows and sum z[:, c] = A1 . W[:, c] is formed from the same fragment-ordered bf16 copy
+// of the kernel the panel launch multiplied with (hi, and for bf16x3 the three cross terms the matrix cores summed); the slots' sums of
+// squares are added per channel; combined in fp64 -> mean (times the channel's sign: the panel kernel works on sgn * z), invstd,
+// scale, shift, moving statistics (only the workgroups of the first cloud slice write them); otherwise the coefficients come from the
+// moving statistics (inference / frozen layer, PointNet.py:585-591).  Then per cloud: the largest pmax over its slots (lowest slot on
+// ties: rows ascend with the slot index), zstar = s_c * max, g = relu(scale * zstar + shift), and the 32-row block that holds the row.
 struct PanelFinArgs {
-  const float* pmax; const int* pq; const float* sumsq; const float* sumz;
-  int T, tpc, B, C, n_blocks32;
+  const float* pmax; const int* pq; const float* sumsq; const float* colsum;
+  const unsigned short *wf_hi, *wf_lo;      // fragment-ordered kernel copies (pn_weights_prep); wf_lo for bf16x3
+  int T, tpc, B, C, K, NT, n_blocks32;
   double inv_count;
   const float* gamma; const float* beta; float* mm; float* mv;
   float momentum, eps;
@@ -584,28 +616,78 @@ struct PanelFinArgs {
   float *mean, *invstd, *scale, *shift, *g, *zstar;
   int* argq;
 };
+constexpr int PANEL_FIN_MAXK = 128;
 __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs a) {
   __shared__ double red[8][2][32];
+  __shared__ double A1[2 * PANEL_FIN_MAXK];
+  __shared__ double A1part[8 * PANEL_FIN_MAXK];      // [group][column]: 8 groups x 128 columns, or 4 x 256
   __shared__ float sc_s[32], sh_s[32], sg_s[32];
   const int tid = threadIdx.x, cl = tid & 31, part = tid >> 5;
   const int c = blockIdx.x * 32 + cl;
   const float gam = a.gamma[c];
   const float sg = gam < 0.f ? -1.f : 1.f;
   if (a.use_batch) {
-    // thread <-> (channel, every 8th slot): sixteen slots (32 independent loads) in flight, summed in slot order
+    // A1[col] = sum over the slots of colsum[slot][col]: thread <-> (four columns, every `groups`-th slot), sixteen 16-byte loads in
+    // flight; the groups' partial sums meet in LDS and are added in group order (fixed order: reproducible)
+    const int ncol = a.NT * a.K, nq = ncol >> 2, groups = 256 / nq;
+    {
+      const int cq = tid % nq, gi = tid / nq;
+      double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+      for (int p = gi; p < a.T; p += groups * 16) {
+        float4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const int pp = p + u * groups;
+          v[u] = *reinterpret_cast<const float4*>(a.colsum + (long long)(pp < a.T ? pp : p) * ncol + 4 * cq);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (p + u * groups < a.T) { t0 += (double)v[u].x; t1 += (double)v[u].y; t2 += (double)v[u].z; t3 += (double)v[u].w; }
+      }
+      double* dst = &A1part[gi * ncol + 4 * cq];
+      dst[0] = t0; dst[1] = t1; dst[2] = t2; dst[3] = t3;
+    }
+    // thread <-> (channel, every 8th slot): sixteen slots in flight, summed in slot order
     double s1 = 0.0, s2 = 0.0;
     for (int p = part; p < a.T; p += 8 * 16) {
-      float v[16], q[16];
+      float q[16];
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int pp = p + u * 8;
-        const long long o = (long long)(pp < a.T ? pp : p) * a.C + c;
-        v[u] = a.sumz[o];
-        q[u] = a.sumsq[o];
+        q[u] = a.sumsq[(long long)(pp < a.T ? pp : p) * a.C + c];
       }
 #pragma unroll
       for (int u = 0; u < 16; ++u)
-        if (p + u * 8 < a.T) { s1 += (double)v[u]; s2 += (double)q[u]; }
+        if (p + u * 8 < a.T) s2 += (double)q[u];
+    }
+    __syncthreads();
+    if (tid < ncol) {
+      double t = 0.0;
+      for (int q = 0; q < groups; ++q) t += A1part[q * ncol + tid];
+      A1[tid] = t;
+    }
+    __syncthreads();
+    // sum z = A1 . W[:, c]: thread (channel, part) takes the k-steps part, part + 8, ... of its column: the sixteen k of a step are the
+    // two 16-byte fragments of lanes (c % 32) and (c % 32) + 32
+    {
+      const int KS = a.K / 16;
+      const long long cb = c >> 5;
+      for (int ks = part; ks < KS; ks += 8) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const long long fo = ((cb * KS + ks) * 64 + hh * 32 + cl) * 8;
+          const uint4 wh = *reinterpret_cast<const uint4*>(a.wf_hi + fo);
+          float whf[8], wlf[8];
+          bf16x8_unpack(wh, whf);
+          if (a.NT == 2) bf16x8_unpack(*reinterpret_cast<const uint4*>(a.wf_lo + fo), wlf);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int k = ks * 16 + hh * 8 + e;
+            s1 += A1[k] * (double)whf[e];
+            if (a.NT == 2) s1 += A1[a.K + k] * (double)whf[e] + A1[k] * (double)wlf[e];
+          }
+        }
+      }
     }
     red[part][0][cl] = s1;
     red[part][1][cl] = s2;
@@ -665,15 +747,21 @@ __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs 
   }
 }
 
-int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const float* sumz, int B, int N, int C, const float* gamma,
-                   const float* beta, float* mm, float* mv, float momentum, float eps, int use_batch, int update, float* mean, float* invstd,
-                   float* scale, float* shift, float* g, float* zstar, int* argq, hipStream_t st) {
+int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const float* colsum, const void* wf_hi, const void* wf_lo, int prec,
+                   int B, int N, int K, int C, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps,
+                   int use_batch, int update, float* mean, float* invstd, float* scale, float* shift, float* g, float* zstar, int* argq,
+                   hipStream_t st) {
   PN_CHECK_ARG(pmax && pq && gamma && beta && mm && mv && mean && invstd && scale && shift && g, "pn_panel_finalize: null pointer");
-  PN_CHECK_ARG(!use_batch || (sumsq && sumz), "pn_panel_finalize: batch statistics need sumsq and sumz");
+  prec &= ~PN_STORE_BF16;
+  PN_CHECK_ARG(!use_batch || (sumsq && colsum && wf_hi && (prec != PN_PREC_BF16X3 || wf_lo)),
+               "pn_panel_finalize: batch statistics need sumsq, colsum and the kernel copies");
   PN_CHECK_ARG(B > 0 && N > 0 && C > 0 && C % 32 == 0, "pn_panel_finalize: bad sizes");
+  PN_CHECK_ARG(!use_batch || ((K == 64 || K == 128) && (prec == PN_PREC_BF16 || prec == PN_PREC_BF16X3)), "pn_panel_finalize: K must be 64 or 128 (K=%d), prec bf16 or bf16x3", K);
   PanelFinArgs a;
   memset(&a, 0, sizeof(a));
-  a.pmax = pmax; a.pq = pq; a.sumsq = sumsq; a.sumz = sumz;
+  a.pmax = pmax; a.pq = pq; a.sumsq = sumsq; a.colsum = colsum;
+  a.wf_hi = reinterpret_cast<const unsigned short*>(wf_hi); a.wf_lo = reinterpret_cast<const unsigned short*>(wf_lo);
+  a.K = K; a.NT = prec == PN_PREC_BF16X3 ? 2 : 1;
   a.tpc = panel_slots_per_cloud(B, N); a.T = B * a.tpc; a.B = B; a.C = C;
   a.n_blocks32 = cdiv(N, 32);
   a.inv_count = 1.0 / ((double)B * (double)N);

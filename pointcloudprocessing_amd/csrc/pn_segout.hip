@@ -233,14 +233,18 @@ __global__ __launch_bounds__(SEG_RPB) void seg_out_fwd_kernel(const pn_operand x
 //     BatchNormalization + ReLU applied to the stored value, hi + lo operands for the output layer), so the two plans agree bit for
 //     bit -- tests/test_gpu_model.py compares them.
 // Five launches and ~67 MB of stored activations (C2) become one launch and none.
-constexpr int SH_ROWS = 64;
+constexpr int SH_ROWS = 64;                                               // rows per loss / accuracy partial (and per tile of the 64-row form)
 constexpr int SH_P64 = 64 + 8, SH_P128 = 128 + 8, SH_P256 = 256 + 8;     // LDS pitches (bf16 elements): conflict-free 16-byte rows
 constexpr int SH_PF = 128 + 4;                                            // fp32 pitch of the output layer's input
-constexpr int SH_REGION_A = (SH_ROWS * SH_P64 + SH_ROWS * SH_P128) * 2;   // input tile + seg_l1 chunk; later seg_l3's output, then the
+// A workgroup takes MB 32-row blocks: 64 rows (two workgroups per CU), or 128 rows (one per CU) -- every workgroup streams ALL of the
+// head's kernels (424 KB of bf16 fragments) from L2 whatever its height, and at 64 rows that traffic (217 MB at B*N = 32,768) is what
+// bounds the launch; 128 rows halve it.  The taller form is used when it still fills the chip (seg_head_fused).
+constexpr int sh_region_a(int rows) { return (rows * SH_P64 + rows * SH_P128) * 2; }   // input tile + seg_l1 chunk; later seg_l3's output, then the
                                                                           // output layer's kernel image and logit tile
-constexpr int SH_REGION_B = SH_ROWS * SH_P256 * 2;                        // seg_l2's output; later the output layer's fp32 input
-static_assert(SH_ROWS * SH_PF * 4 <= SH_REGION_B, "region B holds the fp32 input of the output layer");
-static_assert(2 * 32 * SEG_WP * 2 + SH_ROWS * (SEG_CM + 1) * 4 <= SH_REGION_A, "region A holds the output kernel image and the logit tile");
+constexpr int sh_region_b(int rows) { return rows * SH_P256 * 2; }                      // seg_l2's output; later the output layer's fp32 input
+static_assert(64 * SH_PF * 4 <= sh_region_b(64) && 128 * SH_PF * 4 <= sh_region_b(128), "region B holds the fp32 input of the output layer");
+static_assert(2 * 32 * SEG_WP * 2 + 64 * (SEG_CM + 1) * 4 <= sh_region_a(64) && 2 * 32 * SEG_WP * 2 + 128 * (SEG_CM + 1) * 4 <= sh_region_a(128),
+              "region A holds the output kernel image and the logit tile");
 struct SegHeadArgs {
   pn_operand x;                                     // (B*N, 64) lazy operand: X_64 (or relu(bn(mlp_1_2)) for the vanilla model)
   const float* gb;                                  // (B, 512) global-feature half of seg_l1, per cloud
@@ -279,10 +283,12 @@ __device__ __forceinline__ float sh_bnrelu(float z, float sc, float sh, int s16)
 // Workgroup barrier for LDS hand-offs only: this wave's LDS traffic is drained, the global loads in flight are NOT (__syncthreads
 // waits for vmcnt(0) too, which would land every prefetched fragment at the next barrier: one memory round trip per barrier)
 #define SH_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-__global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArgs a) {
+template <int MB>
+__global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(const SegHeadArgs a) {
+  constexpr int ROWS = 32 * MB, SH_REGION_A = sh_region_a(ROWS);
   extern __shared__ __attribute__((aligned(16))) unsigned char sh_sm[];
   __bf16* Ain = reinterpret_cast<__bf16*>(sh_sm);
-  __bf16* S1c = Ain + SH_ROWS * SH_P64;
+  __bf16* S1c = Ain + ROWS * SH_P64;
   __bf16* S3 = reinterpret_cast<__bf16*>(sh_sm);
   __bf16* S2 = reinterpret_cast<__bf16*>(sh_sm + SH_REGION_A);
   float* S4f = reinterpret_cast<float*>(sh_sm + SH_REGION_A);
@@ -292,12 +298,13 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int cloud = blockIdx.x / a.tiles_per_cloud, tin = blockIdx.x - cloud * a.tiles_per_cloud;
-  const int r0 = tin * SH_ROWS, nrows = min(SH_ROWS, a.N - r0);
+  const int r0 = tin * ROWS, nrows = min(ROWS, a.N - r0);
   const long long row0 = (long long)cloud * a.N + r0;
 
   // ---- the tile's 64 input channels -> LDS (bf16 operand precision; rows past the cloud are zero rows) ----
-  {
-    const int row = tid >> 2, c0 = (tid & 3) * 16;
+#pragma unroll
+  for (int pass = 0; pass < ROWS / 64; ++pass) {
+    const int row = pass * 64 + (tid >> 2), c0 = (tid & 3) * 16;
     float v[16];
     const long long src = (row0 + min(row, nrows - 1)) * a.x.ld + c0;
     if (a.x.h16) {
@@ -330,9 +337,9 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
   };
 
   // ---- seg_l1 in four 128-channel chunks, each at once a K-chunk of seg_l2 ----
-  seg_f32x16 acc2[2][2];
+  seg_f32x16 acc2[MB][2];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < MB; ++m)
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
@@ -352,9 +359,9 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
   SH_KEEP_ABOVE();
 #pragma unroll 1
   for (int j = 0; j < 4; ++j) {
-    seg_f32x16 acc1[2];
+    seg_f32x16 acc1[MB];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc1[m][e] = 0.f;
     const int c1 = 128 * j + 32 * wave + r;                 // this lane's seg_l1 channel
@@ -363,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc1[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(Ain, SH_P64, m, ks * 16), b1[ks], acc1[m], 0, 0, 0);
+      for (int m = 0; m < MB; ++m) acc1[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(Ain, SH_P64, m, ks * 16), b1[ks], acc1[m], 0, 0, 0);
     }
     // next chunk's seg_l1 fragments: under this chunk's epilogue and seg_l2 steps.  Unconditional (the last chunk re-requests its
     // own): behind a branch the compiler must assume at the join that the requests were NOT made and waits for everything
@@ -372,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
     for (int ks = 0; ks < 4; ++ks) b1[ks] = bfrag(a.w1t, 64, 128 * jn + 32 * wave + r, ks * 16);
     SH_KEEP_ABOVE();
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MB; ++m) {
       float y[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) y[e] = sh_bnrelu(acc1[m][e] + bias, sc, sh, a.s16);
@@ -382,7 +389,7 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+      for (int m = 0; m < MB; ++m) {
         const seg_bf16x8 af = afrag(S1c, SH_P128, m, ks * 16);
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2[ks][n], acc2[m][n], 0, 0, 0);
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
     const int c2 = 64 * wave + 32 * n + r;
     const float sc = sc2v[n], sh = sh2v[n];
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < MB; ++m) {
       float y[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) y[e] = sh_bnrelu(acc2[m][n][e], sc, sh, a.s16);
@@ -415,15 +422,15 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
   SH_BARRIER();
   // ---- seg_l3 (256 -> 128): 32 columns per wave ----
   {
-    seg_f32x16 acc[2];
+    seg_f32x16 acc[MB];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(S2, SH_P256, m, ks * 16), b3[ks & 7], acc[m], 0, 0, 0);
+      for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(S2, SH_P256, m, ks * 16), b3[ks & 7], acc[m], 0, 0, 0);
       if (ks < 8) {                                         // steps 8..15 take over the registers of steps 0..7
         b3[ks] = bfrag(a.w3t, 256, c3, (ks + 8) * 16);
         SH_KEEP_ABOVE();
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
     }
     const float sc = sc3v, sh = sh3v;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {                             // region A: the input tile and chunk image are dead
+    for (int m = 0; m < MB; ++m) {                             // region A: the input tile and chunk image are dead
       float y[16];
 #pragma unroll
       for (int e = 0; e < 16; ++e) y[e] = sh_bnrelu(acc[m][e], sc, sh, a.s16);
@@ -441,19 +448,19 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
   SH_BARRIER();
   // ---- seg_l4 (128 -> 128) -> the output layer's input, fp32 (it is split hi + lo there, as in seg_out_fwd) ----
   {
-    seg_f32x16 acc[2];
+    seg_f32x16 acc[MB];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[m][e] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(S3, SH_P128, m, ks * 16), b4[ks], acc[m], 0, 0, 0);
+      for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(S3, SH_P128, m, ks * 16), b4[ks], acc[m], 0, 0, 0);
     }
     const float sc = sc4v, sh = sh4v;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const int row = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -470,7 +477,7 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
     W5lo[c * SEG_WP + k] = (__bf16)(v - (float)hi);
   }
   SH_BARRIER();
-  if (wave < 2) {
+  if (wave < MB) {
     seg_f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -499,22 +506,23 @@ __global__ __launch_bounds__(256, 2) void seg_head_fused_kernel(const SegHeadArg
   }
   SH_BARRIER();
   // ---- softmax, loss, accuracy, d(logits): one thread per point (wave 0) ----
-  if (wave == 0) {
+  if (wave < MB / 2) {                                   // waves 0 (, 1): rows 64 * wave + lane
+    const int prow = 64 * wave + lane;
     float loss = 0.f, corr = 0.f;
     float dl[SEG_CM];
 #pragma unroll
     for (int c = 0; c < SEG_CM; ++c) dl[c] = 0.f;
-    if (lane < nrows) {
+    if (prow < nrows) {
       float acc[SEG_CM];
 #pragma unroll
       for (int c = 0; c < SEG_CM; ++c) {
         acc[c] = (c < a.C && a.b5) ? a.b5[c] : 0.f;
-        acc[c] += lgt[lane * (SEG_CM + 1) + c];
+        acc[c] += lgt[prow * (SEG_CM + 1) + c];
       }
-      seg_row_tail(acc, a.C, row0 + lane, a.labels, a.grad_scale, a.probs, a.dlogits, loss, corr, dl);
+      seg_row_tail(acc, a.C, row0 + prow, a.labels, a.grad_scale, a.probs, a.dlogits, loss, corr, dl);
     }
-    if (a.part) {
-      float* p = a.part + (long long)blockIdx.x * (2 + SEG_CM);
+    if (a.part && r0 + 64 * wave < a.N) {             // one partial per 64 rows of a cloud, whatever the tile height
+      float* p = a.part + ((long long)cloud * ((a.N + 63) / 64) + (r0 >> 6) + wave) * (2 + SEG_CM);
       const float l = wave_sum(loss), cr = wave_sum(corr);
       if (lane == 0) { p[0] = l; p[1] = cr; }
 #pragma unroll
@@ -542,9 +550,20 @@ int seg_head_fused(const pn_operand* x, const float* gb, const void* w1t, const 
   a.w1t = reinterpret_cast<const unsigned short*>(w1t); a.w2t = reinterpret_cast<const unsigned short*>(w2t);
   a.w3t = reinterpret_cast<const unsigned short*>(w3t); a.w4t = reinterpret_cast<const unsigned short*>(w4t);
   a.sc1 = sc1; a.sh1 = sh1; a.sc2 = sc2; a.sh2 = sh2; a.sc3 = sc3; a.sh3 = sh3; a.sc4 = sc4; a.sh4 = sh4;
-  a.w5 = w5; a.b5 = b5; a.N = N; a.C = C; a.tiles_per_cloud = cdiv(N, SH_ROWS); a.s16 = s16;
+  a.w5 = w5; a.b5 = b5; a.N = N; a.C = C; a.s16 = s16;
   a.labels = labels; a.grad_scale = grad_scale; a.probs = probs; a.dlogits = dlogits; a.part = part;
-  hipLaunchKernelGGL(seg_head_fused_kernel, dim3(B * a.tiles_per_cloud), dim3(256), SH_REGION_A + SH_REGION_B, st, a);
+  static const int force_mb = getenv("PN_SEGHEAD_MB") ? atoi(getenv("PN_SEGHEAD_MB")) : 0;     // experiment switch: 2 or 4
+  const bool tall = force_mb ? force_mb == 4 : (long long)B * cdiv(N, 128) >= 256;               // 128-row tiles while they still fill the chip
+  if (tall) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_head_fused_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       sh_region_a(128) + sh_region_b(128));
+    (void)attr;
+    a.tiles_per_cloud = cdiv(N, 128);
+    hipLaunchKernelGGL(seg_head_fused_kernel<4>, dim3(B * a.tiles_per_cloud), dim3(256), sh_region_a(128) + sh_region_b(128), st, a);
+  } else {
+    a.tiles_per_cloud = cdiv(N, 64);
+    hipLaunchKernelGGL(seg_head_fused_kernel<2>, dim3(B * a.tiles_per_cloud), dim3(256), sh_region_a(64) + sh_region_b(64), st, a);
+  }
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

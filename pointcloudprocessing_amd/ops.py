@@ -78,27 +78,29 @@ def weights_prep(w, sgn=None):
 
 def conv_fwd_max_panel(x_op, wf, B, N, K, C_, prec, want_stats=True):
     """the row-panel kernel: per slot (run of 64-row panels) and channel max of sgn*z, the 32-row block holding it and (want_stats)
-    sum z^2 and sum sgn*z.  wf = weights_prep(w, gamma)."""
+    sum z^2, and per slot the column sums of the staged operand rows (panel_finalize turns those into the channel sums of z).
+    wf = weights_prep(w, gamma)."""
     dev = wf[0].device
     T = B * lib().pn_panel_slots_per_cloud(B, N)
     pmax = torch.empty(T, C_, device=dev, dtype=F32)
     pblk = torch.empty(T, C_, device=dev, dtype=torch.int32)
     sumsq = torch.empty(T, C_, device=dev, dtype=F32) if want_stats else None
-    sumz = torch.empty(T, C_, device=dev, dtype=F32) if want_stats else None
-    check(lib().pn_conv_fwd_max_panel(C.byref(x_op), ptr(wf[0]), ptr(wf[1]), B, N, K, C_, ptr(pmax), ptr(pblk), ptr(sumsq), ptr(sumz), prec,
+    colsum = torch.empty(T, (2 if (prec & 3) == 3 else 1) * K, device=dev, dtype=F32) if want_stats else None
+    check(lib().pn_conv_fwd_max_panel(C.byref(x_op), ptr(wf[0]), ptr(wf[1]), B, N, K, C_, ptr(pmax), ptr(pblk), ptr(sumsq), ptr(colsum), prec,
                                       current_stream()), "pn_conv_fwd_max_panel")
-    return pmax, pblk, sumsq, sumz
+    return pmax, pblk, sumsq, colsum
 
 
-def panel_finalize(pmax, pblk, sumsq, sumz, B, N, gamma, beta, moving_mean, moving_var, training=True, momentum=0.99, eps=1e-3):
-    """BN coefficients of the layer + reduce_max over each cloud's tiles -> (mean, invstd, scale, shift, g, zstar, arg_block)"""
+def panel_finalize(pmax, pblk, sumsq, colsum, wf, prec, B, N, K, gamma, beta, moving_mean, moving_var, training=True, momentum=0.99, eps=1e-3):
+    """BN coefficients of the layer + reduce_max over each cloud's tiles -> (mean, invstd, scale, shift, g, zstar, arg_block);
+    wf, prec, K: what the panel launch was given"""
     C_ = pmax.shape[1]
     dev = pmax.device
     mean, invstd, scale, shift = (torch.empty(C_, device=dev, dtype=F32) for _ in range(4))
     g = torch.empty(B, C_, device=dev, dtype=F32)
     zstar = torch.empty(B, C_, device=dev, dtype=F32)
     argb = torch.empty(B, C_, device=dev, dtype=torch.int32)
-    check(lib().pn_panel_finalize(ptr(pmax), ptr(pblk), ptr(sumsq), ptr(sumz), B, N, C_,
+    check(lib().pn_panel_finalize(ptr(pmax), ptr(pblk), ptr(sumsq), ptr(colsum), ptr(wf[0]), ptr(wf[1]), prec, B, N, K, C_,
                                   ptr(gamma), ptr(beta), ptr(moving_mean), ptr(moving_var), momentum, eps, int(training), int(training),
                                   ptr(mean), ptr(invstd), ptr(scale), ptr(shift), ptr(g), ptr(zstar), ptr(argb), current_stream()),
           "pn_panel_finalize")

@@ -160,7 +160,7 @@ def test_conv_fwd_max_matches_reduce_max(dev, prec, B, N, panel):
         wf = ops.weights_prep(w.to(dev), gamma.to(dev))
         pmax, pblk, sumsq, sumz = ops.conv_fwd_max_panel(op, wf, B, N, K, C, prec)
         mmd, mvd = mm.to(dev), mv.to(dev)
-        mean, invstd, scale, shift, gfeat, zstar, argb = ops.panel_finalize(pmax, pblk, sumsq, sumz, B, N, gamma.to(dev), beta.to(dev), mmd, mvd,
+        mean, invstd, scale, shift, gfeat, zstar, argb = ops.panel_finalize(pmax, pblk, sumsq, sumz, wf, prec, B, N, K, gamma.to(dev), beta.to(dev), mmd, mvd,
                                                                            training=True)
         arg = ops.max_resolve(op, wf, argb, B, N, K, C, prec)
         assert int(argb.min()) >= 0 and int(argb.max()) <= (N - 1) // 32
@@ -208,7 +208,7 @@ def test_panel_path_on_real_valued_clouds_with_duplicated_points(dev, prec):
     wf = ops.weights_prep(w.to(dev), gamma.to(dev))
     pmax, pblk, sumsq, sumz = ops.conv_fwd_max_panel(op, wf, B, N, K, C, prec)
     mmd, mvd = torch.zeros(C, device=dev), torch.ones(C, device=dev)
-    mean, invstd, scale, shift, gfeat, zstar, argb = ops.panel_finalize(pmax, pblk, sumsq, sumz, B, N, gamma.to(dev), beta.to(dev), mmd, mvd,
+    mean, invstd, scale, shift, gfeat, zstar, argb = ops.panel_finalize(pmax, pblk, sumsq, sumz, wf, prec, B, N, K, gamma.to(dev), beta.to(dev), mmd, mvd,
                                                                        training=True)
     arg = ops.max_resolve(op, wf, argb, B, N, K, C, prec).cpu().long()
     a = lazy_ref(x, sc, sh, relu=True).float()
@@ -722,7 +722,7 @@ def test_bf16_storage_panel_kernel_and_resolve(dev, B, N):
         op = L.operand(src, ca=ca, cc=cc, relu=True)
         pmax, pblk, sumsq, sumz = ops.conv_fwd_max_panel(op, wf, B, N, K, C_, 1)
         beta = torch.zeros(C_, device=dev); mm = torch.zeros(C_, device=dev); mv = torch.ones(C_, device=dev)
-        fin = ops.panel_finalize(pmax, pblk, sumsq, sumz, B, N, gamma, beta, mm, mv, training=True)
+        fin = ops.panel_finalize(pmax, pblk, sumsq, sumz, wf, 1, B, N, K, gamma, beta, mm, mv, training=True)
         arg = ops.max_resolve(op, wf, fin[-1], B, N, K, C_, 1)
         res.append((pmax, pblk, sumsq, sumz, arg))
     for a_, b_ in zip(res[0], res[1]):

@@ -24,12 +24,12 @@ for B, N in ((32, 1024), (32, 4096)):
         for dbg in (0, 1, 2, 4, 8, 15):
             os.environ["PN_FIN_DBG"] = str(dbg)
             for _ in range(3):
-                ops.panel_finalize(pmax, pblk, sumsq, sumz, B, N, gamma, beta, mm, mv, training=True)
+                ops.panel_finalize(pmax, pblk, sumsq, sumz, wf, prec, B, N, K, gamma, beta, mm, mv, training=True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize()
             e0.record()
             for _ in range(50):
-                ops.panel_finalize(pmax, pblk, sumsq, sumz, B, N, gamma, beta, mm, mv, training=True)
+                ops.panel_finalize(pmax, pblk, sumsq, sumz, wf, prec, B, N, K, gamma, beta, mm, mv, training=True)
             e1.record()
             torch.cuda.synchronize()
             print(json.dumps({"B": B, "N": N, "prec": prec, "dbg": dbg, "us": round(e0.elapsed_time(e1) * 1e3 / 50, 2)}), flush=True)
