@@ -161,11 +161,12 @@ def main():
         return model.workspace_tensor(name, B, N, True, dtype)
     REPS = 20
     calls = []
+    colacc = torch.zeros(B, K_, device=model.params_flat.device, dtype=torch.int64)      # the launches' column-sum accumulators (values unused here)
     for src, ml in layers:
         op = _lib.operand(wsf(src + ".Z", model.activation_dtype).view(B * N, K_), ca=wsf(src + ".scale"), cc=wsf(src + ".shift"), relu=True)
         calls.append((op, (C.byref(op), _lib.ptr(wsf(ml + ".wb_hi", torch.bfloat16)), _lib.ptr(wsf(ml + ".wb_lo", torch.bfloat16)), B, N, K_, C_,
                            _lib.ptr(wsf(ml + ".pmax")), _lib.ptr(wsf(ml + ".pq", torch.int32)), _lib.ptr(wsf(ml + ".sumsq")),
-                           _lib.ptr(wsf(ml + ".colsum")), prec_id, _lib.current_stream())))
+                           _lib.ptr(colacc), prec_id, _lib.current_stream())))
     for _ in range(3):
         for _, a in calls:
             _lib.check(_lib.lib().pn_conv_fwd_max_panel(*a), "pn_conv_fwd_max_panel")

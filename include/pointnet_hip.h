@@ -129,18 +129,20 @@ int pn_conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, in
  * K in {64, 128}; C = 256, 512 or a multiple of 1024; slots = B * pn_panel_slots_per_cloud(B, N).  Per slot and channel the kernel emits
  *     pmax   = max over the run's rows of s_c * z,      pblock = index inside the cloud of the 32-row block holding it (lowest on ties),
  *     sumsq  = sum over the rows of z^2,
- * and per slot colsum[slot][NT * K] = the column sums of the staged operand rows (the bf16 hi image, then -- bf16x3, NT = 2 -- the lo
- * image; NT = 1 otherwise): the channel sums of z are not accumulated element by element, nor per slot -- the finaliser forms
- * sum z[:, c] = (sum over the slots of colsum) . W[:, c] once per launch      (sumsq and colsum: both or neither; NULL for inference). */
+ * and ADDS to colacc[cloud][NT * K] the column sums of the cloud's staged operand rows (the bf16 hi image, then -- bf16x3, NT = 2 -- the
+ * lo image; NT = 1 otherwise) as 64-bit fixed point, unit 2^-24 (integer adds: the result does not depend on the order the cloud's
+ * workgroups arrive in; the caller zeroes colacc before the launch -- the model plan's first launch does).  The channel sums of z are
+ * not accumulated element by element, nor per slot: the finaliser forms sum z[:, c] = (sum over the clouds of colacc) . W[:, c] once
+ * per launch      (sumsq and colacc: both or neither; NULL for inference). */
 int pn_weights_prep(const float* w, const float* sgn, int K, int C, void* wf_hi, void* wf_lo, pn_stream stream);
 int pn_panel_slots_per_cloud(int B, int N);
 int pn_conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo, int B, int N, int K, int C, float* pmax,
-                          int32_t* pblock, float* sumsq, float* colsum, int prec, pn_stream stream);
+                          int32_t* pblock, float* sumsq, int64_t* colacc, int prec, pn_stream stream);
 /* finaliser of the panel kernel: BatchNormalization coefficients of the layer (as pn_bn_finalize; batch statistics from the slots'
- * colsum / sumsq and the SAME kernel copies wf_hi / wf_lo and prec the panel launch was given, or the moving statistics -- then colsum,
+ * colacc / sumsq and the SAME kernel copies wf_hi / wf_lo and prec the panel launch was given, or the moving statistics -- then colacc,
  * sumsq and the copies may be NULL) AND tf.reduce_max over each cloud's slots:  zstar[b][c] = s_c * max,
  * g[b][c] = relu(scale*zstar + shift), arg_block[b][c] = the 32-row block of cloud b holding the row of the maximum. */
-int pn_panel_finalize(const float* pmax, const int32_t* pblock, const float* sumsq, const float* colsum, const void* wf_hi, const void* wf_lo,
+int pn_panel_finalize(const float* pmax, const int32_t* pblock, const float* sumsq, const int64_t* colacc, const void* wf_hi, const void* wf_lo,
                       int prec, int B, int N, int K, int C, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
                       float momentum, float eps, int use_batch_stats, int update_moving, float* mean, float* invstd, float* scale, float* shift,
                       float* g, float* zstar, int32_t* arg_block, pn_stream stream);

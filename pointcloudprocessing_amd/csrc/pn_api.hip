@@ -43,14 +43,14 @@ int pn_weights_prep(const float* w, const float* sgn, int K, int C, void* wf_hi,
 }
 int pn_panel_slots_per_cloud(int B, int N) { return (B > 0 && N > 0) ? panel_slots_per_cloud(B, N) : 0; }
 int pn_conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo, int B, int N, int K, int C, float* pmax,
-                          int32_t* pblock, float* sumsq, float* colsum, int prec, pn_stream stream) {
-  return conv_fwd_max_panel(x, wf_hi, wf_lo, B, N, K, C, pmax, pblock, sumsq, colsum, prec, S(stream));
+                          int32_t* pblock, float* sumsq, int64_t* colacc, int prec, pn_stream stream) {
+  return conv_fwd_max_panel(x, wf_hi, wf_lo, B, N, K, C, pmax, pblock, sumsq, reinterpret_cast<long long*>(colacc), prec, S(stream));
 }
-int pn_panel_finalize(const float* pmax, const int32_t* pblock, const float* sumsq, const float* colsum, const void* wf_hi, const void* wf_lo,
+int pn_panel_finalize(const float* pmax, const int32_t* pblock, const float* sumsq, const int64_t* colacc, const void* wf_hi, const void* wf_lo,
                       int prec, int B, int N, int K, int C, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
                       float momentum, float eps, int use_batch_stats, int update_moving, float* mean, float* invstd, float* scale, float* shift,
                       float* g, float* zstar, int32_t* arg_block, pn_stream stream) {
-  return panel_finalize(pmax, pblock, sumsq, colsum, wf_hi, wf_lo, prec, B, N, K, C, gamma, beta, moving_mean, moving_var, momentum, eps,
+  return panel_finalize(pmax, pblock, sumsq, reinterpret_cast<const long long*>(colacc), wf_hi, wf_lo, prec, B, N, K, C, gamma, beta, moving_mean, moving_var, momentum, eps,
                         use_batch_stats, update_moving, mean, invstd, scale, shift, g, zstar, arg_block, S(stream));
 }
 int pn_max_resolve(const pn_operand* x, const void* wf_hi, const void* wf_lo, const int32_t* arg_block, int B, int N, int K, int C,

@@ -81,6 +81,20 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a0, co
   const bool single = a.nsplit == 1;
   const bool small = a.R <= DL_ROWS;           // block-uniform: one row chunk, the tail keeps z in registers
   float own[DL_ROWS / DL_SLICES];
+  // backward tail: what it reads of the layer below does not depend on this launch's products -- requested now by every workgroup
+  // (only the last arriver of a column block uses them: four small loads wasted elsewhere, one memory round trip saved in the tail)
+  float bt_zz[DL_ROWS / DL_SLICES], bt_mu = 0.f, bt_is = 1.f, bt_g = 1.f, bt_b = 0.f;
+  unsigned bt_kp = 0xfu;
+  if (TRANS && a.bt_dz) {
+#pragma unroll
+    for (int i = 0; i < DL_ROWS / DL_SLICES; ++i) bt_zz[i] = a.bt_z[(long long)min(s + DL_SLICES * i, a.R - 1) * a.C + jc];     // unconditional, clamped
+    if (a.bt_keep) {
+      bt_kp = 0u;
+#pragma unroll
+      for (int i = 0; i < DL_ROWS / DL_SLICES; ++i) bt_kp |= (a.bt_keep[(long long)min(s + DL_SLICES * i, a.R - 1) * a.C + jc] ? 1u : 0u) << i;
+    }
+    if (a.bt_mode) { bt_mu = a.bt_mean[jc]; bt_is = a.bt_invstd[jc]; bt_g = a.bt_gamma[jc]; bt_b = a.bt_beta[jc]; }
+  }
 
   // ---- products on the matrix cores -----------------------------------------------------------------------------------------
   // z tile (32 rows x 32 columns) = x (32 x k) . W (k x 32), one v_mfma_f32_32x32x16_bf16 triple per 16 k: both operands are split
@@ -265,23 +279,17 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a0, co
       }
     }
   }
-  if (a.bt_dz) {      // block-uniform; small (host-checked): zr[] holds this thread's four rows of d(activation)
-    float bsc = 1.f, bsh = 0.f, mu = 0.f, is = 1.f;
+  if (TRANS && a.bt_dz) {      // block-uniform; small (host-checked): zr[] holds this thread's four rows of d(activation)
+    float bsc = 1.f, bsh = 0.f;
+    const float mu = bt_mu, is = bt_is;
     if (a.bt_mode) {
-      mu = a.bt_mean[jc]; is = a.bt_invstd[jc];
-      bsc = a.bt_gamma[jc] * is;
-      bsh = a.bt_beta[jc] - mu * bsc;
+      bsc = bt_g * is;
+      bsh = bt_b - mu * bsc;
     }
     const float kscale = a.bt_keep ? a.bt_keep_scale : 1.f;
-    float v[DL_ROWS / RP], zh[DL_ROWS / RP], zz[DL_ROWS / RP];
-    unsigned kp = 0xfu;
-#pragma unroll
-    for (int i = 0; i < DL_ROWS / RP; ++i) zz[i] = a.bt_z[(long long)min(ty + RP * i, R - 1) * C + jc];     // unconditional, clamped
-    if (a.bt_keep) {
-      kp = 0u;
-#pragma unroll
-      for (int i = 0; i < DL_ROWS / RP; ++i) kp |= (a.bt_keep[(long long)min(ty + RP * i, R - 1) * C + jc] ? 1u : 0u) << i;
-    }
+    float v[DL_ROWS / RP], zh[DL_ROWS / RP];
+    const float (&zz)[DL_ROWS / DL_SLICES] = bt_zz;
+    const unsigned kp = bt_kp;
     float S1 = 0.f, S2 = 0.f;
 #pragma unroll
     for (int i = 0; i < DL_ROWS / RP; ++i) {

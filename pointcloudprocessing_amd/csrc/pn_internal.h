@@ -30,8 +30,8 @@ int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, i
 int weights_prep(const float* w, const float* sgn, int K, int C, void* hi, void* lo, hipStream_t st);
 int panel_slots_per_cloud(int B, int N);
 int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo, int B, int N, int K, int C, float* pmax, int* pq,
-                       float* sumsq, float* colsum, int prec, hipStream_t st);
-int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const float* colsum, const void* wf_hi, const void* wf_lo, int prec,
+                       float* sumsq, long long* colacc, int prec, hipStream_t st);
+int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const long long* colacc, const void* wf_hi, const void* wf_lo, int prec,
                    int B, int N, int K, int C, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps,
                    int use_batch, int update, float* mean, float* invstd, float* scale, float* shift, float* g, float* zstar, int* argq,
                    hipStream_t st);

@@ -130,7 +130,8 @@ struct CL {   // per-point conv layer state
   int C = 0, K = 0;
 };
 struct ML {   // extra state of a max-pooled layer
-  float *pmax, *sumsq, *pa1, *g, *zstar, *hs, *e, *nege, *f, *a1part, *a1, *gram, *GW, *Pm, *q, *D, *Wt, *We, *dG;
+  long long* pa1;
+  float *pmax, *sumsq, *g, *zstar, *hs, *e, *nege, *f, *a1part, *a1, *gram, *GW, *Pm, *q, *D, *Wt, *We, *dG;
   int *pq, *argq, *arg;            // per tile: 32-row block of the maximum; per cloud: the same after the reduction; the row (backward)
   unsigned short *wb_hi, *wb_lo;   // fragment-ordered bf16 copies of the kernel for the panel kernel (pn_panel.hip)
   int T64, tpc64, rows;   // panel tiles (all clouds / per cloud) and rows per panel
@@ -220,7 +221,7 @@ static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, 
   m.pmax = A.get<float>((n + ".pmax").c_str(), (size_t)B * cdiv(N, 64) * C);
   m.pq = A.get<int>((n + ".pq").c_str(), (size_t)B * cdiv(N, 64) * C);
   m.sumsq = A.get<float>((n + ".sumsq").c_str(), (size_t)B * cdiv(N, 64) * C);
-  m.pa1 = A.get<float>((n + ".colsum").c_str(), (size_t)B * cdiv(N, 64) * 2 * K);      // per slot: column sums of the staged rows (hi, lo)
+  m.pa1 = nullptr;                                 // per cloud: fixed-point column sums of the staged rows -- carved from the block the step's first launch clears (plan_ws)
   m.argq = A.get<int>((n + ".argq").c_str(), (size_t)B * C);
   m.wb_hi = A.get<unsigned short>((n + ".wb_hi").c_str(), (size_t)K * C);
   m.wb_lo = A.get<unsigned short>((n + ".wb_lo").c_str(), (size_t)K * C);
@@ -304,7 +305,17 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
   w.seg_part = A.get<float>("seg_part", (size_t)std::max<long long>(cdivll(M, seg_out_part_rows()), (long long)B * cdiv(N, seg_head_fused_rows())) *
                                             seg_out_part_stride());
   w.dense_part = A.get<float>("dense_part", (size_t)8 * B * 4096);          // split-K tiles of the dense layers (<= 8 splits)
-  w.dcount = A.get<unsigned>("dcount", DENSE_MAX_COUNTERS);                 // their in-launch arrival counters
+  // their in-launch arrival counters, followed by the three max-pooled layers' column-sum accumulators (B x 256 64-bit words each):
+  // ONE block, cleared by the step's first launch
+  w.dcount = A.get<unsigned>("dcount", DENSE_MAX_COUNTERS + 3 * (size_t)B * 512);
+  {
+    long long* acc = w.dcount ? reinterpret_cast<long long*>(w.dcount + DENSE_MAX_COUNTERS) : nullptr;
+    if (!d.vanilla) {
+      w.iT.m3.pa1 = acc;
+      w.fT.m3.pa1 = acc ? acc + (size_t)B * 256 : nullptr;
+    }
+    w.mm23.pa1 = acc ? acc + 2 * (size_t)B * 256 : nullptr;
+  }
   w.R3eye = A.get<float>("R3eye", (size_t)B * 9);
   w.regpart = A.get<float>("regpart", (size_t)2 * B);
   w.slab_floats = w.slab_main_floats = w.slab_pool_floats = 0;
@@ -588,7 +599,7 @@ struct Run {
       add_fz(w.s1, L.s1); add_fz(w.s2, L.s2); add_fz(w.s3, L.s3); add_fz(w.s4, L.s4);
       const bool zg = training && G && io.zero_grads_in_forward;
       const bool dm = training && io.dropout_step && io.keep1 && io.keep2 && d.dropout_rate > 0.f;
-      PN_TRY(fwd_prologue(io.pc, B, N, w.pcn, w.cent, w.scl, ws, sgs, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS, zg ? G : nullptr,
+      PN_TRY(fwd_prologue(io.pc, B, N, w.pcn, w.cent, w.scl, ws, sgs, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS + 3 * B * 512, zg ? G : nullptr,
                           zg ? L.total : 0, dm ? const_cast<unsigned char*>(io.keep1) : nullptr, dm ? (long long)B * 512 : 0,
                           dm ? const_cast<unsigned char*>(io.keep2) : nullptr, dm ? (long long)B * 256 : 0, d.dropout_rate, io.dropout_seed,
                           dm ? io.dropout_step : nullptr, wc, nwc, fz, nfz, d.bn_eps, st));

@@ -79,7 +79,8 @@ struct PanelArgs {
   float* pmax;                  // [B * spc][C]  max over the slot's rows of the accumulator (= sgn * z with presigned weights)
   int* pq;                      // [B * spc][C]  index inside the cloud of the 32-row block that held it (lowest on ties)
   float* sumsq;                 // [B * spc][C]  sum over the slot's rows of z^2, or NULL
-  float* colsum;                // [B * spc][NT * K]  column sums of the slot's staged operand rows (hi image, then lo), or NULL (comes with sumsq)
+  long long* colacc;            // [B][NT * K]  per cloud: column sums of the staged operand rows (hi image, then lo) in 2^-24 fixed point,
+                                //   ADDED to what is there (zero on entry), or NULL (comes with sumsq)
 };
 // PN_PANEL_DBG (timing ablations of the bf16, K = 128, statistics variant; WRONG results; tools/panel_probe.py): template bit mask DBG:
 // 1 no epilogue, 4 no activation loads, 8 no MFMAs; 16 (bf16 source only) the product kernel + shader-clock stamps in pq
@@ -492,11 +493,13 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
     }
   }
   stamp();                                           // maxima and sums of squares written
-  if (STATS && g.colsum) {
+  if (STATS && g.colacc) {
     // Column sums a1 = A^T 1 of the slot's staged rows, gathered from the eight waves (lanes l, l + CH, ... of a wave hold the same 8
-    // columns -> butterfly, one slot per (wave, column) in LDS, 8-way sum).  The finaliser turns them into the channel sums of z:
-    // sum over ALL rows of z[:, c] = (sum over the slots of a1) . W[:, c] -- K*C multiply-adds per LAUNCH.  (Round 2 formed a1 . W
-    // here, per slot: K*C multiply-adds per workgroup, 5,200 cycles of an 11,000-cycle run at N = 1024.)
+    // columns -> butterfly, one slot per (wave, column) in LDS, 8-way sum) and added to the CLOUD's accumulators as 64-bit fixed
+    // point (integer addition is associative: the sum does not depend on the order the cloud's workgroups arrive in).  The
+    // finaliser turns them into the channel sums of z: sum over ALL rows of z[:, c] = (sum over the clouds of a1) . W[:, c] -- K*C
+    // multiply-adds per LAUNCH.  (Round 2 formed a1 . W here, per slot: K*C multiply-adds per workgroup, 5,200 cycles of an
+    // 11,000-cycle run at N = 1024.)
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       for (int o = CH; o < 64; o <<= 1) {
@@ -516,7 +519,8 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
       float t = 0.f;
 #pragma unroll
       for (int w = 0; w < 8; ++w) t += red[w][col];
-      g.colsum[(long long)slot * (NT * K) + col] = t;
+      if (cg == 0)       // (bf16x3: the workgroups of the second column half staged the same rows)
+        __hip_atomic_fetch_add(&g.colacc[(long long)cloud * (NT * K) + col], __float2ll_rn(t * 16777216.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
   if constexpr ((DBG & 16) != 0) {
@@ -567,14 +571,14 @@ static void launch_panel_cbw(const PanelArgs& g, int C, bool stats, hipStream_t 
 }
 
 int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo, int B, int N, int K, int C, float* pmax, int* pq,
-                       float* sumsq, float* colsum, int prec, hipStream_t st) {
+                       float* sumsq, long long* colacc, int prec, hipStream_t st) {
   PN_CHECK_ARG(x && x->s1 && !x->s2, "pn_conv_fwd_max_panel: bad operand");
   PN_CHECK_ARG((reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && x->ld % 4 == 0 && x->ld >= K, "pn_conv_fwd_max_panel: operand alignment");
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_fwd_max_panel: B and N must be positive");
   PN_CHECK_ARG(K == 64 || K == 128, "pn_conv_fwd_max_panel: K must be 64 or 128 (K=%d)", K);
   PN_CHECK_ARG(C >= 256 && C % 256 == 0 && (C / 256 == 1 || C / 256 == 2 || C % 1024 == 0), "pn_conv_fwd_max_panel: C must be 256, 512 or a multiple of 1024 (C=%d)", C);
   PN_CHECK_ARG(wf_hi && pmax && pq, "pn_conv_fwd_max_panel: null pointer");
-  PN_CHECK_ARG((sumsq == nullptr) == (colsum == nullptr), "pn_conv_fwd_max_panel: sumsq and colsum come together (both or neither)");
+  PN_CHECK_ARG((sumsq == nullptr) == (colacc == nullptr), "pn_conv_fwd_max_panel: sumsq and colacc come together (both or neither)");
   prec &= ~PN_STORE_BF16;
   PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && wf_lo), "pn_conv_fwd_max_panel: bad prec / missing lo weights");
   PN_CHECK_ARG(x->h16 == 0 || (x->h16 == 1 && prec == PN_PREC_BF16 && x->ld % 8 == 0),
@@ -584,7 +588,7 @@ int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo
   g.a = *x; g.wf_hi = reinterpret_cast<const __bf16*>(wf_hi); g.wf_lo = reinterpret_cast<const __bf16*>(wf_lo);
   g.B = B; g.N = N; g.C = C;
   g.spc = panel_slots_per_cloud(B, N);
-  g.pmax = pmax; g.pq = pq; g.sumsq = sumsq; g.colsum = colsum;
+  g.pmax = pmax; g.pq = pq; g.sumsq = sumsq; g.colacc = colacc;
   const bool st_ = sumsq != nullptr;
   if (prec == PN_PREC_BF16X3) {
     if (K == 128) launch_panel_cbw<3, 128>(g, C, st_, st);
@@ -606,7 +610,7 @@ int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo
 // moving statistics (inference / frozen layer, PointNet.py:585-591).  Then per cloud: the largest pmax over its slots (lowest slot on
 // ties: rows ascend with the slot index), zstar = s_c * max, g = relu(scale * zstar + shift), and the 32-row block that holds the row.
 struct PanelFinArgs {
-  const float* pmax; const int* pq; const float* sumsq; const float* colsum;
+  const float* pmax; const int* pq; const float* sumsq; const long long* colacc;
   const unsigned short *wf_hi, *wf_lo;      // fragment-ordered kernel copies (pn_weights_prep); wf_lo for bf16x3
   int T, tpc, B, C, K, NT, n_blocks32;
   double inv_count;
@@ -620,72 +624,95 @@ constexpr int PANEL_FIN_MAXK = 128;
 __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs a) {
   __shared__ double red[8][2][32];
   __shared__ double A1[2 * PANEL_FIN_MAXK];
-  __shared__ double A1part[8 * PANEL_FIN_MAXK];      // [group][column]: 8 groups x 128 columns, or 4 x 256
+  __shared__ long long A1part[2 * PANEL_FIN_MAXK];   // [group][column]: 256 entries whatever the split
   __shared__ float sc_s[32], sh_s[32], sg_s[32];
   const int tid = threadIdx.x, cl = tid & 31, part = tid >> 5;
   const int c = blockIdx.x * 32 + cl;
   const float gam = a.gamma[c];
   const float sg = gam < 0.f ? -1.f : 1.f;
+  // the first cloud's slot maxima of this thread: requested now, used after the statistics
+  const int b0 = blockIdx.y * 8 + part;
+  float pre_v[8];
+  int pre_q[8];
+  {
+    const long long base0 = (long long)(b0 < a.B ? b0 : 0) * a.tpc * a.C + c;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int t = min(u, a.tpc - 1);
+      pre_v[u] = a.pmax[base0 + (long long)t * a.C];
+      pre_q[u] = a.pq[base0 + (long long)t * a.C];
+    }
+  }
   if (a.use_batch) {
-    // A1[col] = sum over the slots of colsum[slot][col]: thread <-> (four columns, every `groups`-th slot), sixteen 16-byte loads in
-    // flight; the groups' partial sums meet in LDS and are added in group order (fixed order: reproducible)
-    const int ncol = a.NT * a.K, nq = ncol >> 2, groups = 256 / nq;
+    double s1 = 0.0, s2 = 0.0;
+    // Everything the launch reads is requested up front -- the kernel fragments of this thread's k-step, the clouds' column-sum
+    // accumulators (thread <-> column, every `groups`-th cloud) and the slots' sums of squares (thread <-> channel, every 8th slot, 32
+    // deep): ONE round trip to memory for T <= 256 slots (the per-cloud maxima further down are requested above: pre_v / pre_q)
+    const int ncol = a.NT * a.K, groups = 256 / ncol;
+    const int KS = a.K / 16;
+    const long long cb = c >> 5;
+    const int ksw = part < KS ? part : KS - 1;            // (k-steps beyond the first eight: loaded in the loop below)
+    uint4 wraw[2][2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const long long fo = ((cb * KS + ksw) * 64 + hh * 32 + cl) * 8;
+      wraw[hh][0] = *reinterpret_cast<const uint4*>(a.wf_hi + fo);
+      wraw[hh][1] = a.NT == 2 ? *reinterpret_cast<const uint4*>(a.wf_lo + fo) : make_uint4(0, 0, 0, 0);
+    }
     {
-      const int cq = tid % nq, gi = tid / nq;
-      double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
-      for (int p = gi; p < a.T; p += groups * 16) {
-        float4 v[16];
+      // A1[col] = sum over the clouds of colacc[cloud][col]: 64-bit integers (exact, order-free); the groups' partial sums meet in LDS
+      const int col = tid % ncol, gi = tid / ncol;
+      long long ta = 0;
+      double s2a = 0.0;
+      for (int pc = gi, ps = part; pc < a.B || ps < a.T; pc += groups * 16, ps += 8 * 32) {
+        long long v[16];
+        float q[32];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
-          const int pp = p + u * groups;
-          v[u] = *reinterpret_cast<const float4*>(a.colsum + (long long)(pp < a.T ? pp : p) * ncol + 4 * cq);
+          const int pp = pc + u * groups;
+          v[u] = a.colacc[(long long)(pp < a.B ? pp : 0) * ncol + col];
+        }
+#pragma unroll
+        for (int u = 0; u < 32; ++u) {
+          const int pp = ps + u * 8;
+          q[u] = a.sumsq[(long long)(pp < a.T ? pp : 0) * a.C + c];
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u)
-          if (p + u * groups < a.T) { t0 += (double)v[u].x; t1 += (double)v[u].y; t2 += (double)v[u].z; t3 += (double)v[u].w; }
-      }
-      double* dst = &A1part[gi * ncol + 4 * cq];
-      dst[0] = t0; dst[1] = t1; dst[2] = t2; dst[3] = t3;
-    }
-    // thread <-> (channel, every 8th slot): sixteen slots in flight, summed in slot order
-    double s1 = 0.0, s2 = 0.0;
-    for (int p = part; p < a.T; p += 8 * 16) {
-      float q[16];
+          if (pc + u * groups < a.B) ta += v[u];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        const int pp = p + u * 8;
-        q[u] = a.sumsq[(long long)(pp < a.T ? pp : p) * a.C + c];
+        for (int u = 0; u < 32; ++u)
+          if (ps + u * 8 < a.T) s2a += (double)q[u];
       }
-#pragma unroll
-      for (int u = 0; u < 16; ++u)
-        if (p + u * 8 < a.T) s2 += (double)q[u];
+      A1part[gi * ncol + col] = ta;
+      s2 = s2a;
     }
     __syncthreads();
     if (tid < ncol) {
-      double t = 0.0;
+      long long t = 0;
       for (int q = 0; q < groups; ++q) t += A1part[q * ncol + tid];
-      A1[tid] = t;
+      A1[tid] = (double)t * (1.0 / 16777216.0);
     }
     __syncthreads();
     // sum z = A1 . W[:, c]: thread (channel, part) takes the k-steps part, part + 8, ... of its column: the sixteen k of a step are the
     // two 16-byte fragments of lanes (c % 32) and (c % 32) + 32
-    {
-      const int KS = a.K / 16;
-      const long long cb = c >> 5;
-      for (int ks = part; ks < KS; ks += 8) {
+    for (int ks = part; ks < KS; ks += 8) {
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
+      for (int hh = 0; hh < 2; ++hh) {
+        uint4 wh = wraw[hh][0], wl = wraw[hh][1];
+        if (ks != ksw) {
           const long long fo = ((cb * KS + ks) * 64 + hh * 32 + cl) * 8;
-          const uint4 wh = *reinterpret_cast<const uint4*>(a.wf_hi + fo);
-          float whf[8], wlf[8];
-          bf16x8_unpack(wh, whf);
-          if (a.NT == 2) bf16x8_unpack(*reinterpret_cast<const uint4*>(a.wf_lo + fo), wlf);
+          wh = *reinterpret_cast<const uint4*>(a.wf_hi + fo);
+          if (a.NT == 2) wl = *reinterpret_cast<const uint4*>(a.wf_lo + fo);
+        }
+        float whf[8], wlf[8];
+        bf16x8_unpack(wh, whf);
+        bf16x8_unpack(wl, wlf);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const int k = ks * 16 + hh * 8 + e;
-            s1 += A1[k] * (double)whf[e];
-            if (a.NT == 2) s1 += A1[a.K + k] * (double)whf[e] + A1[k] * (double)wlf[e];
-          }
+        for (int e = 0; e < 8; ++e) {
+          const int k = ks * 16 + hh * 8 + e;
+          s1 += A1[k] * (double)whf[e];
+          if (a.NT == 2) s1 += A1[a.K + k] * (double)whf[e] + A1[k] * (double)wlf[e];
         }
       }
     }
@@ -729,11 +756,16 @@ __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs 
     for (int t0 = 0; t0 < a.tpc; t0 += 8) {
       float v[8];
       int q[8];
+      if (b == b0 && t0 == 0) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int t = min(t0 + u, a.tpc - 1);
-        v[u] = a.pmax[base + (long long)t * a.C];
-        q[u] = a.pq[base + (long long)t * a.C];
+        for (int u = 0; u < 8; ++u) { v[u] = pre_v[u]; q[u] = pre_q[u]; }
+      } else {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int t = min(t0 + u, a.tpc - 1);
+          v[u] = a.pmax[base + (long long)t * a.C];
+          q[u] = a.pq[base + (long long)t * a.C];
+        }
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u)
@@ -747,19 +779,19 @@ __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs 
   }
 }
 
-int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const float* colsum, const void* wf_hi, const void* wf_lo, int prec,
+int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const long long* colacc, const void* wf_hi, const void* wf_lo, int prec,
                    int B, int N, int K, int C, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps,
                    int use_batch, int update, float* mean, float* invstd, float* scale, float* shift, float* g, float* zstar, int* argq,
                    hipStream_t st) {
   PN_CHECK_ARG(pmax && pq && gamma && beta && mm && mv && mean && invstd && scale && shift && g, "pn_panel_finalize: null pointer");
   prec &= ~PN_STORE_BF16;
-  PN_CHECK_ARG(!use_batch || (sumsq && colsum && wf_hi && (prec != PN_PREC_BF16X3 || wf_lo)),
-               "pn_panel_finalize: batch statistics need sumsq, colsum and the kernel copies");
+  PN_CHECK_ARG(!use_batch || (sumsq && colacc && wf_hi && (prec != PN_PREC_BF16X3 || wf_lo)),
+               "pn_panel_finalize: batch statistics need sumsq, colacc and the kernel copies");
   PN_CHECK_ARG(B > 0 && N > 0 && C > 0 && C % 32 == 0, "pn_panel_finalize: bad sizes");
   PN_CHECK_ARG(!use_batch || ((K == 64 || K == 128) && (prec == PN_PREC_BF16 || prec == PN_PREC_BF16X3)), "pn_panel_finalize: K must be 64 or 128 (K=%d), prec bf16 or bf16x3", K);
   PanelFinArgs a;
   memset(&a, 0, sizeof(a));
-  a.pmax = pmax; a.pq = pq; a.sumsq = sumsq; a.colsum = colsum;
+  a.pmax = pmax; a.pq = pq; a.sumsq = sumsq; a.colacc = colacc;
   a.wf_hi = reinterpret_cast<const unsigned short*>(wf_hi); a.wf_lo = reinterpret_cast<const unsigned short*>(wf_lo);
   a.K = K; a.NT = prec == PN_PREC_BF16X3 ? 2 : 1;
   a.tpc = panel_slots_per_cloud(B, N); a.T = B * a.tpc; a.B = B; a.C = C;

@@ -78,14 +78,14 @@ def weights_prep(w, sgn=None):
 
 def conv_fwd_max_panel(x_op, wf, B, N, K, C_, prec, want_stats=True):
     """the row-panel kernel: per slot (run of 64-row panels) and channel max of sgn*z, the 32-row block holding it and (want_stats)
-    sum z^2, and per slot the column sums of the staged operand rows (panel_finalize turns those into the channel sums of z).
+    sum z^2, and per cloud the column sums of the staged operand rows in 2^-24 fixed point (panel_finalize turns those into the channel sums of z).
     wf = weights_prep(w, gamma)."""
     dev = wf[0].device
     T = B * lib().pn_panel_slots_per_cloud(B, N)
     pmax = torch.empty(T, C_, device=dev, dtype=F32)
     pblk = torch.empty(T, C_, device=dev, dtype=torch.int32)
     sumsq = torch.empty(T, C_, device=dev, dtype=F32) if want_stats else None
-    colsum = torch.empty(T, (2 if (prec & 3) == 3 else 1) * K, device=dev, dtype=F32) if want_stats else None
+    colsum = torch.zeros(B, (2 if (prec & 3) == 3 else 1) * K, device=dev, dtype=torch.int64) if want_stats else None      # accumulators: zero on entry
     check(lib().pn_conv_fwd_max_panel(C.byref(x_op), ptr(wf[0]), ptr(wf[1]), B, N, K, C_, ptr(pmax), ptr(pblk), ptr(sumsq), ptr(colsum), prec,
                                       current_stream()), "pn_conv_fwd_max_panel")
     return pmax, pblk, sumsq, colsum
