@@ -123,11 +123,11 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
   const int r = lane & 31, h = lane >> 5;
   const int slot = blockIdx.x, cg = blockIdx.y;
   // DBG & 16: shader-clock stamps of wave 0 at the kernel's phase boundaries, left in the slot's pq row (tools/panel_probe.py)
-  __shared__ unsigned stamps[(DBG & 16) ? 32 : 1];
+  __shared__ unsigned stamps[(DBG & 16) ? 2 : 1][(DBG & 16) ? 64 : 1];      // [wave 0, wave 4][stamp]
   int n_stamp = 0;
   auto stamp = [&]() {
     if constexpr ((DBG & 16) != 0) {
-      if (tid == 0 && n_stamp < 32) stamps[n_stamp] = (unsigned)__builtin_amdgcn_s_memtime();
+      if ((tid == 0 || tid == 256) && n_stamp < 64) stamps[tid >> 8][n_stamp] = (unsigned)__builtin_amdgcn_s_memtime();
       ++n_stamp;
     }
   };
@@ -354,12 +354,16 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
           // (Tried and dropped: the panel's barrier in front of its last chain, whose gaps then request the next panel's first A
           // fragments -- the fragments become live across the panel boundary, 32 registers the kernel does not have: spills in the loop.)
           if (t == T_A) {
+            stamp();                                   // (panel) chains 0 .. T_A - 1 issued
             if ((NB < 4 || wave < 4) && pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
+            stamp();                                   // first group's conversion done
           }
           if (NB >= 4 && t == T_B) {
+            stamp();                                   // chains up to T_B - 1 issued
             if (wave >= 4 && pnl + 1 < p_end) convert(pnl + 1, buf ^ 1);
             __builtin_amdgcn_sched_barrier(0);
+            stamp();                                   // second group's conversion done
           }
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int u = 0; u < 7; ++u) unit(u, acc2[(NB - 1) & 1], (NB - 1) % CBW, pnl * 2 + 1);
+        stamp();                                       // last chain and its epilogue done
         __syncthreads();
         stamp();                                       // 4..: a panel done
         return;
@@ -526,8 +531,8 @@ __global__ __launch_bounds__(512) void panel_max_kernel(const PanelArgs g) {
   if constexpr ((DBG & 16) != 0) {
     stamp();                                         // end
     __syncthreads();
-    if (tid < 32) g.pq[(long long)slot * g.C + tid] = tid < n_stamp ? (int)stamps[tid] : 0;
-    if (tid == 32) g.pq[(long long)slot * g.C + 32] = n_stamp;
+    if (tid < 128) g.pq[(long long)slot * g.C + 1 + tid] = (tid & 63) < n_stamp ? (int)stamps[tid >> 6][tid & 63] : 0;
+    if (tid == 0) g.pq[(long long)slot * g.C] = n_stamp;
   }
 }
 

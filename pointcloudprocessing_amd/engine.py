@@ -98,15 +98,16 @@ class TrainStep:
         finally:
             self.model._aux_stream = None
 
-    def _reduce_async(self, lo, hi):
+    def _reduce_async(self, lo, hi, last=False):
         """RCCL sum over xGMI of one gradient bucket; runs on RCCL's stream behind everything enqueued so far"""
         if not self.reduce:
             return None
         if not self.overlap:
-            if lo != 0:
-                return None                                   # single collective: issued with the second bucket (lo == 0), even an empty one
+            if not last:
+                return None                                   # single collective: issued with the second (last) bucket, even an empty one
             # a synchronous collective: recent PyTorch runs it on the CURRENT stream (no cross-stream fence at all)
-            self.dist.all_reduce(self.model.grads_flat)
+            a, _, b = self._buckets()
+            self.dist.all_reduce(self.model.grads_flat[a:b] if b > a else self.model.grads_flat)
             return None
         if hi <= lo:
             return None
@@ -125,18 +126,33 @@ class TrainStep:
             for h in live:
                 h.wait()
 
+    def _buckets(self):
+        """(lo, cut, hi): bucket 1 = [cut, hi) is final after backward phase 1, bucket 2 = [lo, cut) after phase 2; [lo, hi) = the
+        extent of the trainable blocks' gradients (frozen blocks outside it carry zeros on every rank: not reduced, not stepped)"""
+        n = self.model.grads_flat.numel()
+        lo, hi = self.model.grad_extent() if hasattr(self.model, "grad_extent") else (0, n)
+        cut = min(max(self.model.grad_bucket_boundary(), lo), hi)
+        return lo, cut, hi
+
+    def _opt_step(self, scale):
+        lo, _, hi = self._buckets()
+        if (lo, hi) == (0, self.model.grads_flat.numel()) or hi <= lo:
+            self.opt.step(self.model.grads_flat, scale)
+        else:
+            self.opt.step(self.model.grads_flat, scale, lo, hi)
+
     def _eager(self):
         if not self.split:
             self._fwd_bwd()
         else:
             # bucket 1 (feature transform .. heads, ~80 % of the bytes) is reduced while mlp_1 / the input transform run backward
-            cut, end = self.model.grad_bucket_boundary(), self.model.grads_flat.numel()
+            lo, cut, end = self._buckets()
             self._fwd_bwd(1)
             h1 = self._reduce_async(cut, end)
             self._bwd2()
-            h2 = self._reduce_async(0, cut)
+            h2 = self._reduce_async(lo, cut, last=True)
             self._wait_last(h1, h2)
-        self.opt.step(self.model.grads_flat, 1.0 / self.world)
+        self._opt_step(1.0 / self.world)
 
     def _capture(self):
         # capture_error_mode="thread_local": RCCL's watchdog thread polls its work events with hipEventQuery all the time; under the
@@ -156,7 +172,7 @@ class TrainStep:
             with torch.cuda.graph(g1, stream=self._capture_stream, capture_error_mode="thread_local"):
                 self._fwd_bwd(1 if self.split else 0)
                 if not self.split:
-                    self.opt.step(self.model.grads_flat, 1.0)
+                    self._opt_step(1.0)
             g1b = g2 = None
             if self.split:
                 g1b = torch.cuda.CUDAGraph()
@@ -164,7 +180,7 @@ class TrainStep:
                     self._bwd2()
                 g2 = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g2, stream=self._capture_stream, capture_error_mode="thread_local"):
-                    self.opt.step(self.model.grads_flat, 1.0 / self.world)
+                    self._opt_step(1.0 / self.world)
             torch.cuda.synchronize()
             self._g1, self._g1b, self._g2, self.mode = g1, g1b, g2, "hipgraph"
         except Exception as e:                                  # capture unsupported: stay eager (a speed matter only)
@@ -219,10 +235,10 @@ class TrainStep:
             else:
                 self._g1.replay()
                 if self.split:
-                    cut, end = self.model.grad_bucket_boundary(), self.model.grads_flat.numel()
+                    lo, cut, end = self._buckets()
                     h1 = self._reduce_async(cut, end)           # overlaps graph 1b
                     self._g1b.replay()
-                    h2 = self._reduce_async(0, cut)
+                    h2 = self._reduce_async(lo, cut, last=True)
                     self._wait_last(h1, h2)
                     self._g2.replay()
         self._exit()

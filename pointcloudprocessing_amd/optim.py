@@ -34,7 +34,15 @@ class KerasAdam:
         self.m.copy_(state["m"]); self.v.copy_(state["v"]); self.iterations.copy_(state["iterations"])
         self.prepare()
 
-    def step(self, grads_flat: torch.Tensor, grad_scale: float = 1.0):
+    def step(self, grads_flat: torch.Tensor, grad_scale: float = 1.0, lo: int = 0, hi: int = None):
+        """one Adam step over the flat range [lo, hi) (default: everything).  A caller restricts the range to the extent of the
+        trainable blocks (PointNet.grad_extent): elements with zero gradient and zero moments do not move"""
+        if lo or (hi is not None and hi != self.params.numel()):
+            p, g, m, v = self.params[lo:hi], grads_flat[lo:hi], self.m[lo:hi], self.v[lo:hi]
+            check(lib().pn_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(self.iterations), ptr(self._alpha), self.lr0,
+                                     self.decay_rate, self.decay_steps, self.beta_1, self.beta_2, self.epsilon, float(grad_scale),
+                                     current_stream()), "pn_adam_step")
+            return
         check(lib().pn_adam_step(ptr(self.params), ptr(grads_flat), ptr(self.m), ptr(self.v), self.params.numel(),
                                  ptr(self.iterations), ptr(self._alpha), self.lr0, self.decay_rate, self.decay_steps, self.beta_1,
                                  self.beta_2, self.epsilon, float(grad_scale), current_stream()), "pn_adam_step")

@@ -763,6 +763,22 @@ class PointNet(torch.nn.Module):
         cls, seg, R = self._run_forward(pc, False, None)
         return ops.argmax_rows(cls), ops.argmax_rows(seg), R
 
+    def grad_extent(self):
+        """(lo, hi): the smallest range of ``grads_flat`` (floats) that holds every gradient of a trainable block.  Outside it the
+        gradient is identically zero on every rank and every step (frozen blocks, PointNet.py:294-349): the data-parallel all-reduce
+        and the optimizer skip it -- with fresh optimizer state (the trainer builds one per profile stage, pointnet_train.py:310-319)
+        Adam's update of a zero-gradient element is exactly zero, so nothing changes but the bytes moved."""
+        flags = self._block_flags()
+        lo, hi = None, 0
+        for s in self._weights.slots.values():
+            if s["kind"] not in (3, 4) and flags[s["block"]]:
+                o, e = int(s["offset"]), int(s["offset"]) + int(s["rows"]) * int(s["cols"])
+                lo = o if lo is None else min(lo, o)
+                hi = max(hi, e)
+        if lo is None:
+            return 0, 0
+        return lo, (hi + 63) // 64 * 64 if (hi + 63) // 64 * 64 <= self.grads_flat.numel() else hi
+
     def grad_bucket_boundary(self) -> int:
         """offset (floats) in ``grads_flat`` from which every slot is final after backward phase 1"""
         for n, s in self._weights.slots.items():

@@ -291,39 +291,56 @@ SCHEDULE_SCRIPT = textwrap.dedent("""
     class StubModel:
         '''stands in for PointNet on host memory: the backward phases fill known, rank-dependent gradients into the flat buffer,
         exactly where pn_model_backward's phases leave theirs (phase 1: [cut, end), phase 2: [0, cut))'''
-        def __init__(self):
+        def __init__(self, extent=None):
             self.params_flat = torch.zeros(N_PARAMS)
             self.grads_flat = torch.zeros(N_PARAMS)
             self._dropout_rate = 0.0
             self._aux_stream = None
             self.calls = []
+            if extent is not None:                         # frozen blocks outside [lo, hi): zero gradients on every rank (PointNet.grad_extent)
+                self.grad_extent = lambda: extent
+            self.lo, self.hi = extent if extent is not None else (0, N_PARAMS)
         def grad_bucket_boundary(self):
             return CUT
+        def _fill(self, a, b):
+            a, b = max(a, self.lo), min(b, self.hi)
+            self.grads_flat[a:b] = base[a:b] * (rank + 1)
         def fused_loss_step(self, pc, y_cls, y_seg, se3, lw, keep=None, backward_phase=0, dropout_rng=None):
             self.calls.append(("fwd+bwd", backward_phase))
             self.grads_flat.fill_(float("nan"))            # anything the schedule forgets to produce or reduce stays visible
-            self.grads_flat[CUT:] = base[CUT:] * (rank + 1)
+            self.grads_flat[:self.lo] = 0.0
+            self.grads_flat[self.hi:] = 0.0
+            self._fill(CUT, N_PARAMS)
             if backward_phase == 0:
-                self.grads_flat[:CUT] = base[:CUT] * (rank + 1)
+                self._fill(0, CUT)
         def _run_backward(self, a, b, c, phase):
             self.calls.append(("bwd", phase))
-            self.grads_flat[:CUT] = base[:CUT] * (rank + 1)
+            self._fill(0, CUT)
 
     class StubAdam:
         def __init__(self):
             self.seen = []
-        def step(self, grads, scale=1.0):
-            self.seen.append((grads * scale).clone())
+        def step(self, grads, scale=1.0, lo=0, hi=None):
+            g = torch.zeros_like(grads)                    # what an optimizer restricted to [lo, hi) sees; the rest does not move
+            g[lo:hi] = grads[lo:hi] * scale
+            self.seen.append(g)
+            self.ranges = getattr(self, "ranges", []) + [(lo, hi)]
 
     out = {{}}
-    for overlap in ("1", "0"):
-        os.environ["PN_DDP_OVERLAP"] = overlap
-        m, opt = StubModel(), StubAdam()
+    for overlap in ("1", "0", "1x", "0x"):               # x: only [37, 3001) belongs to trainable blocks
+        os.environ["PN_DDP_OVERLAP"] = overlap[0]
+        extent = (37, 3001) if overlap.endswith("x") else None
+        m, opt = StubModel(extent), StubAdam()
         ts = TrainStep(m, opt, 2, 8, (1.0, 0.0, 0.0), use_graph=True)        # graphs are a GPU matter: a host model runs the bare sequence
         assert ts.split and ts.reduce and ts.world == world and ts.mode == "eager"
         for _ in range(3):
             ts.run()
         want = base * sum(r + 1 for r in range(world)) / world               # the mean over ranks: sum all-reduce, then 1/world in Adam
+        if extent is not None:
+            want = want.clone()
+            want[:extent[0]] = 0.0
+            want[extent[1]:] = 0.0
+            assert all(r == extent for r in opt.ranges), opt.ranges
         ok_value = all(torch.allclose(g, want, rtol=1e-6, atol=0) for g in opt.seen) and len(opt.seen) == 3
         both = [torch.zeros(N_PARAMS) for _ in range(world)]
         dist.all_gather(both, opt.seen[-1])
@@ -340,7 +357,8 @@ def test_product_bucket_schedule_world_size_2_gloo(tmp_path):
     """engine.TrainStep's own step sequence -- backward phase 1, all-reduce of the bucket [cut, end) issued asynchronously, backward
     phase 2, all-reduce of [0, cut), wait, Adam with grad_scale = 1/world (and the single synchronous collective of PN_DDP_OVERLAP=0)
     -- run by two gloo ranks on a host-memory stand-in model whose phases fill known per-rank gradients: every element of what Adam
-    receives is the mean over ranks and is bit-identical on both ranks."""
+    receives is the mean over ranks and is bit-identical on both ranks.  The "x" cases restrict both buckets and the optimizer to the
+    extent of the trainable blocks (PointNet.grad_extent): what lies outside is zero on every rank and is neither reduced nor stepped."""
     out = str(tmp_path / "sched.json")
     script = str(tmp_path / "sched.py")
     open(script, "w").write(SCHEDULE_SCRIPT.format(root=ROOT, out=out))
@@ -349,5 +367,5 @@ def test_product_bucket_schedule_world_size_2_gloo(tmp_path):
                         "--master-port", "29533", script], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     res = json.load(open(out))
-    for overlap in ("1", "0"):
+    for overlap in ("1", "0", "1x", "0x"):
         assert res[overlap] == {"value": True, "identical": True, "order": True, "n_calls": 6}, (overlap, res)

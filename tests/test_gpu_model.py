@@ -325,7 +325,9 @@ def test_forward_prologue_draws_masks_and_clears_gradients(dev):
 
 
 @pytest.mark.parametrize("vanilla", [False, True])
-@pytest.mark.parametrize("B,N", [(4, 300), (32, 1024)])
+# (32, 1024), (40, 840), (64, 576): enough tiles for the 128-row form of the kernel (pn_segout.hip: seg_head_fused) -- whole tiles, a ragged
+# last tile with rows in both 64-row halves, a last tile whose second half is empty
+@pytest.mark.parametrize("B,N", [(4, 300), (32, 1024), (40, 840), (64, 576)])
 def test_fused_frozen_segmentation_head_equals_layer_by_layer(dev, vanilla, B, N):
     """A segmentation head that normalises with moving statistics and gets no gradient (inference; `classification_pretrain`) runs as
     ONE launch with its activations kept on chip (pn_segout.hip: seg_head_fused).  It must reproduce the layer-by-layer plan bit for
