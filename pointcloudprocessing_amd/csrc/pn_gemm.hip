@@ -22,7 +22,6 @@
 //   C/D register g (0..15)      = D[row (g&3) + 8*(g>>2) + 4h][col r]
 #include <vector>
 #include "pn_common.h"
-#include "pn_bntail.h"
 #include "pn_internal.h"
 
 namespace pn {
@@ -53,7 +52,6 @@ struct GemmArgs {
   const float* msc;         // mask scale/shift per channel
   const float* msh;
   float* stat_partials;     // [tiles][2][C] (optional)
-  BnTail tail;              // STORE, forward: the layer's BatchNormalization statistics finished by this launch (pn_bntail.h); acc NULL: off
   const float* sgn;         // MAX
   float* pmax;              // MAX [tiles][C]
   int* pidx;                // MAX [tiles][C]
@@ -653,7 +651,7 @@ __device__ __forceinline__ void rows_tile_t(const GemmArgs& g, const int bx, con
       s1[n] = a1 + __shfl_xor(a1, 32, 64);
       s2[n] = a2 + __shfl_xor(a2, 32, 64);
     }
-    if ((g.stat_partials || g.tail.acc) && !(g.dbg & 2)) {
+    if (g.stat_partials && !(g.dbg & 2)) {
       if (h == 0) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
@@ -664,17 +662,9 @@ __device__ __forceinline__ void rows_tile_t(const GemmArgs& g, const int bx, con
       }
       __syncthreads();
       if (tid < BN && col0 + tid < g.C) {
-        const float t1 = red[0 * BN + tid] + red[2 * BN + tid], t2 = red[1 * BN + tid] + red[3 * BN + tid];
-        if (g.stat_partials) {
-          float* p = g.stat_partials + (long long)bx * 2 * g.C + col0 + tid;
-          p[0] = t1;
-          p[g.C] = t2;
-        }
-        if (g.tail.acc) bn_tail_add(g.tail, (int)blockIdx.x, col0 + tid, t1, t2);
-      }
-      if (g.tail.acc) {                                 // block-uniform
-        __syncthreads();                                // `red` is read above; its first word becomes the meeting's flag
-        bn_tail_meet(g.tail, tid, 256, reinterpret_cast<unsigned*>(red));
+        float* p = g.stat_partials + (long long)bx * 2 * g.C + col0 + tid;
+        p[0] = red[0 * BN + tid] + red[2 * BN + tid];
+        p[g.C] = red[1 * BN + tid] + red[3 * BN + tid];
       }
     }
   } else if (EPI == EPI_MAX) {
@@ -784,9 +774,7 @@ __global__ __launch_bounds__(256, (MODE == MODE_FWD && EPI == EPI_STORE) ? 2 : 1
 
 // ---- host-side dispatch ----------------------------------------------------------------------------------
 template <int BM, int BN, int NS, int MODE, bool A2, bool B2, int EPI, bool ADD = false, bool MASK = false>
-static int launch(const GemmArgs& g_in, dim3 grid, hipStream_t st) {
-  GemmArgs g = g_in;
-  g.tail.n_wg = (int)grid.x;                           // every workgroup of the launch draws a ticket (pn_bntail.h)
+static int launch(const GemmArgs& g, dim3 grid, hipStream_t st) {
   hipLaunchKernelGGL((gemm_kernel<BM, BN, NS, MODE, A2, B2, EPI, ADD, MASK>), grid, dim3(256), 0, st, g);
   PN_CHECK_LAUNCH();
   return PN_OK;
@@ -839,7 +827,7 @@ static int dispatch_bwd(const GemmArgs& g, int prec, hipStream_t st) {
 }
 
 int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, int K, int C, const float* cloud_bias,
-             float* z, float* stat_partials, int prec, hipStream_t st, const void* w16, const BnTail* tail) {
+             float* z, float* stat_partials, int prec, hipStream_t st, const void* w16) {
   PN_TRY(check_operand(x, "pn_conv_fwd.x"));
   PN_CHECK_ARG(!x->s2, "pn_conv_fwd: the forward operand has no second source");
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_fwd: B and N must be positive (B=%d N=%d)", B, N);
@@ -856,7 +844,6 @@ int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, i
   g.a = *x; g.w = w; g.w_cloud_stride = wcs; g.B = B; g.N = N; g.K = K; g.C = C;
   g.tiles_per_cloud = cdiv(N, 128);
   g.out = z; g.cloud_bias = cloud_bias; g.stat_partials = stat_partials;
-  if (tail) g.tail = *tail;                            // n_wg is filled in where the grid is known (dispatch_rows)
   if (w16 && wcs == 0 && prec == PN_PREC_BF16 && x->h16 && (reinterpret_cast<uintptr_t>(w16) & 15) == 0 && K % 8 == 0)
     g.w16 = reinterpret_cast<const unsigned short*>(w16);
   static const int dbg = getenv("PN_GEMM_DBG") ? atoi(getenv("PN_GEMM_DBG")) : 0;

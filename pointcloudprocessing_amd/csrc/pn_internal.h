@@ -7,9 +7,8 @@ namespace pn {
 // pn_gemm.hip
 // w16 (optional; used with bf16 operands, bf16 activations and a shared kernel): a bf16 copy of the kernel laid out [C][K] with k
 // contiguous -- for conv_fwd the TRANSPOSED kernel, for conv_bwd_data the kernel as it is -- staged without conversion (pn_prologue.hip)
-struct BnTail;    // pn_bntail.h
 int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, int K, int C, const float* cloud_bias, float* z,
-             float* stat_partials, int prec, hipStream_t st, const void* w16 = nullptr, const BnTail* tail = nullptr);
+             float* stat_partials, int prec, hipStream_t st, const void* w16 = nullptr);
 int conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C, const float* sgn, float* pmax, int* pidx,
                  float* stat_partials, int prec, hipStream_t st);
 int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, int N, int K, int C, const float* addend,
@@ -65,7 +64,7 @@ int fwd_prologue(const float* xyz, int B, int N, float* out, float* centroid, fl
 // Rm: optional per-cloud 3x3 matrices folded into the (shared, wcs = 0) kernel on the fly, w_eff[b] = Rm[b] @ w, also written to
 // weff_out (B, 3, C) and Rm copied to r_copy (B, 9) when given
 int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st, int store16 = 0,
-              const float* Rm = nullptr, float* weff_out = nullptr, float* r_copy = nullptr, const BnTail* tail = nullptr);
+              const float* Rm = nullptr, float* weff_out = nullptr, float* r_copy = nullptr);
 int conv3_wgrad(const float* x3, const pn_operand* dz, int B, int N, int C, float* slabs, hipStream_t st);
 int slab_reduce(const float* slabs, int n_slabs, int per_group, long long elems, float* out, hipStream_t st);
 // several whole-range slab reductions (out_j = sum over the n_slabs_j slabs of job j, same summation order as slab_reduce) in one launch

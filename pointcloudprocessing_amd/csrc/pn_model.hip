@@ -19,7 +19,6 @@
 #include <cstring>
 #include <string>
 #include <vector>
-#include "pn_bntail.h"
 #include "pn_internal.h"
 
 namespace pn {
@@ -128,8 +127,6 @@ struct CL {   // per-point conv layer state
   float *Z = nullptr, *part = nullptr, *mean = nullptr, *invstd = nullptr, *scale = nullptr, *shift = nullptr;
   float *ca = nullptr, *cb = nullptr, *cc = nullptr, *dy = nullptr;
   unsigned short *w16 = nullptr, *wt16 = nullptr;   // bf16 copies of the layer's (K, C) kernel, as it is / transposed (bf16 mode, K >= 64)
-  long long* bacc = nullptr;                        // fixed-point accumulators + ticket of the layer's statistics, finished by the launch
-  unsigned* btick = nullptr;                        //   that produces z (pn_bntail.h); NULL: per-tile partials + a finaliser launch
   int C = 0, K = 0;
 };
 struct ML {   // extra state of a max-pooled layer
@@ -162,7 +159,6 @@ struct WS {
   float* slab_pool;          // slabs of the parameter-gradient jobs whose reduction is deferred to the end of the (phase of the) pass
   size_t slab_pool_floats;
   unsigned* dcount;
-  size_t zero_words;         // 32-bit words of the block behind dcount that the step's first launch clears
 };
 
 static long long wgrad_slab_rows(int B, int N, int Ci, int Cj, int* spc_out, int target_override = 0) {
@@ -311,32 +307,14 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
   w.dense_part = A.get<float>("dense_part", (size_t)8 * B * 4096);          // split-K tiles of the dense layers (<= 8 splits)
   // their in-launch arrival counters, followed by the three max-pooled layers' column-sum accumulators (B x 256 64-bit words each):
   // ONE block, cleared by the step's first launch
-  // ... and the accumulators + tickets of the per-point layers whose BatchNormalization statistics are finished by the launch that
-  // produces them (pn_bntail.h)
+  w.dcount = A.get<unsigned>("dcount", DENSE_MAX_COUNTERS + 3 * (size_t)B * 512);
   {
-    CL* tails[8];
-    int nt = 0;
-    if (!d.vanilla) { tails[nt++] = &w.iT.c1; tails[nt++] = &w.iT.c2; tails[nt++] = &w.fT.c1; tails[nt++] = &w.fT.c2; }
-    tails[nt++] = &w.m11; tails[nt++] = &w.m12; tails[nt++] = &w.m21; tails[nt++] = &w.m22;
-    size_t words = DENSE_MAX_COUNTERS + 3 * (size_t)B * 512;
-    for (int q = 0; q < nt; ++q) words += bn_tail_words(tails[q]->C);
-    w.zero_words = words;
-    w.dcount = A.get<unsigned>("dcount", words);
     long long* acc = w.dcount ? reinterpret_cast<long long*>(w.dcount + DENSE_MAX_COUNTERS) : nullptr;
     if (!d.vanilla) {
       w.iT.m3.pa1 = acc;
       w.fT.m3.pa1 = acc ? acc + (size_t)B * 256 : nullptr;
     }
     w.mm23.pa1 = acc ? acc + 2 * (size_t)B * 256 : nullptr;
-    unsigned* u = w.dcount ? w.dcount + DENSE_MAX_COUNTERS + 3 * (size_t)B * 512 : nullptr;
-    static const bool tails_on = !(getenv("PN_BN_TAIL") && atoi(getenv("PN_BN_TAIL")) == 0);
-    for (int q = 0; q < nt; ++q) {
-      if (u && tails_on) {
-        tails[q]->bacc = reinterpret_cast<long long*>(u);
-        tails[q]->btick = u + (size_t)BN_SHARDS * 2 * tails[q]->C * 2;
-      }
-      if (u) u += bn_tail_words(tails[q]->C);
-    }
   }
   w.R3eye = A.get<float>("R3eye", (size_t)B * 9);
   w.regpart = A.get<float>("regpart", (size_t)2 * B);
@@ -542,20 +520,7 @@ struct Run {
     return bn_finalize(l.part, n_tiles < 0 ? T : n_tiles, r.cout, M, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub, ub, l.mean,
                        l.invstd, l.scale, l.shift, st);
   }
-  // the layer's statistics finished by the launch that produces z (pn_bntail.h): no finaliser launch
-  bool make_tail(const CL& l, const LRef& r, BnTail& t) const {
-    if (!bn_batch(r.block) || !l.bacc) return false;
-    memset(&t, 0, sizeof(t));
-    t.acc = l.bacc; t.ticket = l.btick; t.C = r.cout; t.inv_count = 1.0 / (double)M; t.kind = 0; t.fix = BN_FIX_FWD;
-    t.gamma = p(r.gamma); t.beta = p(r.beta); t.mm = p(r.mm); t.mv = p(r.mv);
-    t.momentum = d.bn_momentum; t.eps = d.bn_eps; t.update = 1;
-    t.mean = l.mean; t.invstd = l.invstd; t.scale = l.scale; t.shift = l.shift;
-    return true;
-  }
   int fwd_conv(CL& l, const LRef& r, const pn_operand& x, const float* W, long long wcs, const float* cloud_bias) {
-    BnTail t;
-    if (make_tail(l, r, t))
-      return conv_fwd(&x, W, wcs, B, N, r.cin, r.cout, cloud_bias, l.Z, nullptr, prec, st, (wcs == 0 && W == p(r.kernel)) ? l.wt16 : nullptr, &t);
     PN_TRY(conv_fwd(&x, W, wcs, B, N, r.cin, r.cout, cloud_bias, l.Z, bn_batch(r.block) ? l.part : nullptr, prec,
                     st, (wcs == 0 && W == p(r.kernel)) ? l.wt16 : nullptr));
     return bn_fin(l, r);
@@ -583,13 +548,8 @@ struct Run {
   }
   int fwd_tnet(TN& t, const TRef& r, const pn_operand* x) {
     if (r.K == 3) {
-      BnTail bt;
-      if (make_tail(t.c1, r.c1, bt)) {
-        PN_TRY(conv3_fwd(w.pcn, p(r.c1.kernel), 0, B, N, 64, t.c1.Z, nullptr, st, s16, nullptr, nullptr, nullptr, &bt));
-      } else {
-        PN_TRY(conv3_fwd(w.pcn, p(r.c1.kernel), 0, B, N, 64, t.c1.Z, bn_batch(r.c1.block) ? t.c1.part : nullptr, st, s16));
-        PN_TRY(bn_fin(t.c1, r.c1));
-      }
+      PN_TRY(conv3_fwd(w.pcn, p(r.c1.kernel), 0, B, N, 64, t.c1.Z, bn_batch(r.c1.block) ? t.c1.part : nullptr, st, s16));
+      PN_TRY(bn_fin(t.c1, r.c1));
     } else {
       PN_TRY(fwd_conv(t.c1, r.c1, *x, p(r.c1.kernel), 0, nullptr));
     }
@@ -639,24 +599,20 @@ struct Run {
       add_fz(w.s1, L.s1); add_fz(w.s2, L.s2); add_fz(w.s3, L.s3); add_fz(w.s4, L.s4);
       const bool zg = training && G && io.zero_grads_in_forward;
       const bool dm = training && io.dropout_step && io.keep1 && io.keep2 && d.dropout_rate > 0.f;
-      PN_TRY(fwd_prologue(io.pc, B, N, w.pcn, w.cent, w.scl, ws, sgs, Ks, Cs, his, los, w.dcount, (int)w.zero_words, zg ? G : nullptr,
+      PN_TRY(fwd_prologue(io.pc, B, N, w.pcn, w.cent, w.scl, ws, sgs, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS + 3 * B * 512, zg ? G : nullptr,
                           zg ? L.total : 0, dm ? const_cast<unsigned char*>(io.keep1) : nullptr, dm ? (long long)B * 512 : 0,
                           dm ? const_cast<unsigned char*>(io.keep2) : nullptr, dm ? (long long)B * 256 : 0, d.dropout_rate, io.dropout_seed,
                           dm ? io.dropout_step : nullptr, wc, nwc, fz, nfz, d.bn_eps, st));
     }
     if (!d.vanilla) {
       PN_TRY(fwd_tnet(w.iT, L.iT, nullptr));
-    }
-    BnTail bt11;
-    const bool tail11 = make_tail(w.m11, L.m11, bt11);
-    float* part11 = (bn_batch(BLK_M11) && !tail11) ? w.m11.part : nullptr;
-    if (!d.vanilla) {
       // tf.matmul(pc, R) (PointNet.py:207) folded into mlp_1_1's kernel inside the launch; it also leaves W_eff and the third output
-      PN_TRY(conv3_fwd(w.pcn, p(L.m11.kernel), 0, B, N, 64, w.m11.Z, part11, st, s16, w.iT.R, w.Weff1, io.out_R, tail11 ? &bt11 : nullptr));
+      PN_TRY(conv3_fwd(w.pcn, p(L.m11.kernel), 0, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st, s16, w.iT.R, w.Weff1,
+                       io.out_R));
     } else {
-      PN_TRY(conv3_fwd(w.pcn, p(L.m11.kernel), 0, B, N, 64, w.m11.Z, part11, st, s16, nullptr, nullptr, nullptr, tail11 ? &bt11 : nullptr));
+      PN_TRY(conv3_fwd(w.pcn, p(L.m11.kernel), 0, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st, s16));
     }
-    if (!tail11) PN_TRY(bn_fin(w.m11, L.m11));
+    PN_TRY(bn_fin(w.m11, L.m11));
     PN_TRY(fwd_conv(w.m12, L.m12, lazy(w.m11), p(L.m12.kernel), 0, nullptr));
     if (!d.vanilla) {
       const pn_operand a12 = lazy(w.m12);

@@ -1,7 +1,6 @@
 // Bandwidth-bound per-point kernels and the small finalisers between contractions (gfx950).
 #include <cstring>
 #include "pn_common.h"
-#include "pn_bntail.h"
 #include "pn_internal.h"
 
 namespace pn {
@@ -14,7 +13,7 @@ __global__ __launch_bounds__(256) void conv3_fwd_kernel(const float* __restrict_
                                                         long long wcs, int N, int C, int tiles_per_cloud,
                                                         float* __restrict__ z, float* __restrict__ part, int store16,
                                                         const float* __restrict__ Rm, float* __restrict__ weff_out,
-                                                        float* __restrict__ r_copy, const BnTail tail) {
+                                                        float* __restrict__ r_copy) {
   __shared__ float red[4][2][64];
   const int bx = blockIdx.x, cloud = bx / tiles_per_cloud, tin = bx - cloud * tiles_per_cloud;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -54,38 +53,26 @@ __global__ __launch_bounds__(256) void conv3_fwd_kernel(const float* __restrict_
       s2 = fmaf(v, v, s2);
     }
   });
-  if (part || tail.acc) {
+  if (part) {
     red[wave][0][lane] = s1;
     red[wave][1][lane] = s2;
     __syncthreads();
-    if (part && tid < 128) {
+    if (tid < 128) {
       const int which = tid >> 6, l = tid & 63;
       const float s = red[0][which][l] + red[1][which][l] + red[2][which][l] + red[3][which][l];
       part[(long long)bx * 2 * C + which * C + blockIdx.y * 64 + l] = s;
-    }
-    if (tail.acc) {                                       // the layer's statistics finished by this launch (pn_bntail.h)
-      if (tid < 64) {
-        const float t1 = red[0][0][tid] + red[1][0][tid] + red[2][0][tid] + red[3][0][tid];
-        const float t2 = red[0][1][tid] + red[1][1][tid] + red[2][1][tid] + red[3][1][tid];
-        bn_tail_add(tail, bx + (int)blockIdx.y * (int)gridDim.x, blockIdx.y * 64 + tid, t1, t2);
-      }
-      __syncthreads();
-      bn_tail_meet(tail, tid, 256, reinterpret_cast<unsigned*>(&red[0][0][0]));
     }
   }
 }
 
 int conv3_fwd(const float* x3, const float* w, long long wcs, int B, int N, int C, float* z, float* part, hipStream_t st, int store16,
-              const float* Rm, float* weff_out, float* r_copy, const BnTail* tail) {
+              const float* Rm, float* weff_out, float* r_copy) {
   PN_CHECK_ARG(x3 && w, "pn_conv3_fwd: null pointer");
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv3_fwd: B and N must be positive");
   PN_CHECK_ARG(C >= 64 && C % 64 == 0, "pn_conv3_fwd: C must be a multiple of 64 (C=%d)", C);
   const int tpc = cdiv(N, 128);
-  BnTail t;
-  memset(&t, 0, sizeof(t));
-  if (tail) { t = *tail; t.n_wg = B * tpc * (C / 64); }
   hipLaunchKernelGGL(conv3_fwd_kernel, dim3(B * tpc, C / 64), dim3(256), 0, st, x3, w, wcs, N, C, tpc, z, part, store16, Rm, weff_out,
-                     r_copy, t);
+                     r_copy);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -286,8 +286,8 @@ __global__ __launch_bounds__(1024) void fwd_prologue_kernel(const PrologueArgs a
   if (bx < a.B) { normalize_body(a.xyz, a.N, a.out, a.centroid, a.scale, bx, red, bc); return; }
   bx -= a.B;
   if (bx < a.n_prep) {
-    if (a.zero_u)                                           // spread over the kernel-copy workgroups
-      for (long long i = (long long)bx * 1024 + threadIdx.x; i < a.zero_u_n; i += (long long)a.n_prep * 1024) a.zero_u[i] = 0u;
+    if (bx == 0 && a.zero_u)
+      for (int i = threadIdx.x; i < a.zero_u_n; i += 1024) a.zero_u[i] = 0u;
     const long long lin = (long long)bx * 1024 + threadIdx.x;            // layer-major: z = lin / prep_chunks
     const int z = (int)(lin / a.prep_chunks);
     if (z < 3) prep3_chunk(a.prep, z, lin - (long long)z * a.prep_chunks);
