@@ -220,3 +220,40 @@ def test_rccl_world_size_1_split_graph_step_equals_fused_step(dev):
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][0][len("RESULT "):])
     assert res["modes"] == ["hipgraph"] * 3 and res["finite"] and res["moved"] > 0
     assert res["same_overlapped"] and res["same_single"], res
+
+
+@pytest.mark.gpu
+def test_optimizer_over_the_trainable_extent_equals_the_full_range(dev):
+    """With the segmentation head frozen (the `classification_pretrain` stage) its slots lie outside PointNet.grad_extent(): the step
+    hands Adam only the extent.  Gradients and moments of the rest are zero, so the weights after a few steps must equal, bit for
+    bit, those of an optimizer stepping the whole flat buffer -- and the frozen slots must not have moved at all."""
+    from pointcloudprocessing_amd.engine import TrainStep
+    from pointcloudprocessing_amd.optim import KerasAdam
+    from pointcloudprocessing_amd.pointnet.PointNet import PointNet
+    B, N = 8, 256
+    g = torch.Generator().manual_seed(2)
+    pc = (torch.rand(B, N, 3, generator=g) * 10).to(dev)
+    y_cls = torch.randint(0, 23, (B,), generator=g, dtype=torch.int32).to(dev)
+    y_seg = torch.randint(0, 12, (B, N), generator=g, dtype=torch.int32).to(dev)
+    se3 = torch.eye(3).expand(B, 3, 3).contiguous().to(dev)
+    finals, w0 = [], None
+    for restricted in (True, False):
+        m = PointNet(23, 12, 0.0, 42, precision="bf16", device=dev)
+        if w0 is None:
+            w0 = m.params_flat.data.clone()
+        else:
+            m.params_flat.data.copy_(w0)
+        m.freeze_segmentation_head()
+        lo, hi = m.grad_extent()
+        n = m.grads_flat.numel()
+        assert 0 <= lo < hi < n, (lo, hi, n)                       # the frozen head is the tail of the flat buffer
+        if not restricted:
+            m.grad_extent = lambda n=n: (0, n)                     # this arm steps everything
+        opt = KerasAdam(m.params_flat.data, 1e-3, 7000, 0.7)
+        ts = TrainStep(m, opt, B, N, (1.0, 0.0, 0.0), use_graph=restricted)
+        for _ in range(6):
+            ts(pc, y_cls, y_seg, se3)
+        torch.cuda.synchronize()
+        assert torch.equal(m.params_flat.data[hi:], w0[hi:])       # nothing outside the extent moved
+        finals.append(m.params_flat.data.clone())
+    assert torch.equal(finals[0], finals[1])
