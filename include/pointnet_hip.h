@@ -221,6 +221,26 @@ int pn_dense_bwd(const float* da, const float* z, const float* x, int ldx, int R
                  const float* beta, const float* mean, const float* invstd, int bn_mode, int act, const uint8_t* keep,
                  float keep_scale, float* dz, float* dgamma, float* dbeta, float* dbias, float* dw, pn_stream stream);
 
+/* --- one launch per layer of a backward CHAIN of dense layers -- the gradient of DenseLayer.call (PointNet.py:642-654) and of the
+ * T-Net's X @ w + b (:436-442) as the model plan runs it; R <= 32 with a tail:
+ * dx (R, C) = dz_above (R, K; row stride lddz) . W_above^T from the (C, K)-shaped kernel (w_above[j*ldw + k]) -- which is d(activation)
+ * of the layer below -- and, tail != NULL, in the same launch that layer's dropout -> ReLU -> BatchNormalization backward (per
+ * column, done by the workgroup that finishes the column block): tail->dz (R, C), dgamma, dbeta (bn_mode 1) or dbias (bn_mode 0).
+ * Same arithmetic as pn_dense_layer(trans = 1) followed by pn_dense_bwd(dw = NULL), up to the order of the column sums.
+ * workspace / counters: as pn_dense_layer. */
+typedef struct pn_dense_tail {
+  const float *z, *gamma, *beta, *mean, *invstd;   /* of the layer below: stored pre-BN output, BN parameters, batch mean / invstd */
+  const uint8_t* keep; float keep_scale;            /* its dropout mask (R, C) or NULL */
+  int bn_mode, act;                                 /* as pn_dense_layer */
+  float *dz, *dgamma, *dbeta, *dbias;               /* outputs; dgamma / dbeta / dbias may be NULL */
+} pn_dense_tail;
+int pn_dense_bwd_step(const float* dz_above, int lddz, const float* w_above, int ldw, int R, int K, int C, float* workspace,
+                      uint32_t* counters, float* dx, const pn_dense_tail* tail, pn_stream stream);
+/* the weight gradients dw (K, C) = x^T . dz (x: (R, K), row stride ldx) and, db != NULL, db (C) = column sums of dz, of up to 12
+ * dense layers in ONE launch (nothing reads them before the optimizer: a backward pass collects them); fp32 fma chain over the rows */
+typedef struct pn_dense_wgrad_job { const float* x; int ldx; const float* dz; int R, K, C; float* dw; float* db; } pn_dense_wgrad_job;
+int pn_dense_wgrad_batch(const pn_dense_wgrad_job* jobs, int n, pn_stream stream);
+
 /* --- tf.nn.softmax (PointNet.py:134) + keras SparseCategoricalCrossentropy(from_logits=False) + sparse accuracy for rows = B
  * (pointnet_train.py:334-345): probs (R, C); with labels: loss_sum[0] = sum_r nll_r, correct[0] = #(argmax == label), and, if
  * dlogits != NULL, dlogits = grad_scale * d(sum nll)/d(logits) including keras' clip to [1e-7, 1-1e-7] (zero gradient outside). */

@@ -37,6 +37,17 @@ class pn_operand(C.Structure):
                 ("cc", C.c_void_p), ("ld", C.c_int64), ("lo", C.c_float), ("h16", C.c_int32)]
 
 
+class pn_dense_tail(C.Structure):
+    _fields_ = [("z", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p),
+                ("keep", C.c_void_p), ("keep_scale", C.c_float), ("bn_mode", C.c_int32), ("act", C.c_int32),
+                ("dz", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dbias", C.c_void_p)]
+
+
+class pn_dense_wgrad_job(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("ldx", C.c_int32), ("dz", C.c_void_p), ("R", C.c_int32), ("K", C.c_int32), ("C", C.c_int32),
+                ("dw", C.c_void_p), ("db", C.c_void_p)]
+
+
 class pn_model_desc(C.Structure):
     _fields_ = [("ccls", C.c_int32), ("cseg", C.c_int32), ("vanilla", C.c_int32), ("reg_in", C.c_int32),
                 ("reg_feat", C.c_int32), ("prec", C.c_int32), ("dropout_rate", C.c_float),
@@ -90,6 +101,8 @@ SIGNATURES = {
     "pn_max_finalize": (_I, [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "pn_dense_workspace_floats": (C.c_size_t, [_I, _I, _I]),
     "pn_dense_layer": (_I, [_P, _I, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
+    "pn_dense_bwd_step": (_I, [_P, _I, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "pn_dense_wgrad_batch": (_I, [_P, _I, _P]),
     "pn_dense_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _I, _P, _F, _P, _P, _P, _P, _P, _P]),
     "pn_softmax_xent": (_I, [_P, _I, _I, _P, _F, _P, _P, _P, _P, _P]),
     "pn_argmax_rows": (_I, [_P, _I64, _I, _P, _P]),

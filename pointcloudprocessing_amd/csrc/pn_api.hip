@@ -98,6 +98,13 @@ int pn_dense_bwd(const float* da, const float* z, const float* x, int ldx, int R
   return dense_bwd_fused(da, z, x, ldx, R, K, C, gamma, beta, mean, invstd, bn_mode, act, keep, keep_scale, dz, dgamma, dbeta, dbias, dw,
                          S(stream));
 }
+int pn_dense_bwd_step(const float* dz_above, int lddz, const float* w_above, int ldw, int R, int K, int C, float* workspace,
+                      uint32_t* counters, float* dx, const pn_dense_tail* tail, pn_stream stream) {
+  return dense_trans_tail(dz_above, lddz, w_above, ldw, R, K, C, workspace, counters, dx, reinterpret_cast<const DenseTail*>(tail), S(stream));
+}
+int pn_dense_wgrad_batch(const pn_dense_wgrad_job* jobs, int n, pn_stream stream) {
+  return dense_wgrad_batch(reinterpret_cast<const DenseWgradJob*>(jobs), n, S(stream));
+}
 int pn_softmax_xent(const float* logits, int R, int C, const int32_t* labels, float grad_scale, float* probs, float* dlogits,
                     float* loss_sum, float* correct, pn_stream stream) {
   return softmax_xent_rows(logits, R, C, labels, grad_scale, probs, dlogits, loss_sum, correct, S(stream));

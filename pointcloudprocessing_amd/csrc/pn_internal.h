@@ -106,17 +106,19 @@ int dense_bwd_pre(const float* da, const float* z, int R, int C, const float* ga
                   float* dbeta, float* dbias, hipStream_t st);
 int dense_wgrad(const float* x, int ldx, const float* dz, int R, int K, int C, float* dw, hipStream_t st, float* db = nullptr);   // db: column sums of dz
 // the layer below a TRANS product, taken backward in the same launch (pn_dense.hip: DenseArgs::bt_*)
-struct DenseTail {
+struct DenseTail {                     // = pn_dense_tail of the C ABI, field for field
   const float *z, *gamma, *beta, *mean, *invstd;
   const unsigned char* keep; float keep_scale;
   int mode, act;                       // mode: 0 bias only, 1 batch statistics, 2 moving statistics; act: 1 relu
   float *dz, *dgamma, *dbeta, *dbias;  // dgamma / dbeta / dbias may be NULL (frozen layer)
 };
+static_assert(sizeof(DenseTail) == sizeof(pn_dense_tail), "DenseTail mirrors pn_dense_tail");
 int dense_trans_tail(const float* dz, int lddz, const float* w, int ldw, int R, int K, int C, float* partial, unsigned* counters, float* dx,
                      const DenseTail* tail, hipStream_t st);
 // dw (K, C) = x^T . dz, db (C) = column sums of dz (or NULL), for several layers in one launch
 constexpr int DENSE_WGRAD_MAX_JOBS = 12;
-struct DenseWgradJob { const float* x; int ldx; const float* dz; int R, K, C; float* dw; float* db; };
+struct DenseWgradJob { const float* x; int ldx; const float* dz; int R, K, C; float* dw; float* db; };      // = pn_dense_wgrad_job
+static_assert(sizeof(DenseWgradJob) == sizeof(pn_dense_wgrad_job), "DenseWgradJob mirrors pn_dense_wgrad_job");
 int dense_wgrad_batch(const DenseWgradJob* jobs, int n, hipStream_t st);
 int transpose(const float* in, int R, int C, float* out, hipStream_t st);
 int transpose2(const float* in, int R, int C, const float* rowscale, float* out, float* out2, hipStream_t st);

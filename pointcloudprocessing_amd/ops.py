@@ -256,6 +256,45 @@ def dense_layer(x, w, trans=False, bias=None, gamma=None, beta=None, moving_mean
     return z, a, mean, invstd
 
 
+def dense_bwd_step(dz_above, w_above, z=None, gamma=None, beta=None, mean=None, invstd=None, bn_mode=0, act=0, keep=None, rate=0.0):
+    """one launch of a backward chain: dx = dz_above . W_above^T (w_above: the (C, K) kernel of the layer above) and, with z given,
+    the layer below taken backward in the same launch: returns (dx, dz, dgamma, dbeta, dbias)"""
+    R, K = dz_above.shape
+    C_ = w_above.shape[0]
+    dev = dz_above.device
+    ws = torch.empty(max(1, lib().pn_dense_workspace_floats(R, K, C_)), device=dev, dtype=F32)
+    counters = torch.zeros(256, device=dev, dtype=torch.int32)
+    dx = torch.empty(R, C_, device=dev, dtype=F32)
+    dz = dg = db = dbias = None
+    tail = None
+    if z is not None:
+        dz = torch.empty(R, C_, device=dev, dtype=F32)
+        dg = torch.zeros(C_, device=dev, dtype=F32); db = torch.zeros(C_, device=dev, dtype=F32); dbias = torch.zeros(C_, device=dev, dtype=F32)
+        tail = _lib.pn_dense_tail()
+        for k, v in dict(z=z, gamma=gamma, beta=beta, mean=mean, invstd=invstd, keep=keep, dz=dz, dgamma=dg, dbeta=db, dbias=dbias).items():
+            setattr(tail, k, None if v is None else v.data_ptr())
+        tail.keep_scale = 1.0 / (1.0 - rate)
+        tail.bn_mode, tail.act = bn_mode, act
+    check(lib().pn_dense_bwd_step(ptr(dz_above), dz_above.stride(0), ptr(w_above), w_above.stride(0), R, K, C_, ptr(ws), ptr(counters), ptr(dx),
+                                  C.byref(tail) if tail is not None else None, current_stream()), "pn_dense_bwd_step")
+    return dx, dz, dg, db, dbias
+
+
+def dense_wgrad_batch(jobs):
+    """jobs: [(x (R, K), dz (R, C), want_db)] -> [(dw (K, C), db (C) or None)] in one launch"""
+    arr = (_lib.pn_dense_wgrad_job * len(jobs))()
+    outs = []
+    for j, (x, dz, want_db) in zip(arr, jobs):
+        R, K = x.shape
+        C_ = dz.shape[1]
+        dw = torch.empty(K, C_, device=x.device, dtype=F32)
+        db = torch.empty(C_, device=x.device, dtype=F32) if want_db else None
+        j.x, j.ldx, j.dz, j.R, j.K, j.C, j.dw, j.db = x.data_ptr(), x.stride(0), dz.data_ptr(), R, K, C_, dw.data_ptr(), (db.data_ptr() if want_db else None)
+        outs.append((dw, db))
+    check(lib().pn_dense_wgrad_batch(arr, len(jobs), current_stream()), "pn_dense_wgrad_batch")
+    return outs
+
+
 def dense_bwd(da, z, x, gamma=None, beta=None, mean=None, invstd=None, bn_mode=0, act=0, keep=None, rate=0.0, want_dw=True):
     """backward of the layer tail + parameters: returns (dz, dgamma, dbeta, dbias, dw)"""
     R, C_ = da.shape

@@ -501,6 +501,50 @@ def test_dense_bwd_matches_autograd(dev, R, K, C_, bn_mode, act, drop):
     assert torch.allclose(dx, x2.grad, rtol=1e-4, atol=1e-4), float((dx - x2.grad).abs().max())
 
 
+@pytest.mark.parametrize("R,Kin,C_,Cup,bn_mode,act,drop", [(32, 256, 512, 256, 1, 1, True), (7, 64, 96, 23, 1, 1, False), (32, 128, 256, 9, 2, 1, False),
+                                                        (16, 64, 64, 40, 0, 0, False)])
+def test_dense_backward_chain_step_equals_the_two_launch_form(dev, R, Kin, C_, Cup, bn_mode, act, drop):
+    """The model plan takes a chain of dense layers backward with ONE launch per layer (pn_dense_bwd_step: dx = dz_above . W_above^T and
+    the layer below's dropout / ReLU / BatchNormalization backward in its finishing workgroups) and one batched weight-gradient launch
+    (pn_dense_wgrad_batch).  Against the two-launch form (pn_dense_layer(trans) then pn_dense_bwd, themselves checked against fp64
+    autograd above): dx is the same kernel -> bit-identical; dz, dgamma, dbeta / dbias differ only by the order of the column sums;
+    dw is an exact fp32 fma chain where pn_dense_bwd multiplies split bf16 operands."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(R * 7 + C_)
+    x = torch.randn(R, Kin, generator=g).to(dev)                       # input of the layer below
+    z = torch.randn(R, C_, generator=g).to(dev)                        # its stored pre-BN output
+    gamma = (torch.rand(C_, generator=g) + 0.5).to(dev); beta = torch.randn(C_, generator=g).to(dev)
+    mean = z.mean(0) if bn_mode == 1 else torch.randn(C_, generator=g).to(dev) * 0.1
+    invstd = torch.rsqrt(z.var(0, unbiased=False) + 1e-3) if bn_mode == 1 else (torch.rand(C_, generator=g).to(dev) + 0.5)
+    keep = (torch.rand(R, C_, generator=g) > 0.3).to(torch.uint8).to(dev) if drop else None
+    w_up = (torch.randn(C_, Cup, generator=g) * 0.1).to(dev)           # kernel of the layer above: (cin = C_, cout = Cup)
+    dz_up = torch.randn(R, Cup, generator=g).to(dev)
+    bn = dict(gamma=gamma if bn_mode else None, beta=beta if bn_mode else None, mean=mean if bn_mode else None, invstd=invstd if bn_mode else None)
+    # two-launch form
+    da, _, _, _ = ops.dense_layer(dz_up, w_up, trans=True)
+    dz_ref, dg_ref, db_ref, dbias_ref, dw_ref = ops.dense_bwd(da, z, x, bn_mode=bn_mode, act=act, keep=keep, rate=0.3, **bn)
+    # chain form
+    dx, dz, dg, db, dbias = ops.dense_bwd_step(dz_up, w_up, z=z, bn_mode=bn_mode, act=act, keep=keep, rate=0.3, **bn)
+    (dw, dbcol), (dw_up, db_up) = ops.dense_wgrad_batch([(x, dz, True), (torch.relu(z), dz_up, True)])
+    assert torch.equal(dx, da)
+    tol = dict(rtol=2e-5, atol=2e-5 * float(dz_ref.abs().max()))
+    assert torch.allclose(dz, dz_ref, **tol), float((dz - dz_ref).abs().max())
+    if bn_mode == 1:
+        assert torch.allclose(dg, dg_ref, rtol=1e-5, atol=1e-4) and torch.allclose(db, db_ref, rtol=1e-5, atol=1e-4)
+    if bn_mode == 0:
+        assert torch.allclose(dbias, dbias_ref, rtol=1e-5, atol=1e-4)
+    ref_dw = x.double().t() @ dz.double()
+    assert torch.allclose(dw.double(), ref_dw, rtol=1e-5, atol=1e-5 * float(ref_dw.abs().max())), float((dw.double() - ref_dw).abs().max())
+    assert torch.allclose(dw, dw_ref, rtol=2e-3, atol=2e-4 * float(ref_dw.abs().max()))
+    assert torch.allclose(dbcol.double(), dz.double().sum(0), rtol=1e-5, atol=1e-5)
+    ref_up = torch.relu(z).double().t() @ dz_up.double()
+    assert torch.allclose(dw_up.double(), ref_up, rtol=1e-5, atol=1e-5 * float(ref_up.abs().max()))
+    assert torch.allclose(db_up.double(), dz_up.double().sum(0), rtol=1e-5, atol=1e-5)
+    # no tail: the plain product
+    dx2, none_dz, _, _, _ = ops.dense_bwd_step(dz_up, w_up)
+    assert none_dz is None and torch.equal(dx2, da)
+
+
 def test_dropout_masks_counter_based(dev):
     """keep-probability, independence of the two layers, fresh masks per call, reproducible from (seed, step)"""
     import ctypes as C
