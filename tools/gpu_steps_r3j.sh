@@ -1,0 +1,27 @@
+out=$1
+R=$GRAFT_REPO_ROOT
+step() { # name, seconds, command... ; a step that times out ends the call
+  local name=$1 secs=$2; shift 2
+  local t0=$(date +%s)
+  timeout -k 10 $secs "$@"; local rc=$?
+  echo "$name rc=$rc ($(( $(date +%s) - t0 )) s)" | tee -a $R/$out/summary.txt
+  if [ $rc -ge 124 ]; then echo "stopping after $name" | tee -a $R/$out/summary.txt; exit 1; fi
+}
+
+step "smoke" 200 bash -c "python -c 'import __graft_entry__ as g; g.smoke()' > $out/smoke.log 2>&1"
+step "bench" 300 bash -c "python bench.py > $out/bench.json 2> $out/bench.err"
+for cfg in "c3 --points 2048 --profile final" "c3_all --points 2048 --profile all" "c4rank --batch 8 --points 4096" "b32n4096 --points 4096" "x3 --precision bf16x3" "f32act --precision bf16_f32act" "final1024 --profile final" "all1024 --profile all"; do
+  set -- $cfg; tag=$1; shift
+  step "bench $tag" 200 bash -c "python bench.py --steps 100 --warmup 10 --no-cpu-baseline $* > $out/bench_$tag.json 2> $out/bench_$tag.err"
+done
+step "panel probe" 200 bash -c "python tools/panel_probe.py > $out/panel_probe.jsonl 2> $out/panel_probe.err"
+step "scan pipeline" 200 bash -c "python tools/bench_scan.py > $out/scan.json 2> $out/scan.err"
+cd /tmp
+step "prof c2" 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof -o c2 -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline
+step "prof c3" 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof -o c3 -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --points 2048 --profile final
+step "prof b32n4096" 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/prof -o b32n4096 -- python3 $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --points 4096
+step "pmc fetch" 200 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$out/pmc_fetch -o f -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-graph
+step "pmc write" 200 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$out/pmc_write -o w -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-graph
+cd $R
+step "pmc summary" 60 python tools/pmc_summary.py $out/pmc_fetch $out/pmc_write $out/pmc r2
+rm -f $out/pmc_fetch/*kernel_trace* $out/pmc_write/*kernel_trace* $out/prof/*kernel_trace*
