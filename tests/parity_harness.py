@@ -163,11 +163,28 @@ def check_training_step(dev, B, N, profile, vanilla=False, precision="bf16x3", r
         dense_map.update({"input_transform.dense1": "iT.d1", "input_transform.dense2": "iT.d2", "feature_transform.dense1": "fT.d1",
                           "feature_transform.dense2": "fT.d2"})
         max_map.update({"input_transform": "iT.m3", "feature_transform": "fT.m3"})
+    # A frozen segmentation head that gets no gradient runs as ONE launch in the bf16 mode and keeps its layers' outputs on chip
+    # (pn_segout.hip: seg_head_fused) -- the workspace entries s1..s4 of `m` are then never written.  Their decisions come from a
+    # second model that keeps its activations (the layer-by-layer plan): tests/test_gpu_model.py shows the two plans agree bit for
+    # bit, and the outputs compared below are still those of `m`, the plan the product runs.
+    seg_src = m
+    if precision == "bf16" and not spec.get("seg", True) and lw[1] == 0:
+        seg_src = build_model(dev, params, vanilla, precision=precision, reg=reg)
+        apply_profile(seg_src, spec)
+        seg_src.keep_activations = True
+        outs_k = seg_src.fused_loss_step(pc.to(dev), y_cls.to(torch.int32).to(dev), y_seg.to(torch.int32).to(dev), se3.to(dev), lw, keep=kp)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a_, b_) for a_, b_ in zip(outs_g, outs_k)), "fused frozen head differs from the layer-by-layer plan"
+
+    def ws_of(on):
+        mm_ = seg_src if on.startswith("mlp_seg_") else m
+        return lambda name, dtype=torch.float32: mm_.workspace_tensor(name, B, N, True, dtype).cpu()
     decisions = {}
     for on, wn in conv_map.items():
-        z = ws(wn + ".Z", act).float()
-        C_ = ws(wn + ".scale").numel()
-        decisions[on + ".relu"] = (torch.addcmul(ws(wn + ".shift"), ws(wn + ".scale"), z.view(-1, C_)) > 0).view(B, N, C_)
+        wsl = ws_of(on)
+        z = wsl(wn + ".Z", act).float()
+        C_ = wsl(wn + ".scale").numel()
+        decisions[on + ".relu"] = (torch.addcmul(wsl(wn + ".shift"), wsl(wn + ".scale"), z.view(-1, C_)) > 0).view(B, N, C_)
     for on, wn in dense_map.items():
         a = ws(wn + ".a")
         decisions[on + ".relu"] = (a > 0).view(B, -1)

@@ -1,0 +1,11 @@
+out=$1
+R=$GRAFT_REPO_ROOT
+step() { # name, seconds, command... ; a step that times out ends the call
+  local name=$1 secs=$2; shift 2
+  local t0=$(date +%s)
+  timeout -k 10 $secs "$@"; local rc=$?
+  echo "$name rc=$rc ($(( $(date +%s) - t0 )) s)" | tee -a $R/$out/summary.txt
+  if [ $rc -ge 124 ]; then echo "stopping after $name" | tee -a $R/$out/summary.txt; exit 1; fi
+}
+step "train then parity (the order that failed)" 800 bash -c "python -m pytest tests/test_gpu_train.py tests/test_gpu_parity_configs.py tests/test_gpu_model.py -q -m gpu -x > $out/tests_order.log 2>&1"
+step "all gpu tests" 800 bash -c "python -m pytest tests -q -m gpu -x > $out/tests_all.log 2>&1"
