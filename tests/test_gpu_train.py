@@ -183,16 +183,22 @@ pc = (torch.rand(B, N, 3, generator=g) * 10).to(dev)
 y_cls = torch.randint(0, 23, (B,), generator=g, dtype=torch.int32).to(dev)
 y_seg = torch.randint(0, 12, (B, N), generator=g, dtype=torch.int32).to(dev)
 se3 = torch.eye(3).expand(B, 3, 3).contiguous().to(dev)
-finals, modes, w0 = [], [], None
-for split in (False, True, True):
-    os.environ["PN_DDP_OVERLAP"] = "1" if len(finals) < 2 else "0"
+finals, modes, w0, extents = [], [], None, []
+# arms 0-2: every block trains; arms 3-5: the `classification_pretrain` stage (segmentation head frozen, loss weights 1/0/0) -- both
+# buckets and the optimizer are clipped to the extent of the trainable blocks (PointNet.grad_extent)
+for arm, split in enumerate((False, True, True, False, True, True)):
+    os.environ["PN_DDP_OVERLAP"] = "0" if arm % 3 == 2 else "1"
+    frozen = arm >= 3
     m = PointNet(23, 12, 0.0, 42, precision="bf16", device=dev)
     if w0 is None:
         w0 = m.params_flat.data.clone()
     else:
         m.params_flat.data.copy_(w0)
+    if frozen:
+        m.freeze_segmentation_head()
+    extents.append(list(m.grad_extent()) + [m.grads_flat.numel()])
     opt = KerasAdam(m.params_flat.data, 1e-3, 7000, 0.7)
-    ts = TrainStep(m, opt, B, N, (1.0, 1.0, 1.0), use_graph=True, split_optimizer=split)
+    ts = TrainStep(m, opt, B, N, (1.0, 0.0, 0.0) if frozen else (1.0, 1.0, 1.0), use_graph=True, split_optimizer=split)
     assert ts.reduce == split
     for i in range(12):
         ts(pc, y_cls, y_seg, se3)
@@ -200,7 +206,9 @@ for split in (False, True, True):
     finals.append(m.params_flat.data.clone()); modes.append(ts.mode)
 print("RESULT", json.dumps(dict(modes=modes, same_overlapped=bool(torch.equal(finals[0], finals[1])),
                                 same_single=bool(torch.equal(finals[0], finals[2])), finite=bool(torch.isfinite(finals[1]).all()),
-                                moved=float((finals[0] - w0).abs().max()))))
+                                moved=float((finals[0] - w0).abs().max()),
+                                frozen_same_overlapped=bool(torch.equal(finals[3], finals[4])), frozen_same_single=bool(torch.equal(finals[3], finals[5])),
+                                frozen_moved=float((finals[3] - w0).abs().max()), extents=extents)))
 dist.barrier()
 dist.destroy_process_group()
 """
@@ -210,7 +218,8 @@ def test_rccl_world_size_1_split_graph_step_equals_fused_step(dev):
     """the data-parallel layout of a step with a REAL RCCL process group (world_size 1, one fresh child process): graph 1 (forward +
     backward phase 1) -> asynchronous all-reduce of the bucket [cut, end) -> graph 1b (backward phase 2) -> all-reduce of [0, cut) ->
     wait -> graph 2 (Adam), captured with RCCL's watchdog thread alive (capture_error_mode="thread_local", engine.py), against the
-    fused single-graph step: the weights after 12 steps must be bit-identical, for the overlapped and the single-collective form."""
+    fused single-graph step: the weights after 12 steps must be bit-identical, for the overlapped and the single-collective form --
+    with every block training, and in the `classification_pretrain` stage, where the buckets and Adam cover only the trainable extent."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -218,8 +227,11 @@ def test_rccl_world_size_1_split_graph_step_equals_fused_step(dev):
                          env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-3000:]
     res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT")][0][len("RESULT "):])
-    assert res["modes"] == ["hipgraph"] * 3 and res["finite"] and res["moved"] > 0
+    assert res["modes"] == ["hipgraph"] * 6 and res["finite"] and res["moved"] > 0 and res["frozen_moved"] > 0
     assert res["same_overlapped"] and res["same_single"], res
+    assert res["frozen_same_overlapped"] and res["frozen_same_single"], res
+    lo, hi, n = res["extents"][3]
+    assert res["extents"][0] == [0, n, n] and lo == 0 and hi < n, res["extents"]       # the frozen head is the tail of the flat buffer
 
 
 @pytest.mark.gpu
