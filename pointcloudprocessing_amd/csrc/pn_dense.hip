@@ -681,6 +681,9 @@ static int dense_args(DenseArgs& a, const float* x, int ldx, const float* w, int
   PN_CHECK_ARG(!bn_mode || (gamma && beta && mm && mv), "dense_layer: BatchNormalization needs gamma/beta/moving statistics");
   a.x = x; a.ldx = ldx; a.w = w; a.ldw = ldw; a.R = R; a.K = K; a.C = C;
   a.nsplit = dl_nsplit(K); a.split_len = dl_split_len(K);
+  // one column block and a short contraction (the logits layer, the 3 x 3 transform's output): one workgroup walks all of K -- two
+  // more 64-k steps per wave cost less than the in-launch meeting of two splits (partial tiles, ticket, re-read)
+  if (cdiv(C, DL_COLS) == 1 && K <= 512) { a.nsplit = 1; a.split_len = cdiv(K, DL_KSTEP) * DL_KSTEP; }
   a.partial = partial; a.counters = counters;
   a.bias = bias; a.gamma = gamma; a.beta = beta; a.mm = mm; a.mv = mv; a.momentum = momentum; a.eps = eps;
   a.bn_mode = bn_mode; a.act = act; a.keep = keep; a.keep_scale = keep_scale;
