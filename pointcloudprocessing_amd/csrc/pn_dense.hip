@@ -83,6 +83,16 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a0, co
   float own[DL_ROWS / DL_SLICES];
   // backward tail: what it reads of the layer below does not depend on this launch's products -- requested now by every workgroup
   // (only the last arriver of a column block uses them: four small loads wasted elsewhere, one memory round trip saved in the tail)
+  // ... and so are the layer's own BatchNormalization parameters and dropout mask, which the last arriver needs only after its
+  // reductions (there they would be one more memory round trip at the tail of the launch)
+  float pf_g = 1.f, pf_b = 0.f, pf_mm = 0.f, pf_mv = 1.f;
+  unsigned pf_keep = 0xfu;
+  if (a.bn_mode) { pf_g = a.gamma[jc]; pf_b = a.beta[jc]; pf_mm = a.mm[jc]; pf_mv = a.mv[jc]; }
+  if (a.keep && a.a_out && a.R <= DL_ROWS) {
+    pf_keep = 0u;
+#pragma unroll
+    for (int i = 0; i < DL_ROWS / DL_SLICES; ++i) pf_keep |= (a.keep[(long long)min(s + DL_SLICES * i, a.R - 1) * a.C + jc] ? 1u : 0u) << i;
+  }
   float bt_zz[DL_ROWS / DL_SLICES], bt_mu = 0.f, bt_is = 1.f, bt_g = 1.f, bt_b = 0.f;
   unsigned bt_kp = 0xfu;
   if (TRANS && a.bt_dz) {
@@ -262,17 +272,17 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a0, co
       for (int q = 0; q < RP; ++q) t += fin[(8 + q) * 32 + tx];
       var = t / (float)R;
       if (ty == 0 && jv) {
-        a.mm[j] = a.mm[j] * a.momentum + mean * (1.f - a.momentum);
-        a.mv[j] = a.mv[j] * a.momentum + var * (1.f - a.momentum);
+        a.mm[j] = pf_mm * a.momentum + mean * (1.f - a.momentum);
+        a.mv[j] = pf_mv * a.momentum + var * (1.f - a.momentum);
       }
     } else if (jv) {
-      mean = a.mm[j];
-      var = a.mv[j];
+      mean = pf_mm;
+      var = pf_mv;
     }
     const float invstd = 1.0f / sqrtf(var + a.eps);
     if (jv) {
-      sc = a.gamma[j] * invstd;
-      sh = a.beta[j] - mean * sc;
+      sc = pf_g * invstd;
+      sh = pf_b - mean * sc;
       if (ty == 0) {
         if (a.mean_o) a.mean_o[j] = mean;
         if (a.invstd_o) a.invstd_o[j] = invstd;
@@ -336,7 +346,7 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a0, co
         if (r < R) {
           float y = fmaf(sc, zr[i], sh);
           if (a.act == 1) y = clamp_lo(y, 0.f);
-          if (a.keep) y = a.keep[(long long)r * C + j] ? y * a.keep_scale : 0.f;
+          if (a.keep) y = ((pf_keep >> i) & 1u) ? y * a.keep_scale : 0.f;
           a.a_out[(long long)r * C + j] = y;
         }
       }

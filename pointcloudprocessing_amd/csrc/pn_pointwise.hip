@@ -320,6 +320,10 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
   __shared__ double red[16][2][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + tx;
+  // the channel's parameters do not depend on the sums: requested with the partials (behind the reduction's barrier they would be a
+  // second memory round trip of a launch that is nothing but round trips)
+  const int cq = c < C ? c : C - 1;
+  const float gam = gamma[cq], bet = beta[cq], mm0 = mm[cq], mv0 = mv[cq];
   double s1 = 0.0, s2 = 0.0;
   if (use_batch) reduce_tiles_2(part, n_tiles, C, c, ty, red, tx, s1, s2);
   if (ty != 0 || c >= C) return;
@@ -331,19 +335,19 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     mean = (float)m;
     var = (float)v;
     if (update) {
-      mm[c] = mm[c] * momentum + mean * (1.f - momentum);
-      mv[c] = mv[c] * momentum + var * (1.f - momentum);
+      mm[c] = mm0 * momentum + mean * (1.f - momentum);
+      mv[c] = mv0 * momentum + var * (1.f - momentum);
     }
   } else {
-    mean = mm[c];
-    var = mv[c];
+    mean = mm0;
+    var = mv0;
   }
   const float invstd = 1.0f / sqrtf(var + eps);
-  const float sc = gamma[c] * invstd;
+  const float sc = gam * invstd;
   if (mean_o) mean_o[c] = mean;
   if (invstd_o) invstd_o[c] = invstd;
   scale_o[c] = sc;
-  shift_o[c] = beta[c] - mean * sc;
+  shift_o[c] = bet - mean * sc;
 }
 
 int bn_finalize(const float* part, int n_tiles, int C, long long count, const float* gamma, const float* beta, float* mm,
@@ -367,23 +371,25 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   __shared__ double red[16][2][16];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + tx;
+  const int cq = c < C ? c : C - 1;
+  const float gam = gamma[cq], mean_c = mean[cq], invstd_c = invstd[cq];      // requested with the partials (see bn_finalize_kernel)
   double s1 = 0.0, s2 = 0.0;
   if (batch_stats) reduce_tiles_2(part, n_tiles, C, c, ty, red, tx, s1, s2);
   if (ty != 0 || c >= C) return;
-  const float a = gamma[c] * invstd[c];
+  const float a = gam * invstd_c;
   if (!batch_stats) {
     ca[c] = a; cb[c] = 0.f; cc[c] = 0.f;
     return;
   }
   // S1 = sum dy_hat ; S2 = sum dy_hat * zhat, zhat = (z - mean) * invstd
   const double S1 = s1;
-  const double S2 = (s2 - (double)mean[c] * s1) * (double)invstd[c];
+  const double S2 = (s2 - (double)mean_c * s1) * (double)invstd_c;
   if (dgamma) dgamma[c] = (float)S2;
   if (dbeta) dbeta[c] = (float)S1;
-  const double b = -(double)a * (double)invstd[c] * S2 * inv_count;
+  const double b = -(double)a * (double)invstd_c * S2 * inv_count;
   ca[c] = a;
   cb[c] = (float)b;
-  cc[c] = (float)(-(double)a * S1 * inv_count - b * (double)mean[c]);
+  cc[c] = (float)(-(double)a * S1 * inv_count - b * (double)mean_c);
 }
 
 int bn_bwd_finalize(const float* part, int n_tiles, int C, long long count, const float* gamma, const float* mean,
