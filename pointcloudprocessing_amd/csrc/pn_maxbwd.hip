@@ -45,15 +45,35 @@ __device__ __forceinline__ void maxbwd_prep_body(const PrepArgs& a, int bx) {
   const int c = bx * 32 + tx;
   float sc = 0.f, mu = 0.f, is = 0.f;
   double S1 = 0.0, S2 = 0.0;
+  // The first 128 kernel rows of the channel-major copies below do not depend on the sums: requested first, so that the launch is
+  // two memory round trips (these + the clouds' values, then the rest) instead of one per cloud group and one more for the kernel
+  const int c0 = bx * 32;
+  float v0[16];
+  if (W) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v0[i] = W[(long long)min(ty + 8 * i, K - 1) * C + min(c0 + tx, C - 1)];
+  }
   if (c < C) {
     sc = scale[c]; mu = mean[c]; is = invstd[c];
-    for (int b = ty; b < B; b += 8) {
-      const long long o = (long long)b * C + c;
-      const float up = (dg ? dg[o] : 0.f) + (dg2 ? dg2[o] : 0.f);   // the heads' gradients meet here (no separate add)
-      const float h = g[o] > 0.f ? up : 0.f;
-      hs[o] = sc * h;
-      S1 += (double)h;
-      S2 += (double)h * (double)((zstar[o] - mu) * is);
+    for (int b0 = ty; b0 < B; b0 += 32) {                 // four clouds per thread in flight (unconditional, clamped loads); same order
+      float up[4], gv[4], zv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long o = (long long)min(b0 + 8 * u, B - 1) * C + c;
+        up[u] = (dg ? dg[o] : 0.f) + (dg2 ? dg2[o] : 0.f);   // the heads' gradients meet here (no separate add)
+        gv[u] = g[o];
+        zv[u] = zstar[o];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (b0 + 8 * u < B) {
+          const long long o = (long long)(b0 + 8 * u) * C + c;
+          const float h = gv[u] > 0.f ? up[u] : 0.f;
+          hs[o] = sc * h;
+          S1 += (double)h;
+          S2 += (double)h * (double)((zv[u] - mu) * is);
+        }
+      }
     }
   }
   red[ty][0][tx] = S1;
@@ -80,13 +100,12 @@ __device__ __forceinline__ void maxbwd_prep_body(const PrepArgs& a, int bx) {
   }
   if (!W) return;
   // channel-major copies of this block's 32 kernel columns: Wt[c][k] = W[k][c], We[c][k] = -e[c] W[k][c]
-  const int c0 = bx * 32;
   for (int k0 = 0; k0 < K; k0 += 128) {           // 128 kernel rows per pass: 16 loads in flight per thread, one barrier pair
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int k = k0 + ty + 8 * i;
-      v[i] = W[(long long)min(k, K - 1) * C + min(c0 + tx, C - 1)];
+      v[i] = k0 == 0 ? v0[i] : W[(long long)min(k, K - 1) * C + min(c0 + tx, C - 1)];
     }
     __syncthreads();
 #pragma unroll

@@ -181,6 +181,17 @@ __device__ __forceinline__ void slab_reduce_block(const float* __restrict__ slab
     const float* s = slabs + (long long)grp * per_group * elems + e;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     int i = ty;
+    // four rounds (16 loads) in flight while that many remain: the reduction is a chain of memory round trips and nothing else; the
+    // four partial sums take their slabs in the same order as the one-round loop below
+    for (; i + 24 + 96 < per_group; i += 128) {
+      float x[4][4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[it][u] = s[(long long)(i + 32 * it + 8 * u) * elems];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) { a0 += x[it][0]; a1 += x[it][1]; a2 += x[it][2]; a3 += x[it][3]; }
+    }
     for (; i + 24 < per_group; i += 32) {
       const float x0 = s[(long long)i * elems], x1 = s[(long long)(i + 8) * elems];
       const float x2 = s[(long long)(i + 16) * elems], x3 = s[(long long)(i + 24) * elems];
@@ -235,7 +246,19 @@ __global__ __launch_bounds__(256) void slab_reduce_q_kernel(const float* __restr
   if (k >= K) return;
   const int lane = threadIdx.x & 63;
   float s = 0.f;
-  for (int c = lane; c < C; c += 64) s = fmaf(f[c], w[(long long)k * C + c], s);
+  // sixteen channel groups (32 loads) in flight per lane: at C = 1024 ONE memory round trip instead of sixteen; same order of the sum
+  for (int c0 = lane; c0 < C; c0 += 64 * 16) {
+    float fv[16], wv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int c = min(c0 + 64 * u, C - 1);
+      fv[u] = f[c];
+      wv[u] = w[(long long)k * C + c];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (c0 + 64 * u < C) s = fmaf(fv[u], wv[u], s);
+  }
   s = wave_sum(s);
   if (lane == 0) q[k] = s;
 }
