@@ -163,7 +163,8 @@ def main():
         return model.workspace_tensor(name, B, N, True, dtype)
     REPS = 20
     calls = []
-    colacc = torch.zeros(B, K_, device=model.params_flat.device, dtype=torch.int64)      # the launches' column-sum accumulators (values unused here)
+    # the launches' column-sum accumulators (values unused here): NT * K words per cloud, NT = 2 in the split-operand mode (pointnet_hip.h)
+    colacc = torch.zeros(B, (2 if args.precision == "bf16x3" else 1) * K_, device=model.params_flat.device, dtype=torch.int64)
     # In the step a launch reads rows another kernel wrote a moment earlier: they come from the Infinity Cache, not from the reading
     # XCD's own L2.  A rotation over only the three layers' inputs (3 x 8 MB at C2, an eighth of each per XCD) would sit in the 4 MB L2s
     # and read ~1.5 us fast (measured: 11.6 us against ~13.1 us in the step).  So every layer's input is cloned until the rotation's

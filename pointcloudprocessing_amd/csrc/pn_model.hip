@@ -575,8 +575,11 @@ struct Run {
       // + the bf16 copies of the other per-point kernels for the row GEMMs (bf16 mode)
       WCopyDesc wc[PN_WCOPY_MAX];
       int nwc = 0;
+      bool dropped = false;      // a layer that does not fit the launch's tables must fail the call, not run on stale copies / coefficients
       auto add_wc = [&](const CL& l, const float* Wk) {
-        if (l.w16 && nwc < PN_WCOPY_MAX) wc[nwc++] = WCopyDesc{Wk, l.w16, l.wt16, l.K, l.C};
+        if (!l.w16) return;
+        if (nwc < PN_WCOPY_MAX) wc[nwc++] = WCopyDesc{Wk, l.w16, l.wt16, l.K, l.C};
+        else dropped = true;
       };
       if (!d.vanilla) {
         add_wc(w.iT.c2, p(L.iT.c2.kernel));
@@ -589,14 +592,20 @@ struct Run {
       FrozenBnDesc fz[PN_FROZEN_MAX];
       int nfz = 0;
       auto add_fz = [&](const CL& l, const LRef& r) {
-        if (!bn_batch(r.block) && nfz < PN_FROZEN_MAX)
-          fz[nfz++] = FrozenBnDesc{p(r.gamma), p(r.beta), p(r.mm), p(r.mv), l.mean, l.invstd, l.scale, l.shift, r.cout};
+        if (bn_batch(r.block)) return;
+        if (nfz < PN_FROZEN_MAX) fz[nfz++] = FrozenBnDesc{p(r.gamma), p(r.beta), p(r.mm), p(r.mv), l.mean, l.invstd, l.scale, l.shift, r.cout};
+        else dropped = true;
       };
       if (!d.vanilla) {
         add_fz(w.iT.c1, L.iT.c1); add_fz(w.iT.c2, L.iT.c2); add_fz(w.fT.c1, L.fT.c1); add_fz(w.fT.c2, L.fT.c2);
       }
       add_fz(w.m11, L.m11); add_fz(w.m12, L.m12); add_fz(w.m21, L.m21); add_fz(w.m22, L.m22);
       add_fz(w.s1, L.s1); add_fz(w.s2, L.s2); add_fz(w.s3, L.s3); add_fz(w.s4, L.s4);
+      if (dropped) {
+        set_error("pn_model_forward: more per-point layers than fwd_prologue's tables hold (PN_WCOPY_MAX %d, PN_FROZEN_MAX %d)", PN_WCOPY_MAX,
+                  PN_FROZEN_MAX);
+        return PN_ERR_INVALID_ARGUMENT;
+      }
       const bool zg = training && G && io.zero_grads_in_forward;
       const bool dm = training && io.dropout_step && io.keep1 && io.keep2 && d.dropout_rate > 0.f;
       PN_TRY(fwd_prologue(io.pc, B, N, w.pcn, w.cent, w.scl, ws, sgs, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS + 3 * B * 512, zg ? G : nullptr,

@@ -60,6 +60,7 @@ class TrainStep:
         self._mask_seed = int(torch.randint(0, 2**62, (1,)).item()) ^ (rank_salt() << 20)   # per process / rank
         self._mask_step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.mode = "eager"
+        self.capture_error = None     # set when hipGraph capture failed and the step fell back to eager launches (the trainer logs it)
         self._g1 = self._g1b = self._g2 = None
         # A host-memory model has no streams or graphs: only the step SEQUENCE runs (forward/backward phases, the bucketed
         # all-reduce schedule, the optimizer).  The product never builds one -- PointNet refuses to compute without a HIP device --
@@ -68,8 +69,12 @@ class TrainStep:
         self.stream = self._capture_stream = self.aux_stream = None
         if self.on_gpu:
             self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
-            # capture needs a created stream; a caller-supplied null stream only replays
-            self._capture_stream = self.stream if self.stream.cuda_stream != 0 else torch.cuda.Stream(device=dev)
+            # Capture runs on a stream of its own that never carries anything else (a graph replays on any stream).  RCCL's watchdog
+            # thread keeps calling hipEventQuery on the end events of the warm-up steps' collectives until it retires them; a
+            # synchronous collective records its end event on the stream it was issued on (self.stream), and HIP refuses a query of an
+            # event whose stream is capturing (hipErrorCapturedEvent -> the watchdog aborts the process).  No collective is ever issued
+            # on the capture stream, so no such event exists on it.
+            self._capture_stream = torch.cuda.Stream(device=dev)
             # optional second stream for the parameter-gradient kernels of the backward pass (pn_model_io.aux_stream).
             # Bit-identical results; measured at B=32, N=1024 it does not pay on ROCm 7.2 (graph cross-branch edges cost more
             # than the overlap wins: 1.52-1.68 ms vs 1.54 ms/step), so it is off by default.
@@ -160,14 +165,6 @@ class TrainStep:
         # (c10::DistBackendError "operation not permitted when stream is capturing" -- seen 2 times in 14 data-parallel rehearsals).
         try:
             torch.cuda.synchronize()
-            if self.reduce:
-                # The collectives of the eager warm-up steps are complete (synchronize above), but RCCL's watchdog thread retires their
-                # Work objects on its own clock (a sweep every 100 ms) and, until it has, keeps calling hipEventQuery on their end
-                # events.  An end event recorded on THIS stream (synchronous collectives run on the current stream) is refused by HIP
-                # with hipErrorCapturedEvent once the stream is capturing -- even though the record itself preceded the capture --
-                # and the watchdog aborts the process (seen once in ~10 runs of the world-size-1 RCCL test).  Let it sweep first.
-                import time
-                time.sleep(0.5)
             g1 = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g1, stream=self._capture_stream, capture_error_mode="thread_local"):
                 self._fwd_bwd(1 if self.split else 0)
@@ -185,7 +182,8 @@ class TrainStep:
             self._g1, self._g1b, self._g2, self.mode = g1, g1b, g2, "hipgraph"
         except Exception as e:                                  # capture unsupported: stay eager (a speed matter only)
             import sys
-            print(f"# hipGraph capture failed ({type(e).__name__}: {e}); running the step eagerly", file=sys.stderr)
+            self.capture_error = f"{type(e).__name__}: {e}"
+            print(f"# hipGraph capture failed ({self.capture_error}); running the step eagerly", file=sys.stderr)
             self._g1 = self._g1b = self._g2 = None
             self.mode = "eager"
 

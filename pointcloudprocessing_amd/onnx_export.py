@@ -5,7 +5,8 @@ opset=13)`` (pointnet_train.py:238-248).  ``onnx`` / ``tf2onnx`` are not importa
 ``onnx.proto`` is small: the messages are written field by field with the same wire helpers the tf.train.Example writer uses
 (pointcloud/PointCloudSet.py).  Field numbers (onnx.proto3, IR version 7 = opset 13):
 
-    ModelProto      ir_version 1, producer_name 2, producer_version 3, graph 7, opset_import 8 {domain 1, version 2}
+    ModelProto      ir_version 1, producer_name 2, producer_version 3, graph 7, opset_import 8 {domain 1, version 2},
+                    metadata_props 14 {key 1, value 2}  (the model's constructor arguments, so a file restores as a checkpoint)
     GraphProto      node 1, name 2, initializer 5, input 11, output 12
     NodeProto       input 1, output 2, name 3, op_type 4, attribute 5
     AttributeProto  name 1, f 2, i 3, ints 8, type 20 (FLOAT 1, INT 2, INTS 7)
@@ -27,6 +28,7 @@ with an independent NumPy interpreter against the CPU oracle.
 """
 from __future__ import annotations
 
+import json
 from typing import Dict, List, Sequence
 
 import numpy as np
@@ -97,7 +99,7 @@ class _Graph:
         return outs[0] if n_out == 1 else outs
 
 
-def build_model_bytes(weights: Dict[str, np.ndarray], input_width: int, vanilla: bool = False) -> bytes:
+def build_model_bytes(weights: Dict[str, np.ndarray], input_width: int, vanilla: bool = False, config: dict = None) -> bytes:
     """`weights`: canonical name -> array ('<block>[.<sub>].kernel|bn.gamma|bn.beta|bn.moving_mean|bn.moving_var|bias', '<tnet>.w', '.b')."""
     W = {k: np.asarray(v, dtype=np.float32) for k, v in weights.items()}
     g = _Graph()
@@ -210,13 +212,17 @@ def build_model_bytes(weights: Dict[str, np.ndarray], input_width: int, vanilla:
     graph += _ld(12, value_info(names[0], ["unk__batch", ccls])) + _ld(12, value_info(names[1], ["unk__batch", N, cseg]))
     graph += _ld(12, value_info(names[2], ["unk__batch", 3, 3]))
     model = _vi(1, 7) + _str(2, "pointcloudprocessing_amd") + _str(3, "1") + _ld(7, graph) + _ld(8, _str(1, "") + _vi(2, 13))
+    # PointNet.get_config() as metadata_props: what the weights alone do not say (dropout rate, seed, regularisers, ...)
+    for k, v in sorted((config or {}).items()):
+        model += _ld(14, _str(1, "pointnet." + str(k)) + _str(2, json.dumps(v)))
     return model
 
 
-def export_onnx(weights: Dict[str, np.ndarray], input_width: int, path: str, vanilla: bool = False) -> None:
-    """the counterpart of ``onnx.save(tf2onnx.convert.from_keras(...), path)`` (pointnet_train.py:238-248)"""
+def export_onnx(weights: Dict[str, np.ndarray], input_width: int, path: str, vanilla: bool = False, config: dict = None) -> None:
+    """the counterpart of ``onnx.save(tf2onnx.convert.from_keras(...), path)`` (pointnet_train.py:238-248); ``config`` =
+    PointNet.get_config(), kept in the file's metadata_props"""
     with open(path, "wb") as f:
-        f.write(build_model_bytes(weights, input_width, vanilla))
+        f.write(build_model_bytes(weights, input_width, vanilla, config))
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -255,10 +261,13 @@ def _parse_attr(buf):
 
 def parse_model(data: bytes) -> dict:
     """{'ir_version', 'opset', 'nodes': [{'op','name','inputs','outputs','attrs'}], 'initializers': {name: array}, 'inputs', 'outputs'}"""
-    out = {"nodes": [], "initializers": {}, "inputs": [], "outputs": []}
+    out = {"nodes": [], "initializers": {}, "inputs": [], "outputs": [], "metadata": {}}
     for f, wt, v in _fields(memoryview(data)):
         if f == 1:
             out["ir_version"] = int(v)
+        elif f == 14:
+            kv = {f2: bytes(v2).decode() for f2, _, v2 in _fields(v)}
+            out["metadata"][kv.get(1, "")] = kv.get(2, "")
         elif f == 8:
             for f2, _, v2 in _fields(v):
                 if f2 == 2:
@@ -311,3 +320,10 @@ def read_onnx_weights(path: str) -> Dict[str, np.ndarray]:
             arr = arr.reshape(arr.shape[0], arr.shape[1]).T
         w[name] = np.array(arr, dtype=np.float32)
     return w
+
+
+def read_onnx_config(path: str) -> dict:
+    """the PointNet constructor arguments export_onnx stored in the file's metadata_props ({} for a file without them)"""
+    with open(path, "rb") as f:
+        m = parse_model(f.read())
+    return {k[len("pointnet."):]: json.loads(v) for k, v in m["metadata"].items() if k.startswith("pointnet.")}

@@ -93,20 +93,25 @@ class HipEngine:
         if not torch.cuda.is_available():
             raise RuntimeError("No HIP device available: the PointNet hot path has no CPU compute path")
         self.torch, self.dist = torch, dist
+        self._log = log
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.device = torch.device("cuda", torch.cuda.current_device())
         p = cfg['params']
         if checkpoint and checkpoint.endswith(".onnx"):
             # an exported inference graph (onnx_export.py) keeps every raw parameter under its canonical name
-            from .onnx_export import read_onnx_weights
+            from .onnx_export import read_onnx_config, read_onnx_weights
             w = read_onnx_weights(checkpoint)
-            self.model = PN.PointNet(classification_output_width=int(w["mlp_cls_3.kernel"].shape[1]),
-                                     segmentation_output_width=int(w["mlp_seg_5.kernel"].shape[1]), dropout_rate=0.3,
-                                     random_seed=p['random_seed'], debugging=p.get('debugging', False),
-                                     vanilla="input_transform.w" not in w,
-                                     regularize_input_transform=p.get('regularize_input_transform', False),
-                                     regularize_feature_transform=p.get('regularize_feature_transform', False), precision=precision)
+            # the model's own constructor arguments travel in the file (metadata_props), as payload['config'] does in a .pt checkpoint;
+            # a file without them (written by another exporter) falls back to the training config and the reference's 0.3
+            mc = dict(classification_output_width=int(w["mlp_cls_3.kernel"].shape[1]),
+                      segmentation_output_width=int(w["mlp_seg_5.kernel"].shape[1]), dropout_rate=0.3,
+                      random_seed=p['random_seed'], debugging=p.get('debugging', False), vanilla="input_transform.w" not in w,
+                      regularize_input_transform=p.get('regularize_input_transform', False),
+                      regularize_feature_transform=p.get('regularize_feature_transform', False))
+            mc.update({k: v for k, v in read_onnx_config(checkpoint).items() if k in mc})
+            mc["precision"] = precision
+            self.model = PN.PointNet(**mc)
             self.model.set_weights({k: torch.from_numpy(v) for k, v in w.items()})
         elif checkpoint:
             payload = torch.load(checkpoint, map_location="cpu", weights_only=True)
@@ -141,6 +146,10 @@ class HipEngine:
         self._steps = {}          # (B, N) -> engine.TrainStep (hipGraph replay of the whole step)
         self.stream = torch.cuda.Stream(device=self.device)   # every launch of this engine; see engine.TrainStep
 
+    def model_config(self) -> dict:
+        """the model's constructor arguments (what an exported .onnx keeps in its metadata_props); the arithmetic mode is the loader's choice"""
+        return {k: v for k, v in self.model.get_config().items() if k != "precision"}
+
     def stream_context(self):
         return self.torch.cuda.stream(self.stream)
 
@@ -165,7 +174,12 @@ class HipEngine:
         if key not in self._steps:
             self._steps[key] = TrainStep(self.model, self.opt, self.B, self.N, self.loss_weights, stream=self.stream)
         # forward + fused losses + backward (graph), one RCCL all-reduce of the flat 16.8 MB gradient buffer, Adam (graph)
-        self._steps[key](x.to(self.device), yc, ys, yr)
+        ts = self._steps[key]
+        ts(x.to(self.device), yc, ys, yr)
+        if ts.capture_error and not getattr(ts, "_fallback_logged", False):
+            # the step could not be captured into a hipGraph and is launched kernel by kernel: correct, but several times slower
+            ts._fallback_logged = True
+            self._log.warning(f"hipGraph capture of the training step failed ({ts.capture_error}); steps run eagerly (slower, same results)")
         self.acc += self.model.scalars
         self.n_steps += 1
 
@@ -411,7 +425,8 @@ class TrainProfile:
                         from .onnx_export import export_onnx
                         onnx_path = f"{self._model_path}{pd['path']}{self._name}_{prof}.onnx"
                         export_onnx({k: np.asarray(v, dtype=np.float32) for k, v in best_weights.items()}, self._input_width, onnx_path,
-                                    vanilla=not any(k.startswith("input_transform.") for k in best_weights))
+                                    vanilla=not any(k.startswith("input_transform.") for k in best_weights),
+                                    config=engine.model_config() if hasattr(engine, "model_config") else None)
                         self._log.info(f"ONNX model (opset 13) written to {onnx_path}")
                     except Exception as e:            # the reference logs and carries on as well (:246-248)
                         self._log.info(f"ONNX export failed: {e}")

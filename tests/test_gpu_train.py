@@ -42,6 +42,42 @@ def test_trainer_at_baseline_config_c1_size(dev, tmp_path):
     assert ck["config"]["precision"] == "bf16" and tuple(ck["weights"]["mlp_2_3.kernel"].shape) == (128, 1024)
 
 
+def test_gpu_trained_model_exports_to_onnx_and_matches_hip_inference(dev, tmp_path):
+    """N3 on the GPU: 3 training steps per epoch through the trainer entry point (pointnet_train.py:238-248 writes <name>_<prof>.onnx
+    from the restored best weights), then the written file -- parsed and evaluated by the independent NumPy interpreter of
+    tests/test_cpu_onnx.py -- against HIP inference (PointNet.__call__, training=False) on the very weights the file restores:
+    probabilities within 1e-4 (bf16x3 inference vs the file evaluated in fp64), class / part indices identical where the margin allows.
+    The file also restores as a checkpoint with the model's own constructor arguments (metadata_props)."""
+    from pointcloudprocessing_amd import onnx_export as X
+    from pointcloudprocessing_amd import pointnet_train as T
+    from pointcloudprocessing_amd.pointnet.PointNet import PointNet
+    from test_cpu_onnx import _run_onnx
+    cfg, d = write_config(tmp_path, vanilla=False, epochs=1, input_width=256, batch_size=4, n_frames=24)
+    assert T.train_pointnet([cfg], max_steps_per_epoch=3)
+    path = d + "models/unit/final/unit_final.onnx"
+    model = X.parse_model(open(path, "rb").read())
+    w = X.read_onnx_weights(path)
+    conf = X.read_onnx_config(path)
+    assert conf["dropout_rate"] == 0.3 and conf["vanilla"] is False and conf["classification_output_width"] == 23
+    ck = torch.load(d + "models/unit/final/unit_final.pt", weights_only=True)
+    for k, v in ck["weights"].items():                            # the file holds the trained weights bit for bit
+        assert np.array_equal(w[k], v.numpy()), k
+    assert not np.array_equal(w["mlp_2_3.kernel"], PointNet(23, 12, 0.3, ck["config"]["random_seed"], device="cpu").named_weights()["mlp_2_3.kernel"].numpy())
+    m = PointNet(**{**conf, "precision": "bf16x3", "device": dev})
+    m.set_weights({k: torch.from_numpy(v) for k, v in w.items()})
+    g = torch.Generator().manual_seed(11)
+    pc = (torch.rand(3, 256, 3, generator=g) * 40 - 20).float()
+    cls, seg, R = m(pc.to(dev), training=False)
+    out = _run_onnx(model, {"pointnet_input": pc.numpy().astype(np.float64)})
+    e = [float(np.abs(cls.cpu().double().numpy() - out[0]).max()), float(np.abs(seg.cpu().double().numpy() - out[1]).max()),
+         float(np.abs(R.cpu().double().numpy() - out[2]).max())]
+    assert max(e) < 1e-4, e
+    assert np.array_equal(cls.cpu().numpy().argmax(-1), out[0].argmax(-1))
+    top2 = np.sort(out[1], -1)
+    safe = (top2[..., -1] - top2[..., -2]) > 1e-3
+    assert np.array_equal(seg.cpu().numpy().argmax(-1)[safe], out[1].argmax(-1)[safe])
+
+
 def test_native_train_step_learns_and_graph_matches_eager(dev):
     """a few hundred Adam steps on one fixed batch must drive the classification loss down; the hipGraph replay of the
     step must produce exactly the same weights as eager launches (same kernels, same order)."""
@@ -69,13 +105,36 @@ def test_native_train_step_learns_and_graph_matches_eager(dev):
         for i in range(62):
             ts(pc, y_cls, y_seg, se3)
             losses.append(float(m.scalars[0]) / B)
-        # (the best of the last steps: at this learning rate the fixed-batch loss spikes now and then on its way down)
-        assert min(losses[-8:]) < 0.5 * losses[0], (losses[0], losses[-8:])
+        # The fixed 8-cloud batch is fitted to a loss of ~0.005 within 40 steps and then, at this learning rate, spikes now and then
+        # (batch-statistics BatchNormalization over 8 rows): the fp32 CPU oracle's own trajectory on this problem does the same
+        # (O.train_step, lr 1e-3: 3.38 -> 0.005 with excursions to 0.97 among its last 30 steps).  So "it learns" is asserted on the
+        # best and the median of the tail, each far below the round-2 form (last < 0.5 x first) in what it demands of the typical step.
+        tail = sorted(losses[-16:])
+        assert min(losses[-8:]) < 0.1 * losses[0] and tail[len(tail) // 2] < 0.25 * losses[0], (losses[0], losses[-16:])
         finals.append(m.params_flat.data.clone())
         assert int(opt.iterations) == 62
         assert ts.mode == ("hipgraph" if use_graph else "eager")
     for f in finals[1:]:
         assert torch.equal(finals[0], f)
+    # the mode bench.py and the trainer default to on the GPU box ('bf16': bf16 MFMA operands, bf16 layer-boundary tensors) against the
+    # fp32-grade mode from the same start: the first steps, before the trajectories decorrelate, stay within a band, and it learns too
+    traj = {}
+    for prec in ("bf16x3", "bf16"):
+        m = PointNet(23, 12, 0.0, 42, precision=prec, device=dev)
+        m.params_flat.data.copy_(w0)
+        opt = KerasAdam(m.params_flat.data, 1e-3, 7000, 0.7)
+        ts = TrainStep(m, opt, B, N, (1.0, 1.0, 1.0))
+        traj[prec] = []
+        for i in range(62):
+            ts(pc, y_cls, y_seg, se3)
+            traj[prec].append(float(m.scalars[0]) / B)
+    from parity_harness import report
+    report("fixed-batch loss, first 12 steps  bf16x3: " + " ".join(f"{v:.3f}" for v in traj["bf16x3"][:12]))
+    report("fixed-batch loss, first 12 steps  bf16:   " + " ".join(f"{v:.3f}" for v in traj["bf16"][:12]))
+    for i in range(10):
+        assert abs(traj["bf16"][i] - traj["bf16x3"][i]) < 0.1 * traj["bf16x3"][0], (i, traj["bf16"][:12], traj["bf16x3"][:12])
+    tail = sorted(traj["bf16"][-16:])
+    assert min(traj["bf16"][-8:]) < 0.1 * traj["bf16"][0] and tail[len(tail) // 2] < 0.25 * traj["bf16"][0], traj["bf16"][-16:]
 
 
 def test_interleaved_models_graph_replay_is_exact(dev):
