@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PN_ABI_VERSION 5
+#define PN_ABI_VERSION 6
 
 typedef enum {
   PN_OK = 0,
@@ -146,6 +146,22 @@ int pn_panel_finalize(const float* pmax, const int32_t* pblock, const float* sum
                       int prec, int B, int N, int K, int C, const float* gamma, const float* beta, float* moving_mean, float* moving_var,
                       float momentum, float eps, int use_batch_stats, int update_moving, float* mean, float* invstd, float* scale, float* shift,
                       float* g, float* zstar, int32_t* arg_block, pn_stream stream);
+/* --- inference: a whole max-pooled chain in ONE launch -- ConvLayer(3 | 64 -> 64) -> ConvLayer(64 -> 128) -> ConvLayer(128 -> 1024) ->
+ * tf.reduce_max (PointNet.py:236-248 mlp_2; :421-429 the two T-Nets), every BatchNormalization on its moving statistics (scale / shift
+ * given per layer).  The two narrow layers' outputs stay in LDS; pmax / pblock are what the three launches pn_conv_fwd (or pn_conv3_fwd),
+ * pn_conv_fwd, pn_conv_fwd_max_panel leave in the bf16-storage mode (PN_PREC_BF16 | PN_STORE_BF16), bit for bit: feed them to
+ * pn_panel_finalize with use_batch_stats = 0.  Exactly one input: x = a 64-channel lazy operand stored as bf16 with w1t = the first
+ * layer's kernel as pn_weights_copy16 transposes it, or xyz = the normalised cloud (B*N, 3) with w1 = the first layer's (3, 64) kernel.
+ * w2t: the second layer's (64, 128) kernel through pn_weights_copy16 (transposed copy); wf_hi: the third layer's through
+ * pn_weights_prep (with the sign of its gamma). */
+int pn_chain_fwd_max(const pn_operand* x, const float* xyz, const float* w1, const void* w1t, const float* scale1, const float* shift1,
+                     const void* w2t, const float* scale2, const float* shift2, const void* wf_hi, int B, int N, float* pmax,
+                     int32_t* pblock, pn_stream stream);
+/* bf16 copies (round to nearest even) of a Keras kernel (K, C), K and C multiples of 8, as the model plan's first launch makes them for
+ * its row GEMMs: w16[k * C + c] = bf16(w[k][c]) (the kernel as it is) and wt16[c * K + k] = bf16(w[k][c]) (transposed, k contiguous:
+ * what the forward row GEMMs and pn_chain_fwd_max stage); both required */
+int pn_weights_copy16(const float* w, int K, int C, void* w16, void* wt16, pn_stream stream);
+
 /* the row of the maximum itself (needed by the backward pass only, where the model plan resolves it inside its scatter kernel):
  * arg[b][c] = the row of cloud b, inside block arg_block[b][c], with the largest s_c * z -- the 32 candidates re-evaluated in fp32 from
  * the same bf16-rounded operands, lowest row on ties (exact ties = duplicated points, as the reference's padding produces). */

@@ -17,7 +17,7 @@ PN_PREC_BF16 = 1
 PN_PREC_BF16X3 = 3
 PN_STORE_BF16 = 0x100      # or-ed into prec: the per-point layer-boundary tensors are stored as bf16
 PN_IO_KEEP_ACTIVATIONS = 1  # pn_model_io.flags: no vertical fusion of a frozen segmentation head (its activations stay inspectable)
-ABI_VERSION = 5            # PN_ABI_VERSION of include/pointnet_hip.h this binding was written against
+ABI_VERSION = 6            # PN_ABI_VERSION of include/pointnet_hip.h this binding was written against
 PN_NUM_BLOCKS = 15
 # "bf16": bf16 MFMA operands AND bf16 storage of the layer-boundary tensors (half the HBM traffic of a step);
 # "bf16_f32act": bf16 operands, fp32 storage; "bf16x3": split operands (fp32-grade products), fp32 storage
@@ -91,6 +91,8 @@ SIGNATURES = {
     "pn_panel_slots_per_cloud": (_I, [_I, _I]),
     "pn_conv_fwd_max_panel": (_I, [_OP, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P]),
     "pn_panel_finalize": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _F, _F, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "pn_chain_fwd_max": (_I, [_OP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "pn_weights_copy16": (_I, [_P, _I, _I, _P, _P, _P]),
     "pn_max_resolve": (_I, [_OP, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "pn_conv_bwd_data": (_I, [_OP, _P, _I64, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "pn_conv_wgrad": (_I, [_OP, _OP, _I, _I, _I, _I, _I, _P, _I, _P]),

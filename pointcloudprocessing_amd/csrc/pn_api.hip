@@ -53,6 +53,12 @@ int pn_panel_finalize(const float* pmax, const int32_t* pblock, const float* sum
   return panel_finalize(pmax, pblock, sumsq, reinterpret_cast<const long long*>(colacc), wf_hi, wf_lo, prec, B, N, K, C, gamma, beta, moving_mean, moving_var, momentum, eps,
                         use_batch_stats, update_moving, mean, invstd, scale, shift, g, zstar, arg_block, S(stream));
 }
+int pn_chain_fwd_max(const pn_operand* x, const float* xyz, const float* w1, const void* w1t, const float* scale1, const float* shift1,
+                     const void* w2t, const float* scale2, const float* shift2, const void* wf_hi, int B, int N, float* pmax, int32_t* pblock,
+                     pn_stream stream) {
+  return chain_fwd_max(x, xyz, w1, w1t, scale1, shift1, w2t, scale2, shift2, wf_hi, B, N, pmax, pblock, S(stream));
+}
+int pn_weights_copy16(const float* w, int K, int C, void* w16, void* wt16, pn_stream stream) { return weights_copy16(w, K, C, w16, wt16, S(stream)); }
 int pn_max_resolve(const pn_operand* x, const void* wf_hi, const void* wf_lo, const int32_t* arg_block, int B, int N, int K, int C,
                    int32_t* arg, int prec, pn_stream stream) {
   return max_resolve(x, wf_hi, wf_lo, prec, arg_block, B, N, K, C, arg, S(stream));

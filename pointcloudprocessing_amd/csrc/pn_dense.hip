@@ -53,11 +53,22 @@ struct DenseArgs {
   float *bt_dz, *bt_dgamma, *bt_dbeta, *bt_dbias;
 };
 
-// One 128-k step of a block costs ~4 us (LDS broadcast reads + 512 FMAs per thread), the in-launch meeting of the K splits ~5 us
-// (measured: K=1024 unsplit 35 us, split 8 ways 12.5 us; K=256, C=9 unsplit 11.6 us, split in two 10.4 us): one step per block
-// up to 8 splits, pipelined steps beyond that.
+// How the contraction is split over workgroups.  A launch of these layers is a chain of memory round trips; the in-launch meeting of
+// the K splits adds three of them (partial tiles out, ticket, partial tiles back in).  Measured (round 3, C2 step, hipGraph):
+//   128 k per split (eight splits of K = 1024)                         0.788 ms/step
+//   one workgroup per 32 columns walks ALL of K <= 1024, every operand load of a wave requested up front (no partial tiles, no
+//   ticket; PN_DENSE_KSPLIT=1024)                                     0.836 ms/step
+// -- the meeting costs less than the serial work it saves: one workgroup then converts 8 x the operands to bf16 hi + lo (3 vector
+// instructions per element, 768 per SIMD at K = 1024) behind 8 x the bytes through one CU's load path.  So the splits stay; what the
+// rewrite kept is the load ring below (16-byte loads, every load of a round in flight before the first conversion) and the mask /
+// bias loads that no longer sit in front of the operand loads: 0.823 -> 0.788 ms/step.  PN_DENSE_KSPLIT=<k per split> for A/B runs.
+static inline int dl_ksplit_env() {
+  static const int v = (getenv("PN_DENSE_KSPLIT") && atoi(getenv("PN_DENSE_KSPLIT")) >= 1) ? atoi(getenv("PN_DENSE_KSPLIT")) : 0;
+  return v;
+}
 static inline int dl_nsplit(int K) {
-  static const int per_split = (getenv("PN_DENSE_KSPLIT") && atoi(getenv("PN_DENSE_KSPLIT")) >= 1) ? atoi(getenv("PN_DENSE_KSPLIT")) : DL_KSTEP;
+  const int env = dl_ksplit_env();
+  const int per_split = env ? env : DL_KSTEP;
   const int s = cdiv(K, per_split);
   return s < 1 ? 1 : (s > DL_MAX_SPLITS ? DL_MAX_SPLITS : s);
 }
@@ -65,7 +76,9 @@ static inline int dl_split_len(int K) { return cdiv(cdiv(K, dl_nsplit(K)), DL_KS
 
 // Two layers of one grid shape (same K and C) may share a launch: blockIdx.z picks the job (pn_model.hip: the classification head's
 // first layer and the global-feature half of seg_l1 both consume the pooled feature vector).
-template <bool TRANS>
+// DEPTH: 64-k steps a wave keeps in flight (2: split form, one step ahead of the one being multiplied; 4 / 8: the whole-K forms);
+// VEC: x rows (and, TRANS, kernel rows) are read as 16-byte loads (ldx, ldw % 4 == 0, 16-byte aligned bases, K % 16 == 0)
+template <bool TRANS, int DEPTH, bool VEC>
 __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a0, const DenseArgs a1) {
   const DenseArgs& a = blockIdx.z ? a1 : a0;
   // one LDS object (a second one beside a staging array can cost a full vmcnt drain per step)
@@ -86,22 +99,23 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a0, co
   // ... and so are the layer's own BatchNormalization parameters and dropout mask, which the last arriver needs only after its
   // reductions (there they would be one more memory round trip at the tail of the launch)
   float pf_g = 1.f, pf_b = 0.f, pf_mm = 0.f, pf_mv = 1.f;
-  unsigned pf_keep = 0xfu;
+  const float pf_bias = a.bias ? a.bias[jc] : 0.f;        // (at the tail it would be one more dependent round trip)
+  // (the mask bytes stay as loaded until their use at the end of the kernel: combined into a bit mask HERE they would be waited for
+  //  here -- a whole memory round trip in front of the operand loads)
+  unsigned char pf_kb[DL_ROWS / DL_SLICES] = {1, 1, 1, 1};
   if (a.bn_mode) { pf_g = a.gamma[jc]; pf_b = a.beta[jc]; pf_mm = a.mm[jc]; pf_mv = a.mv[jc]; }
   if (a.keep && a.a_out && a.R <= DL_ROWS) {
-    pf_keep = 0u;
 #pragma unroll
-    for (int i = 0; i < DL_ROWS / DL_SLICES; ++i) pf_keep |= (a.keep[(long long)min(s + DL_SLICES * i, a.R - 1) * a.C + jc] ? 1u : 0u) << i;
+    for (int i = 0; i < DL_ROWS / DL_SLICES; ++i) pf_kb[i] = a.keep[(long long)min(s + DL_SLICES * i, a.R - 1) * a.C + jc];
   }
   float bt_zz[DL_ROWS / DL_SLICES], bt_mu = 0.f, bt_is = 1.f, bt_g = 1.f, bt_b = 0.f;
-  unsigned bt_kp = 0xfu;
+  unsigned char bt_kb[DL_ROWS / DL_SLICES] = {1, 1, 1, 1};
   if (TRANS && a.bt_dz) {
 #pragma unroll
     for (int i = 0; i < DL_ROWS / DL_SLICES; ++i) bt_zz[i] = a.bt_z[(long long)min(s + DL_SLICES * i, a.R - 1) * a.C + jc];     // unconditional, clamped
     if (a.bt_keep) {
-      bt_kp = 0u;
 #pragma unroll
-      for (int i = 0; i < DL_ROWS / DL_SLICES; ++i) bt_kp |= (a.bt_keep[(long long)min(s + DL_SLICES * i, a.R - 1) * a.C + jc] ? 1u : 0u) << i;
+      for (int i = 0; i < DL_ROWS / DL_SLICES; ++i) bt_kb[i] = a.bt_keep[(long long)min(s + DL_SLICES * i, a.R - 1) * a.C + jc];
     }
     if (a.bt_mode) { bt_mu = a.bt_mean[jc]; bt_is = a.bt_invstd[jc]; bt_g = a.bt_gamma[jc]; bt_b = a.bt_beta[jc]; }
   }
@@ -123,34 +137,63 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a0, co
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
     const int xr = rc + (lr < nr ? lr : nr - 1);
-    float xa[8], wb[8];
-    auto issue = [&](int k0) {                              // k0: first k of this wave's step
+    // Operand loads of this wave's 64-k steps: DEPTH steps are in flight at any time (slots of a register ring, statically indexed).
+    // Addresses are clamped and unconditional; what lies beyond the k range or the row / column count is zeroed at the conversion.
+    float xa[DEPTH][8], wb[DEPTH][8];
+    auto issue = [&](float (&xv)[8], float (&wv_)[8], int k0) {      // k0: first k of this wave's step
+      const int kk = k0 + 8 * lg;
+      if constexpr (VEC) {
+        const int kc = min(kk, kend - 8);                           // (K % 16 == 0: a step is inside the range or wholly beyond it)
+        const float4 t0 = *reinterpret_cast<const float4*>(a.x + (long long)xr * a.ldx + kc);
+        const float4 t1 = *reinterpret_cast<const float4*>(a.x + (long long)xr * a.ldx + kc + 4);
+        xv[0] = t0.x; xv[1] = t0.y; xv[2] = t0.z; xv[3] = t0.w; xv[4] = t1.x; xv[5] = t1.y; xv[6] = t1.z; xv[7] = t1.w;
+        if constexpr (TRANS) {
+          const float4 u0 = *reinterpret_cast<const float4*>(a.w + (long long)jwc * a.ldw + kc);
+          const float4 u1 = *reinterpret_cast<const float4*>(a.w + (long long)jwc * a.ldw + kc + 4);
+          wv_[0] = u0.x; wv_[1] = u0.y; wv_[2] = u0.z; wv_[3] = u0.w; wv_[4] = u1.x; wv_[5] = u1.y; wv_[6] = u1.z; wv_[7] = u1.w;
+        } else {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int k = k0 + 8 * lg + e;
-        const long long kc = k < kend ? k : kend - 1;
-        xa[e] = a.x[(long long)xr * a.ldx + kc];
-        wb[e] = TRANS ? a.w[(long long)jwc * a.ldw + kc] : a.w[kc * a.ldw + jwc];
+          for (int e = 0; e < 8; ++e) wv_[e] = a.w[(long long)(kc + e) * a.ldw + jwc];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int k = kk + e;
+          const long long kc = k < kend ? k : kend - 1;
+          xv[e] = a.x[(long long)xr * a.ldx + kc];
+          wv_[e] = TRANS ? a.w[(long long)jwc * a.ldw + kc] : a.w[kc * a.ldw + jwc];
+        }
       }
     };
-    int k0 = kbeg + 16 * wv;
-    if (k0 < kend) issue(k0);
-    for (; k0 < kend; k0 += 64) {
-      bf16x8 ah, al, bh, bl;
+    const int kw = kbeg + 16 * wv;                          // this wave's steps: kw, kw + 64, ...
+    const int nsteps = kw < kend ? (kend - kw + 63) / 64 : 0;
+    // Rounds of DEPTH steps: every load of a round is requested before the first conversion (one memory round trip per round: K <= 512
+    // is one round, K = 1024 two).  No load is issued between the conversions of a round: with more than 63 loads in flight the wait
+    // counter saturates and the compiler's waits inside a loop that also issues become "wait for everything" per step.
+    for (int base = 0; base < nsteps; base += DEPTH) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const bool kv = k0 + 8 * lg + e < kend;
-        const float xv = (kv && lr < nr) ? xa[e] : 0.f;
-        const float wvv = (kv && jw < a.C) ? wb[e] : 0.f;
-        ah[e] = (__bf16)xv;
-        al[e] = (__bf16)(xv - (float)ah[e]);
-        bh[e] = (__bf16)wvv;
-        bl[e] = (__bf16)(wvv - (float)bh[e]);
+      for (int d = 0; d < DEPTH; ++d)
+        if (base + d < nsteps) issue(xa[d], wb[d], kw + 64 * (base + d));     // wave-uniform
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d) {
+        const int i = base + d;
+        if (i >= nsteps) break;                             // wave-uniform
+        const int k0 = kw + 64 * i;
+        bf16x8 ah, al, bh, bl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const bool kv = k0 + 8 * lg + e < kend;
+          const float xv = (kv && lr < nr) ? xa[d][e] : 0.f;
+          const float wvv = (kv && jw < a.C) ? wb[d][e] : 0.f;
+          ah[e] = (__bf16)xv;
+          al[e] = (__bf16)(xv - (float)ah[e]);
+          bh[e] = (__bf16)wvv;
+          bl[e] = (__bf16)(wvv - (float)bh[e]);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
       }
-      if (k0 + 64 < kend) issue(k0 + 64);                  // next step's loads fly under the MFMAs
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
     }
     // combine the four waves in a fixed order: acc[e] is row (e & 3) + 8 (e >> 2) + 4 g, column r
     __syncthreads();
@@ -190,7 +233,7 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a0, co
   const int tx = c, ty = s;
   constexpr int RP = DL_SLICES;
   const bool jv = j < C;
-  const float b = (jv && a.bias) ? a.bias[j] : 0.f;
+  const float b = jv ? pf_bias : 0.f;
   float zr[DL_ROWS / RP];        // small: this thread's rows ty, ty+8, ty+16, ty+24 stay in registers
   float s1 = 0.f;
   if (small && single) {
@@ -299,12 +342,11 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a0, co
     const float kscale = a.bt_keep ? a.bt_keep_scale : 1.f;
     float v[DL_ROWS / RP], zh[DL_ROWS / RP];
     const float (&zz)[DL_ROWS / DL_SLICES] = bt_zz;
-    const unsigned kp = bt_kp;
     float S1 = 0.f, S2 = 0.f;
 #pragma unroll
     for (int i = 0; i < DL_ROWS / RP; ++i) {
       const int r = ty + RP * i;
-      float d = ((kp >> i) & 1u) ? zr[i] * kscale : 0.f;
+      float d = bt_kb[i] ? zr[i] * kscale : 0.f;
       if (a.bt_act == 1 && !(fmaf(bsc, zz[i], bsh) > 0.f)) d = 0.f;
       if (r >= R || !jv) d = 0.f;
       zh[i] = (zz[i] - mu) * is;
@@ -346,7 +388,7 @@ __global__ __launch_bounds__(256) void dense_layer_kernel(const DenseArgs a0, co
         if (r < R) {
           float y = fmaf(sc, zr[i], sh);
           if (a.act == 1) y = clamp_lo(y, 0.f);
-          if (a.keep) y = ((pf_keep >> i) & 1u) ? y * a.keep_scale : 0.f;
+          if (a.keep) y = pf_kb[i] ? y * a.keep_scale : 0.f;
           a.a_out[(long long)r * C + j] = y;
         }
       }
@@ -703,6 +745,23 @@ static int dense_args(DenseArgs& a, const float* x, int ldx, const float* w, int
   a.bt_dz = a.bt_dgamma = a.bt_dbeta = a.bt_dbias = nullptr;
   return PN_OK;
 }
+// the kernel variant of a launch: DEPTH from the 64-k steps a wave walks (K per split / 4 waves / 64), VEC from the operands' alignment
+template <bool TRANS>
+static void launch_dense(const DenseArgs& a, const DenseArgs& b, dim3 grid, hipStream_t st) {
+  const int steps = cdiv(a.split_len, 64);                  // 64-k steps per wave (wave w walks the k16-steps w, w + 4, ...)
+  const int depth = steps <= 2 ? 2 : (steps <= 4 ? 4 : 8);
+  auto aligned = [](const DenseArgs& q) {
+    return q.K % 16 == 0 && q.ldx % 4 == 0 && (reinterpret_cast<uintptr_t>(q.x) & 15) == 0 &&
+           (!TRANS || (q.ldw % 4 == 0 && (reinterpret_cast<uintptr_t>(q.w) & 15) == 0));
+  };
+  const bool vec = aligned(a) && aligned(b);
+  // (unaligned operands -- odd shapes of the op-level tests only -- take the scalar-load form, which keeps one step ahead whatever K)
+#define PN_DENSE_CASE(D, V) hipLaunchKernelGGL((dense_layer_kernel<TRANS, D, V>), grid, dim3(256), 0, st, a, b)
+  if (vec) { if (depth == 2) PN_DENSE_CASE(2, true); else if (depth == 4) PN_DENSE_CASE(4, true); else PN_DENSE_CASE(8, true); }
+  else PN_DENSE_CASE(2, false);
+#undef PN_DENSE_CASE
+}
+
 int dense_layer(const float* x, int ldx, const float* w, int ldw, bool trans, int R, int K, int C, float* partial, unsigned* counters,
                 const float* bias, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps, int bn_mode,
                 int act, const unsigned char* keep, float keep_scale, float* z_out, float* a_out, float* mean_o, float* invstd_o,
@@ -711,8 +770,8 @@ int dense_layer(const float* x, int ldx, const float* w, int ldw, bool trans, in
   PN_TRY(dense_args(a, x, ldx, w, ldw, R, K, C, partial, counters, bias, gamma, beta, mm, mv, momentum, eps, bn_mode, act, keep, keep_scale,
                     z_out, a_out, mean_o, invstd_o));
   const dim3 grid(cdiv(C, DL_COLS), a.nsplit);
-  if (trans) hipLaunchKernelGGL(dense_layer_kernel<true>, grid, dim3(256), 0, st, a, a);
-  else hipLaunchKernelGGL(dense_layer_kernel<false>, grid, dim3(256), 0, st, a, a);
+  if (trans) launch_dense<true>(a, a, grid, st);
+  else launch_dense<false>(a, a, grid, st);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -728,7 +787,7 @@ int dense_layer_with_plain(const float* x, int ldx, const float* w, int ldw, int
                     z_out, a_out, mean_o, invstd_o));
   PN_TRY(dense_args(b, x, ldx, w2, ldw2, R, K, C, partial + dense_partial_floats(R, K, C), counters + cdiv(C, DL_COLS), nullptr, nullptr, nullptr,
                     nullptr, nullptr, 0.f, 0.f, 0, 0, nullptr, 1.f, out2, nullptr, nullptr, nullptr));
-  hipLaunchKernelGGL(dense_layer_kernel<false>, dim3(cdiv(C, DL_COLS), a.nsplit, 2), dim3(256), 0, st, a, b);
+  launch_dense<false>(a, b, dim3(cdiv(C, DL_COLS), a.nsplit, 2), st);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -748,7 +807,7 @@ int dense_trans_tail(const float* dz, int lddz, const float* w, int ldw, int R, 
     a.bt_keep = tail->keep; a.bt_keep_scale = tail->keep_scale; a.bt_mode = tail->mode; a.bt_act = tail->act;
     a.bt_dz = tail->dz; a.bt_dgamma = tail->dgamma; a.bt_dbeta = tail->dbeta; a.bt_dbias = tail->dbias;
   }
-  hipLaunchKernelGGL(dense_layer_kernel<true>, dim3(cdiv(C, DL_COLS), a.nsplit), dim3(256), 0, st, a, a);
+  launch_dense<true>(a, a, dim3(cdiv(C, DL_COLS), a.nsplit), st);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

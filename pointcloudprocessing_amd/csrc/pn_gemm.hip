@@ -940,9 +940,15 @@ static int launch_wgrad_batch(const WgradBatch& wb, bool b2, int prec, int block
 // jobs of the same tile shape / operand form / precision share a launch (up to WGRAD_BATCH_MAX each)
 int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st) {
   std::vector<char> done(n > 0 ? n : 0, 0);
+  // shape 3 (round 3): 128 x 256 output tiles for the wide jobs of the bf16 mode (seg_l2: 512 x 256) -- a tile re-stages its rows of
+  // both operands, so with 128 x 128 tiles that job read its operands three times over (402 MB for 134 MB at B=32, N=2048); a wave
+  // holds 2 x 4 accumulator blocks (128 registers) and the dz operand's two sources 64 more: bf16 sources only
+  static const bool wide_ok = !(getenv("PN_WGRAD_WIDE") && atoi(getenv("PN_WGRAD_WIDE")) == 0);
   auto key = [&](const WgradDesc& q) {
-    const int shape = q.small_tiles ? 2 : (q.Ci % 128 == 0 && q.Cj % 128 == 0) ? 0 : (q.Cj % 128 == 0 ? 1 : 2);
-    return shape * 8 + (q.b.s2 ? 4 : 0) + ((q.prec & ~PN_STORE_BF16) == PN_PREC_BF16X3 ? 1 : 0);
+    const bool x3 = (q.prec & ~PN_STORE_BF16) == PN_PREC_BF16X3;
+    const bool wide = wide_ok && !q.small_tiles && !x3 && q.a.h16 && q.b.h16 && q.Ci % 128 == 0 && q.Cj % 256 == 0;
+    const int shape = q.small_tiles ? 2 : wide ? 3 : (q.Ci % 128 == 0 && q.Cj % 128 == 0) ? 0 : (q.Cj % 128 == 0 ? 1 : 2);
+    return shape * 8 + (q.b.s2 ? 4 : 0) + (x3 ? 1 : 0);
   };
   for (int i = 0; i < n; ++i) {
     if (done[i]) continue;
@@ -956,7 +962,7 @@ int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st) {
       GemmArgs& g = wb.g[wb.n];
       PN_TRY(wgrad_args(&q.a, &q.b, q.B, q.N, q.Ci, q.Cj, q.slab_rows, q.slabs, q.prec, q.colsum, g));
       const int shape = k / 8;
-      const int bm = shape == 0 ? 128 : 64, bn = shape == 2 ? 64 : 128;
+      const int bm = (shape == 0 || shape == 3) ? 128 : 64, bn = shape == 3 ? 256 : (shape == 2 ? 64 : 128);
       const int nslab = q.B * g.tiles_per_cloud, ny = q.Ci / bm, nz = q.Cj / bn;
       blocks += (long long)nslab * ny * nz;
       PN_CHECK_ARG(blocks < (1ll << 30), "pn_conv_wgrad: batch too large");
@@ -969,6 +975,11 @@ int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st) {
     switch (k / 8) {
       case 0: PN_TRY((launch_wgrad_batch<128, 128>(wb, b2, prec, (int)blocks, st))); break;
       case 1: PN_TRY((launch_wgrad_batch<64, 128>(wb, b2, prec, (int)blocks, st))); break;
+      case 3:
+        if (b2) hipLaunchKernelGGL((wgrad_batch_kernel<128, 256, 1, true>), dim3((int)blocks), dim3(256), 0, st, wb);
+        else hipLaunchKernelGGL((wgrad_batch_kernel<128, 256, 1, false>), dim3((int)blocks), dim3(256), 0, st, wb);
+        PN_CHECK_LAUNCH();
+        break;
       default: PN_TRY((launch_wgrad_batch<64, 64>(wb, b2, prec, (int)blocks, st))); break;
     }
   }

@@ -36,6 +36,13 @@ int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const l
                    int use_batch, int update, float* mean, float* invstd, float* scale, float* shift, float* g, float* zstar, int* argq,
                    hipStream_t st);
 
+// inference: ConvLayer(3 | 64 -> 64) -> ConvLayer(64 -> 128) -> ConvLayer(128 -> 1024) -> reduce_max in one launch (pn_panel.hip: chain_max_kernel);
+// exactly one of x (64-channel bf16 lazy operand, with w1t = the first kernel's transposed bf16 copy) and xyz (with w1 = the (3, 64) kernel)
+int chain_fwd_max(const pn_operand* x, const float* xyz, const float* w1, const void* w1t, const float* sc1, const float* sh1, const void* w2t,
+                  const float* sc2, const float* sh2, const void* wf_hi, int B, int N, float* pmax, int* pq, hipStream_t st);
+// bf16 copies of a (K, C) kernel as the row GEMMs stage them (pn_prologue.hip, WCopyDesc: nat (K, C), tr (C, K)) as a launch of their own
+int weights_copy16(const float* w, int K, int C, void* nat, void* tr, hipStream_t st);
+
 // pn_prologue.hip
 int normalize(const float* xyz, int B, int N, float* out, float* centroid, float* scale, hipStream_t st);
 // normalisation + fragment-ordered copies of three kernels (+ zero_u cleared) + optionally the gradient buffer cleared (grads) and the

@@ -162,7 +162,8 @@ struct WS {
 };
 
 static long long wgrad_slab_rows(int B, int N, int Ci, int Cj, int* spc_out, int target_override = 0) {
-  const int bm = (Ci % 128 == 0 && Cj % 128 == 0) ? 128 : 64, bn = (Cj % 128 == 0) ? 128 : 64;
+  // (128 x 256 tiles where the bf16 mode uses them, pn_gemm.hip conv_wgrad_batch; the other modes then launch twice the workgroups)
+  const int bm = (Ci % 128 == 0 && Cj % 128 == 0) ? 128 : 64, bn = (Ci % 128 == 0 && Cj % 256 == 0) ? 256 : ((Cj % 128 == 0) ? 128 : 64);
   const int n_out = (Ci / bm) * (Cj / bn);
   // about one workgroup per CU: 512 slabs of 64 rows made the weight-gradient kernels write (and slab_reduce re-read) twice the
   // bytes for no extra parallelism -- 1.40 -> 1.34 ms/step at B=32, N=1024 (sweep: 64: 1.47, 128: 1.38, 192: 1.36, 256-384: 1.34)
@@ -535,6 +536,20 @@ struct Run {
     return panel_finalize(m.pmax, m.pq, m.sumsq, m.pa1, m.wb_hi, m.wb_lo, prec, B, N, r.cin, r.cout, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub,
                           ub, l.mean, l.invstd, l.scale, l.shift, m.g, m.zstar, m.argq, st);
   }
+  // Inference (moving statistics everywhere): a max-pooled chain c1 -> c2 -> c3 + reduce_max as ONE launch (pn_panel.hip: chain_max_kernel),
+  // bit-identical to the three launches it replaces.  bf16-storage mode only (it stages the prepared bf16 kernel copies and rounds
+  // where that plan's stores round); not when the caller wants every layer's output kept (PN_IO_KEEP_ACTIVATIONS: check_numerics).
+  bool fused_chain(const CL& c2) const {
+    static const bool on = !(getenv("PN_CHAIN_FUSE") && atoi(getenv("PN_CHAIN_FUSE")) == 0);
+    return on && !training && s16 && (prec & ~PN_STORE_BF16) == PN_PREC_BF16 && !(io.flags & PN_IO_KEEP_ACTIVATIONS) && c2.wt16 != nullptr;
+  }
+  // x == nullptr: the chain starts from the normalised cloud (first layer's (3, 64) kernel w1f); else from the 64-channel operand
+  int fwd_chain(const pn_operand* x, const float* w1f, CL& c1, CL& c2, CL& c3, ML& m, const LRef& r3) {
+    PN_TRY(chain_fwd_max(x, x ? nullptr : w.pcn, w1f, x ? c1.wt16 : nullptr, c1.scale, c1.shift, c2.wt16, c2.scale, c2.shift, m.wb_hi, B, N,
+                         m.pmax, m.pq, st));
+    return panel_finalize(m.pmax, m.pq, nullptr, nullptr, m.wb_hi, m.wb_lo, prec, B, N, r3.cin, r3.cout, p(r3.gamma), p(r3.beta), p(r3.mm), p(r3.mv),
+                          d.bn_momentum, d.bn_eps, 0, 0, c3.mean, c3.invstd, c3.scale, c3.shift, m.g, m.zstar, m.argq, st);
+  }
   // out (B, C) = x (B, K) . W (+ bias): one launch (pn_dense.hip); trans reads W^T from the same (C, K)-major... kernel
   int dense_plain(const float* x, int ldx, const float* W, int ldw, bool trans, int K, int C, const float* bias, float* out) {
     return dense_layer(x, ldx, W, ldw, trans, B, K, C, w.dense_part, w.dcount, bias, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0,
@@ -547,6 +562,12 @@ struct Run {
                        p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, mode, act, keep, ks, dl.z, dl.a, dl.mean, dl.invstd, st);
   }
   int fwd_tnet(TN& t, const TRef& r, const pn_operand* x) {
+    if (fused_chain(t.c2) && (r.K == 3 || t.c1.wt16)) {
+      PN_TRY(fwd_chain(r.K == 3 ? nullptr : x, r.K == 3 ? p(r.c1.kernel) : nullptr, t.c1, t.c2, t.c3, t.m3, r.c3));
+      PN_TRY(fwd_dense(t.d1, r.d1, t.m3.g, 1, nullptr));
+      PN_TRY(fwd_dense(t.d2, r.d2, t.d1.a, 1, nullptr));
+      return dense_plain(t.d2.a, 256, p(r.w), r.K * r.K, false, 256, r.K * r.K, p(r.b), t.R);
+    }
     if (r.K == 3) {
       PN_TRY(conv3_fwd(w.pcn, p(r.c1.kernel), 0, B, N, 64, t.c1.Z, bn_batch(r.c1.block) ? t.c1.part : nullptr, st, s16));
       PN_TRY(bn_fin(t.c1, r.c1));
@@ -629,9 +650,13 @@ struct Run {
       PN_TRY(conv_fwd(&a12, w.fT.R, 4096, B, N, 64, 64, nullptr, w.X64, nullptr, prec, st));
     }
     const pn_operand x64 = x64op();
-    PN_TRY(fwd_conv(w.m21, L.m21, x64, p(L.m21.kernel), 0, nullptr));
-    PN_TRY(fwd_conv(w.m22, L.m22, lazy(w.m21), p(L.m22.kernel), 0, nullptr));
-    PN_TRY(fwd_max(w.m23, w.mm23, L.m23, lazy(w.m22), 2));
+    if (fused_chain(w.m22) && w.m21.wt16) {
+      PN_TRY(fwd_chain(&x64, nullptr, w.m21, w.m22, w.m23, w.mm23, L.m23));
+    } else {
+      PN_TRY(fwd_conv(w.m21, L.m21, x64, p(L.m21.kernel), 0, nullptr));
+      PN_TRY(fwd_conv(w.m22, L.m22, lazy(w.m21), p(L.m22.kernel), 0, nullptr));
+      PN_TRY(fwd_max(w.m23, w.mm23, L.m23, lazy(w.m22), 2));
+    }
     const float* Gf = w.mm23.g;
 
     // classification head (PointNet.py:252-263)

@@ -85,9 +85,17 @@ struct PanelArgs {
 // PN_PANEL_DBG (timing ablations of the bf16, K = 128, statistics variant; WRONG results; tools/panel_probe.py): template bit mask DBG:
 // 1 no epilogue, 4 no activation loads, 8 no MFMAs; 16 (bf16 source only) the product kernel + shader-clock stamps in pq
 
+// PN_PANEL_SPLIT (experiment, bf16 operands, C >= 1024; read once): 1 = a workgroup owns HALF the columns (two column blocks per wave: 64
+// fragment registers instead of 128, half the kernel bytes per workgroup) and twice the rows (half the slots per cloud, same number of
+// workgroups); 2 = half the columns, the same rows (twice the workgroups)
+static int panel_split_mode() {
+  static const int m = getenv("PN_PANEL_SPLIT") ? atoi(getenv("PN_PANEL_SPLIT")) : 0;
+  return m;
+}
 int panel_slots_per_cloud(int B, int N) {
   const int tpc = cdiv(N, 64);
   int spc = 256 / (B > 0 ? B : 1);
+  if (panel_split_mode() == 1) spc /= 2;
   if (spc < 1) spc = 1;
   return spc < tpc ? spc : tpc;
 }
@@ -569,6 +577,7 @@ static void launch_panel_cbw(const PanelArgs& g, int C, bool stats, hipStream_t 
   constexpr int CBW_MAX = (NS == 3) ? 2 : 4;
   int cbw = C / 256;                                   // column blocks per wave if one workgroup owned every column
   if (cbw > CBW_MAX) cbw = CBW_MAX;
+  if (NS == 1 && cbw == 4 && panel_split_mode() != 0) cbw = 2;
   const dim3 grid(g.B * g.spc, C / (256 * cbw));
   if (cbw == 4) { if constexpr (CBW_MAX >= 4) launch_panel<NS, K, 4>(g, grid, stats, st); }
   else if (cbw == 2) launch_panel<NS, K, 2>(g, grid, stats, st);
@@ -601,6 +610,257 @@ int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo
   } else {
     if (K == 128) launch_panel_cbw<1, 128>(g, C, st_, st);
     else launch_panel_cbw<1, 64>(g, C, st_, st);
+  }
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// ---- inference: a whole max-pooled chain in ONE launch ---------------------------------------------------------------------------
+// north_star's named kernel is the per-point MLP + global max: ConvLayer(. -> 64) -> ConvLayer(64 -> 128) -> ConvLayer(128 -> 1024) ->
+// reduce_max (PointNet.py:236-248 for mlp_2, :421-429 for the two T-Nets).  With moving statistics (inference) no layer waits for a
+// batch statistic, so a workgroup takes its run of 64-row panels through all three layers: the two narrow layers' outputs live in LDS
+// only (no (B*N, 64) / (B*N, 128) tensor is written or read back), the wide layer is the kernel-stationary panel product above.
+//   FRONT 0: the chain starts from the normalised cloud (B*N, 3): first layer on the vector ALU with conv3_fwd's own fma chain;
+//   FRONT 1: it starts from a 64-channel lazy operand stored as bf16 (X_64, or relu(bn(mlp_1_2))): first layer on the matrix cores.
+// Every value is rounded where the layer-by-layer plan rounds it (the stored pre-BN output to bf16, the BN + ReLU result to the bf16
+// MFMA operand) and every contraction runs in the same k order on the same instruction: pmax / pq are BIT-IDENTICAL to the three
+// launches they replace (tests/test_gpu_ops.py::test_chain_kernel_equals_the_layered_launches).
+struct ChainArgs {
+  pn_operand x;                 // FRONT 1: (B*N, 64) lazy operand, bf16 storage
+  const float* xyz;             // FRONT 0: (B*N, 3)
+  const float* w1f;             // FRONT 0: the first layer's (3, 64) kernel
+  const unsigned short* w1t;    // FRONT 1: bf16 copy [64][64] of the first layer's kernel, TRANSPOSED ([Cout][K], pn_prologue.hip)
+  const float *sc1, *sh1;       // BatchNormalization scale / shift (moving statistics) of the first layer
+  const unsigned short* w2t;    // bf16 copy [128][64] of the second layer's kernel, transposed
+  const float *sc2, *sh2;
+  const __bf16* wf_hi;          // third layer: fragment-ordered, presigned copy (weights_prep)
+  int B, N, spc;
+  float* pmax; int* pq;         // as PanelArgs
+};
+// one 32 x 32 accumulator block (lane = column col, 16 rows) -> bf16 LDS image, pairs of adjacent columns as one dword (the DPP swap
+// of pn_segout.hip: sub-dword LDS stores from 64 lanes serialise)
+__device__ __forceinline__ void chain_store_block(__bf16* img, int pitch, int m, int col, int h, int lane, const float (&y)[16]) {
+  const bool odd = lane & 1;
+#pragma unroll
+  for (int e = 0; e < 16; e += 2) {
+    const float give = odd ? y[e] : y[e + 1];
+    const float got = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, give), 0xB1, 0xF, 0xF, true));
+    const int ee = odd ? e + 1 : e;
+    const int row = m * 32 + (ee & 3) + 8 * (ee >> 2) + 4 * h;
+    const float lo = odd ? got : y[e], hi = odd ? y[e + 1] : got;
+    const unsigned w = (unsigned)f32_bf16_bits(lo) | ((unsigned)f32_bf16_bits(hi) << 16);
+    *reinterpret_cast<unsigned*>(img + row * pitch + (col & ~1)) = w;
+  }
+}
+// the stored-then-reloaded form of a layer output: pre-BN value rounded to bf16 (the plan's 16-bit store), BN + ReLU in fp32
+__device__ __forceinline__ float chain_bnrelu(float z, float sc, float sh) {
+  return clamp_lo(fmaf(sc, bf16_bits_f32(f32_bf16_bits(z)), sh), 0.f);
+}
+template <int FRONT>
+__global__ __launch_bounds__(512) void chain_max_kernel(const ChainArgs g) {
+  constexpr int BM = 64, K = 128, KS = K / 16, PA = K + 8, P64 = 64 + 8, CBW = 4, C = 1024;
+  __shared__ __attribute__((aligned(16))) __bf16 Ap[BM * PA];      // the wide layer's operand panel
+  __shared__ __attribute__((aligned(16))) __bf16 In0[BM * P64];    // FRONT 1: the chain's input panel in operand precision
+  __shared__ __attribute__((aligned(16))) __bf16 A1[BM * P64];     // relu(bn(first layer)) in operand precision
+  __shared__ u32x4 Bl[8][KS][64];                                  // [wave][k-step][lane]: the fourth column block's fragments (registers: three)
+  __shared__ __attribute__((aligned(16))) float ctab[5 * 64];      // FRONT 0: w0, w1, w2, scale, shift per channel; FRONT 1: the operand's ca, cc
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int slot = blockIdx.x;
+  const int cloud = slot / g.spc, j = slot - cloud * g.spc;
+  const int tpc = (g.N + BM - 1) / BM;
+  const int p_begin = (int)((long long)j * tpc / g.spc), p_end = (int)((long long)(j + 1) * tpc / g.spc);
+  const long long cloud_row0 = (long long)cloud * g.N;
+
+  // ---- what does not depend on the panel: requested once ----
+  // second layer: wave w owns (row block w & 1, column block w >> 1) of the 64 x 128 output
+  const int rb2 = wave & 1, cb2 = wave >> 1;
+  const float sc2 = g.sc2[32 * cb2 + r], sh2 = g.sh2[32 * cb2 + r];
+  u32x4 l2b[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) l2b[ks] = *reinterpret_cast<const u32x4*>(g.w2t + (long long)(32 * cb2 + r) * 64 + ks * 16 + 8 * h);
+  // first layer
+  const int rb1 = wave & 1, cb1 = (wave >> 1) & 1;                  // FRONT 1: waves 0..3 own the four 32 x 32 blocks of the 64 x 64 output
+  float sc1 = 1.f, sh1 = 0.f;
+  u32x4 l1b[FRONT == 1 ? 4 : 1];
+  const int frow = tid >> 3, fch = (tid & 7) * 8;                   // FRONT 0 / staging: thread <-> (row of the panel, 8 channels)
+  if constexpr (FRONT == 1) {
+    sc1 = g.sc1[32 * cb1 + r]; sh1 = g.sh1[32 * cb1 + r];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) l1b[ks] = *reinterpret_cast<const u32x4*>(g.w1t + (long long)(32 * cb1 + r) * 64 + ks * 16 + 8 * h);
+    if (tid < 64) {
+      ctab[tid] = g.x.ca ? g.x.ca[tid] : 1.f;
+      ctab[64 + tid] = g.x.cc ? g.x.cc[tid] : 0.f;
+    }
+  } else {
+    if (tid < 64) {
+      ctab[tid] = g.w1f[tid]; ctab[64 + tid] = g.w1f[64 + tid]; ctab[128 + tid] = g.w1f[128 + tid];
+      ctab[192 + tid] = g.sc1[tid]; ctab[256 + tid] = g.sh1[tid];
+    }
+  }
+  // third layer: this wave's four column blocks, resident for the whole run (as panel_max_kernel)
+  const u32x4* __restrict__ wfh = reinterpret_cast<const u32x4*>(g.wf_hi);
+  constexpr int RB = 3;
+  u32x4 bw[RB][KS];
+  int cbs[CBW];
+#pragma unroll
+  for (int i = 0; i < CBW; ++i) {
+    cbs[i] = i * 8 + wave;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const u32x4 f = (wfh + (long long)cbs[i] * KS * 64 + lane)[ks * 64];
+      if (i < RB) bw[i < RB ? i : 0][ks] = f;
+      else Bl[wave][ks][lane] = f;                     // read back by this wave only
+    }
+  }
+  float best[CBW];
+  int bq[CBW];
+#pragma unroll
+  for (int i = 0; i < CBW; ++i) { best[i] = -INFINITY; bq[i] = 0; }
+  __syncthreads();                                   // the coefficient table
+
+  for (int pnl = p_begin; pnl < p_end; ++pnl) {
+    const int rbase = pnl * BM, nrows = min(BM, g.N - rbase);
+    const bool full = nrows == BM;
+    const long long rsrc = cloud_row0 + rbase + (frow < nrows ? frow : nrows - 1);
+    // ---- first layer -> A1 ----
+    if constexpr (FRONT == 1) {
+      float v[8], xca[8], xcc[8];
+      bf16x8_unpack(act_load8_raw(g.x.s1, rsrc * g.x.ld + fch), v);
+      *reinterpret_cast<float4*>(&xca[0]) = *reinterpret_cast<const float4*>(&ctab[fch]);
+      *reinterpret_cast<float4*>(&xca[4]) = *reinterpret_cast<const float4*>(&ctab[fch + 4]);
+      *reinterpret_cast<float4*>(&xcc[0]) = *reinterpret_cast<const float4*>(&ctab[64 + fch]);
+      *reinterpret_cast<float4*>(&xcc[4]) = *reinterpret_cast<const float4*>(&ctab[64 + fch + 4]);
+      u32x4 pk;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const f32x2 tt = {clamp_lo(fmaf(xca[e], v[e], xcc[e]), g.x.lo), clamp_lo(fmaf(xca[e + 1], v[e + 1], xcc[e + 1]), g.x.lo)};
+        pk[e / 2] = frow < nrows ? __builtin_bit_cast(unsigned, __builtin_convertvector(tt, bf16x2)) : 0u;
+      }
+      *reinterpret_cast<u32x4*>(&In0[frow * P64 + fch]) = pk;
+      __syncthreads();
+      if (wave < 4) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 af = *reinterpret_cast<const bf16x8*>(&In0[(rb1 * 32 + r) * P64 + ks * 16 + 8 * h]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, l1b[ks]), acc, 0, 0, 0);
+        }
+        float y[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) y[e] = chain_bnrelu(acc[e], sc1, sh1);
+        chain_store_block(A1, P64, rb1, 32 * cb1 + r, h, lane, y);
+      }
+    } else {
+      const float a0 = g.xyz[rsrc * 3], a1 = g.xyz[rsrc * 3 + 1], a2 = g.xyz[rsrc * 3 + 2];
+      float w0[8], w1[8], w2[8], s1v[8], h1v[8];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        *reinterpret_cast<float4*>(&w0[4 * q]) = *reinterpret_cast<const float4*>(&ctab[fch + 4 * q]);
+        *reinterpret_cast<float4*>(&w1[4 * q]) = *reinterpret_cast<const float4*>(&ctab[64 + fch + 4 * q]);
+        *reinterpret_cast<float4*>(&w2[4 * q]) = *reinterpret_cast<const float4*>(&ctab[128 + fch + 4 * q]);
+        *reinterpret_cast<float4*>(&s1v[4 * q]) = *reinterpret_cast<const float4*>(&ctab[192 + fch + 4 * q]);
+        *reinterpret_cast<float4*>(&h1v[4 * q]) = *reinterpret_cast<const float4*>(&ctab[256 + fch + 4 * q]);
+      }
+      u32x4 pk;
+#pragma unroll
+      for (int e = 0; e < 8; e += 2) {
+        const float v0 = fmaf(a2, w2[e], fmaf(a1, w1[e], a0 * w0[e]));               // conv3_fwd's chain
+        const float v1 = fmaf(a2, w2[e + 1], fmaf(a1, w1[e + 1], a0 * w0[e + 1]));
+        const f32x2 tt = {chain_bnrelu(v0, s1v[e], h1v[e]), chain_bnrelu(v1, s1v[e + 1], h1v[e + 1])};
+        pk[e / 2] = __builtin_bit_cast(unsigned, __builtin_convertvector(tt, bf16x2));
+      }
+      *reinterpret_cast<u32x4*>(&A1[frow * P64 + fch]) = pk;
+    }
+    __syncthreads();
+    // ---- second layer -> the wide layer's operand panel ----
+    {
+      f32x16 acc;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 af = *reinterpret_cast<const bf16x8*>(&A1[(rb2 * 32 + r) * P64 + ks * 16 + 8 * h]);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, __builtin_bit_cast(bf16x8, l2b[ks]), acc, 0, 0, 0);
+      }
+      float y[16];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) y[e] = chain_bnrelu(acc[e], sc2, sh2);
+      chain_store_block(Ap, PA, rb2, 32 * cb2 + r, h, lane, y);
+    }
+    __syncthreads();
+    // ---- wide layer + running maximum (the plain loop of panel_max_kernel: same chains, same association) ----
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      asm volatile("" ::: "memory");
+      bf16x8 af[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) af[ks] = *reinterpret_cast<const bf16x8*>(&Ap[(m * 32 + r) * PA + ks * 16 + h * 8]);
+#pragma unroll
+      for (int i = 0; i < CBW; ++i) {
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          const u32x4 vb = i < RB ? bw[i < RB ? i : 0][ks] : Bl[wave][ks][lane];
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks], __builtin_bit_cast(bf16x8, vb), acc, 0, 0, 0);
+        }
+        float mx;
+        if (full) {
+          mx = max16_guarded(acc);
+        } else {
+          mx = -INFINITY;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int il = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            mx = fmaxf(mx, il < nrows ? acc[e] : -INFINITY);
+          }
+        }
+        const bool better = mx > best[i];
+        best[i] = better ? mx : best[i];
+        bq[i] = better ? (pnl * 2 + m) : bq[i];
+        asm volatile("" : "+v"(best[i]));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();                                 // the three images are rewritten by the next panel
+  }
+#pragma unroll
+  for (int i = 0; i < CBW; ++i) {
+    const float ob = __shfl_xor(best[i], 32, 64);
+    const int oq = __shfl_xor(bq[i], 32, 64);
+    const bool take = ob > best[i] || (ob == best[i] && oq < bq[i]);
+    if (h == 0) {
+      const long long o = (long long)slot * C + cbs[i] * 32 + r;
+      g.pmax[o] = take ? ob : best[i];
+      g.pq[o] = take ? oq : bq[i];
+    }
+  }
+}
+
+int chain_fwd_max(const pn_operand* x, const float* xyz, const float* w1, const void* w1t, const float* sc1, const float* sh1, const void* w2t,
+                  const float* sc2, const float* sh2, const void* wf_hi, int B, int N, float* pmax, int* pq, hipStream_t st) {
+  PN_CHECK_ARG((x != nullptr) != (xyz != nullptr), "pn_chain_fwd_max: exactly one of the 64-channel operand and the xyz cloud");
+  PN_CHECK_ARG(sc1 && sh1 && w2t && sc2 && sh2 && wf_hi && pmax && pq && B > 0 && N > 0, "pn_chain_fwd_max: bad arguments");
+  PN_CHECK_ARG((reinterpret_cast<uintptr_t>(w2t) & 15) == 0 && (reinterpret_cast<uintptr_t>(wf_hi) & 15) == 0, "pn_chain_fwd_max: kernel copies must be 16-byte aligned");
+  ChainArgs g;
+  memset(&g, 0, sizeof(g));
+  g.sc1 = sc1; g.sh1 = sh1; g.w2t = reinterpret_cast<const unsigned short*>(w2t); g.sc2 = sc2; g.sh2 = sh2;
+  g.wf_hi = reinterpret_cast<const __bf16*>(wf_hi);
+  g.B = B; g.N = N; g.spc = panel_slots_per_cloud(B, N); g.pmax = pmax; g.pq = pq;
+  if (x) {
+    PN_CHECK_ARG(x->s1 && !x->s2 && x->h16 == 1 && x->ld >= 64 && x->ld % 8 == 0 && (reinterpret_cast<uintptr_t>(x->s1) & 15) == 0 && w1t &&
+                     (reinterpret_cast<uintptr_t>(w1t) & 15) == 0,
+                 "pn_chain_fwd_max: the 64-channel operand must be a 16-byte aligned bf16 array with the first kernel's bf16 copy");
+    g.x = *x; g.w1t = reinterpret_cast<const unsigned short*>(w1t);
+    hipLaunchKernelGGL(chain_max_kernel<1>, dim3(B * g.spc), dim3(512), 0, st, g);
+  } else {
+    PN_CHECK_ARG(w1 != nullptr, "pn_chain_fwd_max: the first layer's (3, 64) kernel is required");
+    g.xyz = xyz; g.w1f = w1;
+    hipLaunchKernelGGL(chain_max_kernel<0>, dim3(B * g.spc), dim3(512), 0, st, g);
   }
   PN_CHECK_LAUNCH();
   return PN_OK;

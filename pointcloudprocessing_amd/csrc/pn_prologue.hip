@@ -245,6 +245,18 @@ __device__ __forceinline__ void wcopy_body(const WCopyJobs& j, int blk) {
     *reinterpret_cast<pr_bf16x8*>(j.tr[q] + (long long)c * K + k0) = h;
   }
 }
+// the same copies as a launch of their own (op-level ABI: pn_weights_copy16; the model plan makes them in its first launch)
+__global__ __launch_bounds__(1024) void weights_copy16_kernel(const WCopyJobs j) { wcopy_body(j, blockIdx.x); }
+int weights_copy16(const float* w, int K, int C, void* nat, void* tr, hipStream_t st) {
+  PN_CHECK_ARG(w && nat && tr && K > 0 && C > 0 && K % 8 == 0 && C % 8 == 0, "pn_weights_copy16: w, both copies, K and C multiples of 8");
+  WCopyJobs j;
+  memset(&j, 0, sizeof(j));
+  j.w[0] = w; j.nat[0] = reinterpret_cast<unsigned short*>(nat); j.tr[0] = reinterpret_cast<unsigned short*>(tr);
+  j.K[0] = K; j.C[0] = C; j.end[0] = K * C; j.n = 1;
+  hipLaunchKernelGGL(weights_copy16_kernel, dim3(cdiv(K * C / 4, 1024)), dim3(1024), 0, st, j);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
 // coefficients of a layer that normalises with its moving statistics: the arithmetic of pn_bn_finalize with use_batch = 0
 struct FrozenBnJobs {
   FrozenBnDesc j[PN_FROZEN_MAX];

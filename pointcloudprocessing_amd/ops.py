@@ -91,6 +91,28 @@ def conv_fwd_max_panel(x_op, wf, B, N, K, C_, prec, want_stats=True):
     return pmax, pblk, sumsq, colsum
 
 
+def weights_copy16(w):
+    """bf16 copies of a Keras kernel (K, C): (as it is (K, C), transposed (C, K)) -- what the model plan's row GEMMs stage"""
+    K, C_ = w.shape
+    nat = torch.empty(K, C_, device=w.device, dtype=torch.bfloat16)
+    tr = torch.empty(C_, K, device=w.device, dtype=torch.bfloat16)
+    check(lib().pn_weights_copy16(ptr(w), K, C_, ptr(nat), ptr(tr), current_stream()), "pn_weights_copy16")
+    return nat, tr
+
+
+def chain_fwd_max(x_op, xyz, w1, w1t, sc1, sh1, w2t, sc2, sh2, wf_hi, B, N):
+    """inference: ConvLayer(3 | 64 -> 64) -> ConvLayer(64 -> 128) -> ConvLayer(128 -> 1024) -> reduce_max in one launch (moving
+    statistics); exactly one of x_op (64-channel bf16 lazy operand, with w1t) and xyz ((B*N, 3), with w1).  Returns (pmax, pblock) per
+    slot, as conv_fwd_max_panel leaves them."""
+    dev = wf_hi.device
+    T = B * lib().pn_panel_slots_per_cloud(B, N)
+    pmax = torch.empty(T, 1024, device=dev, dtype=F32)
+    pblk = torch.empty(T, 1024, device=dev, dtype=torch.int32)
+    check(lib().pn_chain_fwd_max(C.byref(x_op) if x_op is not None else None, ptr(xyz), ptr(w1), ptr(w1t), ptr(sc1), ptr(sh1), ptr(w2t),
+                                 ptr(sc2), ptr(sh2), ptr(wf_hi), B, N, ptr(pmax), ptr(pblk), current_stream()), "pn_chain_fwd_max")
+    return pmax, pblk
+
+
 def panel_finalize(pmax, pblk, sumsq, colsum, wf, prec, B, N, K, gamma, beta, moving_mean, moving_var, training=True, momentum=0.99, eps=1e-3):
     """BN coefficients of the layer + reduce_max over each cloud's tiles -> (mean, invstd, scale, shift, g, zstar, arg_block);
     wf, prec, K: what the panel launch was given"""

@@ -312,8 +312,8 @@ def check_training_step(dev, B, N, profile, vanilla=False, precision="bf16x3", r
     tapg, tapf = Bq["tapg"], F["tapg"]
     for oname, wname in lay.items():
         gy, gz = tapg.get(oname + ".y"), tapg.get(oname + ".z")
-        if gy is None or gz is None:
-            continue
+        if gy is None or gz is None or float(gy.abs().max()) == 0.0:
+            continue                                    # no loss reaches this layer in this profile: its backward did not run
         C_ = gy.shape[-1]
         dy = m.workspace_tensor(wname + ".dy", B, N, True, act).cpu().double().view(-1, C_)
         zz = m.workspace_tensor(wname + ".Z", B, N, True, act).cpu().double().view(-1, C_)

@@ -15,13 +15,15 @@ activation gradients, parameter gradients) must agree within a small fixed toler
 type, relative to the tensor's largest element.  Nothing cascades, so the tolerances do not depend on how well conditioned the
 network is, and a wrong index, coefficient, mask or summation range in any one kernel fails its own line.
 
-Tolerances (max |gpu - ref| <= tol * max |ref|, per tensor):
-  bf16 storage ('bf16'):     stored per-point tensors 2^-8 forward (half an ulp of the store + one operand flip), 2^-7 backward;
-  fp32 storage:              1e-3 with bf16 operands (an operand whose fp32 affine lands on the other side of a bf16 rounding boundary
-                             than the fp64 one moves a product by 2^-8), 1e-4 with split operands ('bf16x3');
-  per-cloud dense layers, statistics, coefficients, pooled features: fp32-grade (1e-4 .. 1e-3, stated at each check);
+Tolerances:
+  tensors stored as bf16 ('bf16' mode: pre-BN outputs, X_64, activation gradients): ELEMENT BY ELEMENT, |gpu - ref| <= half a bf16 ulp
+                             of that element + 2^-10 (forward) / 2^-9 (backward) of the tensor maximum (an MFMA operand whose fp32
+                             affine lands on the other side of a bf16 rounding boundary than the fp64 one moves a product by 2^-8);
+  fp32-stored tensors (max |gpu - ref| <= tol * max |ref|): 1e-3 forward / 2e-3 backward with bf16 operands, 1e-4 / 2e-4 with split
+                             operands ('bf16x3');
+  per-cloud dense layers, statistics, coefficients, pooled features: fp32-grade (1e-5 .. 1e-3, stated at each check);
   the Gram-form backward of the three max-pooled layers is algebraically, not operation by operation, the canonical backward it is
-  compared with: 2^-6 of the tensor maximum in 'bf16', 2e-3 otherwise.
+  compared with: 2^-7 of the tensor maximum in 'bf16' (measured <= 0.5 of that), 2e-3 otherwise.
 The measured ratio err / limit of every line goes to gpurun_out/model_report.txt.
 """
 import math
@@ -58,7 +60,7 @@ class Forced:
         self.t_z = 2.0 ** -8 if self.s16 else (1e-4 if precision == "bf16x3" else 1e-3)
         self.t_dy = 2.0 ** -7 if self.s16 else (2e-4 if precision == "bf16x3" else 2e-3)
         self.t_wg = 1e-4 if precision == "bf16x3" else 2e-3       # weight gradients: fp32 accumulation of products of rounded operands
-        self.t_gram = 2.0 ** -6 if self.s16 else 2e-3
+        self.t_gram = 2.0 ** -7 if self.s16 else 2e-3            # (measured: at most 0.5 x 2^-7 over the BASELINE configurations)
         self.t_pool = 1e-4 if precision == "bf16x3" else 1e-3     # pooled features, fp32, from fp32 accumulators
         self.fails = []
         self.G = m.named_grads()
@@ -73,12 +75,12 @@ class Forced:
         return self.ws(name, self.act, model).view(-1, C_)
 
     def judge(self, what, got, ref, tol, floor=0.0):
-        got, ref = got.double().reshape(-1), ref.double().reshape(-1)
+        got, ref = got.detach().cpu().double().reshape(-1), ref.detach().cpu().double().reshape(-1)
         assert got.numel() == ref.numel(), (what, got.numel(), ref.numel())
         skip = torch.isnan(ref)                                    # elements whose ReLU decision is within rounding (lazy())
         if bool(skip.any()):
-            if float(skip.double().mean()) >= 1e-4:
-                self.fails.append((what + ": too many undecided ReLU elements", float(skip.double().mean()), 1e-4))
+            if float(skip.double().mean()) >= 1e-3:
+                self.fails.append((what + ": too many undecided ReLU elements", float(skip.double().mean()), 1e-3))
             got, ref = got.masked_fill(skip, 0.0), ref.masked_fill(skip, 0.0)
         scale = max(_amax(ref), floor)
         err = _amax(got - ref)
@@ -87,6 +89,32 @@ class Forced:
         self.report(f"{self.tag} TF {what:52s} err {err:.3e}  max|ref| {scale:.3e}  limit {lim:.3e}  err/limit {err / lim:.2f}{'' if ok else '   <-- FAIL'}")
         if not ok:
             self.fails.append((what, err, lim))
+
+    def judge_stored(self, what, got, ref, slack):
+        """a tensor the GPU stored as bf16: element by element  |gpu - ref| <= half a bf16 ulp OF THAT ELEMENT + slack * max |ref|
+        (slack: an MFMA operand that rounded the other way moves a product by 2^-8; fp32 accumulation order)"""
+        got, ref = got.detach().cpu().double().reshape(-1), ref.detach().cpu().double().reshape(-1)
+        assert got.numel() == ref.numel(), (what, got.numel(), ref.numel())
+        skip = torch.isnan(ref)
+        if bool(skip.any()):
+            if float(skip.double().mean()) >= 1e-3:
+                self.fails.append((what + ": too many undecided ReLU elements", float(skip.double().mean()), 1e-3))
+            got, ref = got.masked_fill(skip, 0.0), ref.masked_fill(skip, 0.0)
+        scale = _amax(ref)
+        half_ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(1e-38))) - 8.0)
+        lim = half_ulp * 1.0001 + slack * scale + 1e-30
+        ratio = float(((got - ref).abs() / lim).max())
+        ok = ratio <= 1.0 and bool(torch.isfinite(got).all())
+        self.report(f"{self.tag} TF {what:52s} worst |err| / (half bf16 ulp of the element + {slack:.1e} max|ref|) = {ratio:.2f}  max|ref| {scale:.3e}"
+                    f"{'' if ok else '   <-- FAIL'}")
+        if not ok:
+            self.fails.append((what, ratio, 1.0))
+
+    def stored(self, what, got, ref, bwd=False):
+        if self.s16:
+            self.judge_stored(what, got, ref, 2.0 ** -9 if bwd else 2.0 ** -10)
+        else:
+            self.judge(what, got, ref, self.t_dy if bwd else self.t_z)
 
     def bn_batch(self, block):
         return self.tr.get(block, True)
@@ -98,7 +126,7 @@ class Forced:
         y = z * sc + sh
         # the ReLU decision of an element whose fp32 affine is within rounding of zero is the GPU's to make: such elements (a handful in
         # millions) are left out of the comparisons that apply this mask (second value: NaN there, which judge() skips)
-        sure = y.abs() > 1e-5 * ((z * sc).abs() + sh.abs())
+        sure = y.abs() > 1e-6 * ((z * sc).abs() + sh.abs())       # (fp32 rounding of the affine is 6e-8 of its terms)
         return self.qa(torch.relu(y)), torch.where(sure, (y > 0).double(), torch.full_like(y, float("nan")))
 
     # ---------------------------------------------------------------- forward pieces
@@ -143,7 +171,12 @@ class Forced:
             z = a @ Wq
         if cloud_bias is not None:
             z = (z.view(self.B, self.N, C_) + cloud_bias.view(self.B, 1, C_)).reshape(self.M, C_)
-        self.judge(f"{pref} pre-BN output Z", self.ws_act(wn + ".Z", C_, model), z, self.t_z if quant_w else (2.0 ** -8 if self.s16 else 1e-5))
+        if quant_w:
+            self.stored(f"{pref} pre-BN output Z", self.ws_act(wn + ".Z", C_, model), z)
+        elif self.s16:
+            self.judge_stored(f"{pref} pre-BN output Z", self.ws_act(wn + ".Z", C_, model), z, 1e-6)
+        else:
+            self.judge(f"{pref} pre-BN output Z", self.ws_act(wn + ".Z", C_, model), z, 1e-5)
         if f"{pref}.bn.gamma" in self.P:
             self.fwd_stats(pref, wn, block, z, self.M, model)
         return z
@@ -286,7 +319,7 @@ class Forced:
         arg = self.ws(mwn + ".arg", torch.int32).long().view(B, 1024)
         gfeat = self.ws(mwn + ".g").view(B, 1024)
         hs = dG.view(B, 1024) * (gfeat > 0)
-        self.judge(f"{pref} hs = dG [g > 0]", self.ws(mwn + ".hs"), hs, 1e-5)
+        self.judge(f"{pref} hs = scale dG [g > 0]", self.ws(mwn + ".hs"), hs * self.ws(cwn + ".scale"), 1e-5)
         batch = self.bn_batch(block)
         zst = torch.stack([zs[b].gather(0, arg[b].unsqueeze(0)).squeeze(0) for b in range(B)])
         zh_st = (zst - mean) * inv
@@ -329,7 +362,7 @@ class Forced:
                 d = d + addend
             if mask is not None:
                 d = d * mask
-            self.judge(f"{pref} -> d(BN output) of the layer below ({pwn}.dy)", self.ws_act(pwn + ".dy", pC), d, self.t_dy)
+            self.stored(f"{pref} -> d(BN output) of the layer below ({pwn}.dy)", self.ws_act(pwn + ".dy", pC), d, bwd=True)
         return dzq
 
     # ---------------------------------------------------------------- the whole step
@@ -339,7 +372,7 @@ class Forced:
         # ---- forward ----
         pcn_ref, _ = O.normalize(self.pc.double())
         pcn = self.ws("pcn").view(M, 3)
-        self.judge("normalised cloud (PointCloudNormalization)", pcn, pcn_ref, 1e-5)
+        self.judge("normalised cloud (PointCloudNormalization)", pcn, pcn_ref, 2e-5)       # fp32 sums over N points; values <= 1
         zs = {}
         if not van:
             self.fwd_conv("input_transform.conv1", "iT.c1", "input_transform", pcn, P["input_transform.conv1.kernel"], quant_w=False)
@@ -372,7 +405,7 @@ class Forced:
             self.judge("feature transform R_64", self.ws("fT.R"), R64, 1e-4)
             R64g = self.ws("fT.R").view(B, 64, 64)
             x64_ref = torch.einsum("bnk,bkc->bnc", a12.view(B, N, 64), self.qa(R64g)).reshape(M, 64)
-            self.judge("X_64 = relu(bn(mlp_1_2)) . R_64", self.ws_act("X64", 64), x64_ref, self.t_z)
+            self.stored("X_64 = relu(bn(mlp_1_2)) . R_64", self.ws_act("X64", 64), x64_ref)
             x64 = self.qa(self.ws_act("X64", 64))
         else:
             x64 = a12
@@ -455,7 +488,7 @@ class Forced:
                 self.judge("grad mlp_seg_5.bias", self.G["mlp_seg_5.bias"], dls.sum(0), 1e-3)
             _, mask_s4 = self.lazy("s4", 128)
             d4 = (dls @ P["mlp_seg_5.kernel"].t()) * mask_s4
-            self.judge("seg_l5 -> d(BN output) of seg_l4 (s4.dy)", self.ws_act("s4.dy", 128), d4, self.t_dy)
+            self.stored("seg_l5 -> d(BN output) of seg_l4 (s4.dy)", self.ws_act("s4.dy", 128), d4, bwd=True)
             self.conv_bwd("mlp_seg_4", "s4", "mlp_seg_4", a3, ("s3", 128, mask_s3, None))
             self.conv_bwd("mlp_seg_3", "s3", "mlp_seg_3", a2, ("s2", 256, mask_s2, None))
             self.conv_bwd("mlp_seg_2", "s2", "mlp_seg_2", a1, ("s1", 512, mask_s1, None))
@@ -483,9 +516,9 @@ class Forced:
         if dx64_seg is not None:
             dx = dx + dx64_seg
         if van:
-            self.judge("d(BN output) of mlp_1_2 (m12.dy)", self.ws_act("m12.dy", 64), dx * mask12, self.t_dy)
+            self.stored("d(BN output) of mlp_1_2 (m12.dy)", self.ws_act("m12.dy", 64), dx * mask12, bwd=True)
         else:
-            self.judge("d(X_64) = mlp_2_1 part + segmentation part", self.ws_act("dX64", 64), dx, self.t_dy)
+            self.stored("d(X_64) = mlp_2_1 part + segmentation part", self.ws_act("dX64", 64), dx, bwd=True)
             dxg = self.qa(self.ws_act("dX64", 64))
             dR = torch.einsum("bnk,bnc->bkc", a12.view(B, N, 64), dxg.view(B, N, 64))
             # feature transform: X_64 = A_12 . R_64 -> dR_64 = A_12^T dX_64 per cloud, dA_12 = dX_64 . R_64^T
@@ -494,13 +527,13 @@ class Forced:
                 dR = dR + 1e-3 * 2 * ((Rm @ Rm.transpose(1, 2) - torch.eye(64, dtype=torch.float64)) @ Rm)
             self.judge("d(R_64) = A_12^T dX_64 per cloud (+ regulariser)", self.ws("fT.dR"), dR, self.t_wg)
             tmp = torch.einsum("bnc,bkc->bnk", dxg.view(B, N, 64), self.qa(R64g)).reshape(M, 64)
-            self.judge("dX_64 . R_64^T (tmpA12)", self.ws_act("tmpA12", 64), tmp, self.t_dy)
+            self.stored("dX_64 . R_64^T (tmpA12)", self.ws_act("tmpA12", 64), tmp, bwd=True)
             self.tnet_bwd("feature_transform", "fT", 64, zs["fT"], a12)
             dzf1q, _ = self.bn_bwd_coeffs("feature_transform.conv1", "fT.c1", "feature_transform")
             if self.tr.get("feature_transform", True):
                 self.judge("grad feature_transform.conv1.kernel", self.G["feature_transform.conv1.kernel"], a12.t() @ dzf1q, self.t_wg)
             d12 = (dzf1q @ self.qa(P["feature_transform.conv1.kernel"]).t() + self.ws_act("tmpA12", 64)) * mask12
-            self.judge("d(BN output) of mlp_1_2 (m12.dy): T-Net path + transform path", self.ws_act("m12.dy", 64), d12, self.t_dy)
+            self.stored("d(BN output) of mlp_1_2 (m12.dy): T-Net path + transform path", self.ws_act("m12.dy", 64), d12, bwd=True)
         _, a11m = self.lazy("m11", 64)
         self.conv_bwd("mlp_1_2", "m12", "mlp_1_2", a11, ("m11", 64, a11m, None))
         _, dz11 = self.bn_bwd_coeffs("mlp_1_1", "m11", "mlp_1_1")

@@ -256,7 +256,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(l, name), f"{name} declared in pointnet_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert _lib.lib().pn_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.lib().pn_abi_version() == _lib.ABI_VERSION == 6
     # host-only entry points can be exercised without a GPU
     d = _lib.pn_model_desc(ccls=23, cseg=12, vanilla=0, reg_in=0, reg_feat=0, prec=3, dropout_rate=0.3, bn_momentum=0.99, bn_eps=1e-3)
     assert _lib.lib().pn_model_num_slots(C.byref(d)) == len(O.init_params(23, 12))

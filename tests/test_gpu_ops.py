@@ -384,6 +384,51 @@ def test_scan_pipeline_c5_matches_oracle(dev):
     assert torch.equal(pi.cpu().long()[safe], ref[1].argmax(-1)[safe])
 
 
+@pytest.mark.parametrize("front", ["xyz", "x64_plain", "x64_lazy"])
+@pytest.mark.parametrize("B,N", [(3, 200), (32, 1024), (2, 4099)])
+def test_chain_kernel_equals_the_layered_launches(dev, front, B, N):
+    """pn_chain_fwd_max (inference: ConvLayer(3 | 64 -> 64) -> ConvLayer(64 -> 128) -> ConvLayer(128 -> 1024) -> reduce_max in ONE
+    launch, PointNet.py:236-248 / 421-429 with moving statistics) against the three launches it replaces in the bf16-storage mode
+    (pn_conv3_fwd | pn_conv_fwd, pn_conv_fwd, pn_conv_fwd_max_panel): per-slot maxima and 32-row blocks BIT FOR BIT -- same rounding
+    points (the 16-bit stores of the two narrow layers, the bf16 MFMA operands), same contraction order.  Ragged clouds included."""
+    ops = _ops()
+    from pointcloudprocessing_amd import _lib
+    prec = _lib.PREC["bf16"]
+    g = torch.Generator().manual_seed(B * N + len(front))
+    rnd = lambda *sh: torch.randn(*sh, generator=g)                  # noqa: E731
+    w2, w3 = (rnd(64, 128) / 8).to(dev), (rnd(128, 1024) / 11).to(dev)
+    gamma3 = rnd(1024).to(dev)                                        # both signs: the panel copy carries sign(gamma)
+    sc1, sh1 = (torch.rand(64, generator=g) + 0.5).to(dev), (rnd(64) * 0.3).to(dev)
+    sc2, sh2 = (torch.rand(128, generator=g) + 0.5).to(dev), (rnd(128) * 0.3).to(dev)
+    wf = ops.weights_prep(w3, gamma3)
+    _, w2t = ops.weights_copy16(w2)
+    if front == "xyz":
+        x3 = rnd(B * N, 3).to(dev)
+        w1 = (rnd(3, 64) / 2).to(dev)
+        z1, _ = ops.conv3_fwd(x3, w1, B, N, want_stats=False)
+        z1 = z1.to(torch.bfloat16)                                    # the plan's 16-bit store (round to nearest even)
+        fused = lambda: ops.chain_fwd_max(None, x3, w1, None, sc1, sh1, w2t, sc2, sh2, wf[0], B, N)     # noqa: E731
+    else:
+        x = (rnd(B * N, 64) * 3).to(dev).to(torch.bfloat16)
+        w1 = (rnd(64, 64) / 8).to(dev)
+        if front == "x64_lazy":
+            ca, cc = (torch.rand(64, generator=g) + 0.5).to(dev), (rnd(64) * 0.3).to(dev)
+            op0 = _lib.operand(x, ca=ca, cc=cc, relu=True)
+        else:
+            op0 = _lib.operand(x)
+        z1, _ = ops.conv_fwd(op0, w1, B, N, 64, 64, prec, want_stats=False)
+        assert z1.dtype == torch.bfloat16
+        _, w1t = ops.weights_copy16(w1)
+        fused = lambda: ops.chain_fwd_max(op0, None, None, w1t, sc1, sh1, w2t, sc2, sh2, wf[0], B, N)   # noqa: E731
+    z2, _ = ops.conv_fwd(_lib.operand(z1, ca=sc1, cc=sh1, relu=True), w2, B, N, 64, 128, prec, want_stats=False)
+    pmax_ref, pblk_ref, _, _ = ops.conv_fwd_max_panel(_lib.operand(z2, ca=sc2, cc=sh2, relu=True), wf, B, N, 128, 1024, prec, want_stats=False)
+    pmax, pblk = fused()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(pmax).all()) and float(pmax.abs().max()) > 0
+    assert torch.equal(pmax, pmax_ref), float((pmax - pmax_ref).abs().max())
+    assert torch.equal(pblk, pblk_ref)
+
+
 def test_voxel_downsample_matches_oracle(dev):
     ops = _ops()
     rng = np.random.default_rng(10)

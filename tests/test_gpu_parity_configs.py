@@ -81,11 +81,11 @@ def test_inference_at_baseline_size(dev, name, B, N, vanilla, precision):
     e = [float((cls - ref[0]).abs().max()), float((seg - ref[1]).abs().max()), float((R - ref[2]).abs().max())]
     rms = [float((cls - ref[0]).pow(2).mean().sqrt()), float((seg - ref[1]).pow(2).mean().sqrt())]
     report(f"inference {name} {precision} B={B} N={N}: max abs err cls {e[0]:.3e} seg {e[1]:.3e} R {e[2]:.3e}; RMS cls {rms[0]:.3e} seg {rms[1]:.3e}")
-    # fp32-grade mode: north_star's 1e-3 with two orders of margin.  bf16 mode (bf16 MFMA operands, bf16 layer-boundary tensors): the
-    # fp64 oracle ITSELF moves by 1.6e-4 (class) / 1.3e-3 (part) / 1.0e-3 (R) at B=32, N=1024 when its operands are rounded the same
-    # way (oracle A vs B, measured on the CPU), so the class probabilities meet 1e-3 and the worst of the B*N*12 part probabilities
-    # and R sit at 1-2e-3: stated tolerances 1e-3 / 3e-3 / 2e-3, RMS of the part probabilities below 3e-4
-    t_cls, t_seg, t_R, t_rms = (1e-3, 3e-3, 2e-3, 3e-4) if precision == "bf16" else (5e-5, 5e-5, 5e-5, 5e-6)
+    # north_star's 1e-3 holds in BOTH modes.  Measured (round 3, gpurun_out/model_report.txt): bf16x3 6e-7 / 1.6e-6 / 7e-6 (class / part /
+    # R); bf16 (bf16 MFMA operands AND bf16 layer-boundary tensors) 1.0e-4 / 8.4e-4 / 9.0e-4, RMS of the part probabilities 1.3e-4 --
+    # the fp64 oracle itself moves by about as much when its operands are rounded the same way (oracle A vs B on the CPU: 1.6e-4 / 1.3e-3
+    # / 1.0e-3).  R is a 3x3 matrix with entries of order 1, not a probability: its bf16 tolerance is 1.5e-3.
+    t_cls, t_seg, t_R, t_rms = (1e-3, 1e-3, 1.5e-3, 3e-4) if precision == "bf16" else (2e-5, 2e-5, 2e-5, 2e-6)
     assert e[0] < t_cls and e[1] < t_seg and e[2] < t_R and rms[1] < t_rms, (name, precision, e, rms)
     assert torch.equal(cls.argmax(-1), ref[0].argmax(-1)) and torch.equal(ci.cpu().long(), ref[0].argmax(-1))
     top2 = ref[1].topk(2, dim=-1).values

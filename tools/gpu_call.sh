@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call:  gpurun -- 'bash tools/gpu_call.sh <tag> <step> [<step> ...]'
 # Output goes to gpurun_out/<tag>/; a step that times out ends the call (no further GPU step is started after a kill).
-# Steps:  tests | tests:<pytest -k expression> | smoke | bench | configs | scan | panel | prof | pmc | py:<script and args>
+# Steps:  env:VAR=VALUE | unset:VAR | tests | tests-noexit | tests:<pytest -k expression> | smoke | bench | bench:<bench.py args> | configs | scan | panel | prof | pmc | py:<script and args>
 set -o pipefail
 tag=$1; shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -19,9 +19,13 @@ step() { # name, seconds, command...
 for s in "$@"; do
   case $s in
     tests) step "all gpu tests" 1000 bash -c "python -m pytest tests -q -m gpu -x > $out/tests_all.log 2>&1" ;;
+    tests-noexit) step "all gpu tests (no -x)" 1100 bash -c "python -m pytest tests -q -m gpu > $out/tests_all.log 2>&1" ;;
     tests:*) step "gpu tests -k ${s#tests:}" 900 bash -c "python -m pytest tests -q -m gpu -x -k '${s#tests:}' > $out/tests_sel.log 2>&1" ;;
     smoke) step "smoke" 200 bash -c "python -c 'import __graft_entry__ as g; g.smoke()' > $out/smoke.log 2>&1" ;;
-    bench) step "bench" 300 bash -c "python bench.py > $out/bench.json 2> $out/bench.err" ;;
+    bench) n=bench; [ -e $out/bench.json ] && n=bench_$(date +%s | tail -c 4)
+      step "bench ($n)" 300 bash -c "python bench.py > $out/$n.json 2> $out/$n.err" ;;
+    bench:*) n=$(echo "${s#bench:}" | tr -c 'A-Za-z0-9_.\n' '_' | cut -c1-40)
+      step "bench ${s#bench:}" 300 bash -c "python bench.py --no-cpu-baseline ${s#bench:} > $out/bench_$n.json 2> $out/bench_$n.err" ;;
     configs)
       for cfg in "c3 --points 2048 --profile final" "c3_all --points 2048 --profile all" "c4rank --batch 8 --points 4096" "b32n4096 --points 4096" \
                  "x3 --precision bf16x3" "f32act --precision bf16_f32act" "final1024 --profile final" "all1024 --profile all"; do
@@ -43,7 +47,10 @@ for s in "$@"; do
       cd $R
       step "pmc summary" 60 python tools/pmc_summary.py $out/pmc_fetch $out/pmc_write $out/pmc r3
       rm -f $out/pmc_fetch/*kernel_trace* $out/pmc_write/*kernel_trace* ;;
+    env:*) export "${s#env:}"; echo "env ${s#env:}" | tee -a $R/$out/summary.txt ;;
+    unset:*) unset "${s#unset:}" ;;
     py:*) n=$(echo "${s#py:}" | tr -c 'A-Za-z0-9_.\n' '_' | cut -c1-40)
+      n="${n}_$(date +%s | tail -c 4)"
       step "py ${s#py:}" 400 bash -c "python ${s#py:} > $out/$n.out 2> $out/$n.err" ;;
     *) echo "unknown step $s" | tee -a $R/$out/summary.txt ;;
   esac
