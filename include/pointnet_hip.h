@@ -322,6 +322,11 @@ typedef struct pn_model_desc {
   float dropout_rate; /* PointNet.py:88 (0.3 in pointnet_train.py:301) */
   float bn_momentum;  /* 0.99 (PointNet.py:502) */
   float bn_eps;       /* 1e-3 (keras default)   */
+  /* Synchronised BatchNormalization (data parallel, numerics-parity mode): the number of ranks whose batches form ONE batch for every
+   * training-mode BatchNormalization (0 or 1: off -- each rank normalises with the statistics of its own clouds, standard DDP).
+   * The reference computes the statistics over the whole batch on one device (PointNet.py:528,559,623,647); with sync_world = W a step
+   * on W ranks of B clouds each is the reference's step on the B*W clouds: see pn_model_io.sync_hook.  Sizes the workspace. */
+  int32_t sync_world;
 } pn_model_desc;
 
 /* one named range of the flat parameter buffer.  kind: 0 kernel, 1 gamma, 2 beta, 3 moving_mean,
@@ -383,6 +388,22 @@ typedef struct pn_model_io {
    * included -- instead of taking them as inputs.  dropout_step: device uint32 counter; NULL = the masks are inputs. */
   uint64_t dropout_seed;
   uint32_t* dropout_step;
+  /* Synchronised BatchNormalization (pn_model_desc.sync_world = W > 1, training only).  The plan calls sync_hook wherever a quantity
+   * has to be formed over all W ranks, between two of its launches, on `stream`:
+   *   op 0 (all-reduce): dst[0..n) = sum over the ranks of src[0..n)        (src may equal dst)
+   *   op 1 (all-gather): dst[rank r][0..n) = rank r's src[0..n), r = 0..W-1  (src may be dst + sync_rank * n)
+   * dtype 0 = float32, 1 = int64.  The hook must order the collective after everything enqueued on `stream` so far and make its
+   * result visible to what is enqueued next (a synchronous collective on the stream; torch.distributed does).  Returns 0 on success.
+   * What is exchanged: the per-tile BatchNormalization partial sums of every per-point layer, forward and backward (summed); the
+   * pooled features, the T-Nets' output gradients and the classification logits' gradients (gathered: the per-cloud dense layers then
+   * run on all B*W rows on every rank, so their batch statistics are the whole batch's by construction).  Conventions the caller keeps:
+   * the fused loss weights are divided by W (every rank seeds the gradient of the GLOBAL mean loss); keep1 / keep2 hold B*W rows, the
+   * same on every rank; gradients are then SUMMED over the ranks with grad_scale 1, after the slots every rank computed in full (all
+   * bn.gamma / bn.beta, the dense layers' kernels and bias, the T-Nets' w / b) have been zeroed on every rank but one. */
+  int32_t sync_rank;
+  int32_t pad3_;
+  int (*sync_hook)(void* ctx, int op, const void* src, void* dst, int64_t n, int dtype, void* stream);
+  void* sync_ctx;
 } pn_model_io;
 
 int pn_model_num_slots(const pn_model_desc* d);

@@ -51,7 +51,7 @@ class pn_dense_wgrad_job(C.Structure):
 class pn_model_desc(C.Structure):
     _fields_ = [("ccls", C.c_int32), ("cseg", C.c_int32), ("vanilla", C.c_int32), ("reg_in", C.c_int32),
                 ("reg_feat", C.c_int32), ("prec", C.c_int32), ("dropout_rate", C.c_float),
-                ("bn_momentum", C.c_float), ("bn_eps", C.c_float)]
+                ("bn_momentum", C.c_float), ("bn_eps", C.c_float), ("sync_world", C.c_int32)]
 
 
 class pn_slot_info(C.Structure):
@@ -67,7 +67,12 @@ class pn_model_io(C.Structure):
                 ("pad2_", C.c_float), ("out_cls", C.c_void_p), ("out_seg", C.c_void_p), ("out_R", C.c_void_p),
                 ("scalars", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 ("prof_events", C.POINTER(C.c_void_p)), ("aux_stream", C.c_void_p),
-                ("bwd_phase", C.c_int32), ("flags", C.c_int32), ("dropout_seed", C.c_uint64), ("dropout_step", C.c_void_p)]
+                ("bwd_phase", C.c_int32), ("flags", C.c_int32), ("dropout_seed", C.c_uint64), ("dropout_step", C.c_void_p),
+                ("sync_rank", C.c_int32), ("pad3_", C.c_int32), ("sync_hook", C.c_void_p), ("sync_ctx", C.c_void_p)]
+
+
+# pn_model_io.sync_hook: int (*)(void* ctx, int op, const void* src, void* dst, int64_t n, int dtype, void* stream)
+SYNC_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p)
 
 
 # every symbol include/pointnet_hip.h declares: name -> (restype, argtypes)

@@ -131,6 +131,7 @@ struct CL {   // per-point conv layer state
 };
 struct ML {   // extra state of a max-pooled layer
   long long* pa1;
+  float *g_all = nullptr, *zstar_all = nullptr;   // synchronised BatchNormalization: the pooled features / pre-BN maxima of ALL ranks' clouds
   float *pmax, *sumsq, *g, *zstar, *hs, *e, *nege, *f, *a1part, *a1, *gram, *GW, *Pm, *q, *D, *Wt, *We, *dG;
   int *pq, *argq, *arg;            // per tile: 32-row block of the maximum; per cloud: the same after the reduction; the row (backward)
   unsigned short *wb_hi, *wb_lo;   // fragment-ordered bf16 copies of the kernel for the panel kernel (pn_panel.hip)
@@ -155,6 +156,7 @@ struct WS {
   DLs c1, c2, c3;
   float *Weff1, *dWeff1, *X64, *dX64, *tmpA12, *gb, *dgb, *dGseg, *dGcls;
   float *cls_logits, *cls_dlogits, *seg_dlogits, *seg_part, *dense_part, *slabs, *slabs_main, *bpart, *s5slab, *R3eye, *regpart;
+  float* sync_part = nullptr;
   size_t slab_floats, slab_main_floats;
   float* slab_pool;          // slabs of the parameter-gradient jobs whose reduction is deferred to the end of the (phase of the) pass
   size_t slab_pool_floats;
@@ -213,8 +215,9 @@ static void plan_cl(Arena& A, CL& l, const char* nm, long long M, int T, int C, 
   }
 }
 
-static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, int T, int K, int C, bool training, int prec) {
+static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, int T, int K, int C, bool training, int prec, int W = 1) {
   std::string n(nm);
+  const int Bd = B * W;                            // rows of the per-cloud tensors that feed / come back from the dense layers
   const bool s16 = (prec & PN_STORE_BF16) != 0;
   m.rows = 64;
   m.tpc64 = panel_slots_per_cloud(B, N);   // slots (workgroups) per cloud of the panel kernel; never more than ceil(N / 64)
@@ -229,8 +232,12 @@ static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, 
   m.g = A.get<float>((n + ".g").c_str(), (size_t)B * C);
   m.zstar = A.get<float>((n + ".zstar").c_str(), (size_t)B * C);
   m.arg = A.get<int>((n + ".arg").c_str(), (size_t)B * C);
+  if (W > 1) {
+    m.g_all = A.get<float>((n + ".g_all").c_str(), (size_t)Bd * C);
+    m.zstar_all = A.get<float>((n + ".zstar_all").c_str(), (size_t)Bd * C);
+  }
   if (training) {
-    m.hs = A.get<float>((n + ".hs").c_str(), (size_t)B * C);
+    m.hs = A.get<float>((n + ".hs").c_str(), (size_t)Bd * C);
     m.e = A.get<float>((n + ".e").c_str(), C);
     m.nege = A.get<float>((n + ".nege").c_str(), C);
     m.f = A.get<float>((n + ".f").c_str(), C);
@@ -243,7 +250,7 @@ static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, 
     m.D = plan_act(A, n + ".D", (size_t)M * K, s16);
     m.Wt = A.get<float>((n + ".Wt").c_str(), (size_t)K * C);
     m.We = A.get<float>((n + ".We").c_str(), (size_t)K * C);
-    m.dG = A.get<float>((n + ".dG").c_str(), (size_t)B * C);
+    m.dG = A.get<float>((n + ".dG").c_str(), (size_t)Bd * C);
   }
 }
 static void plan_dl(Arena& A, DLs& d, const char* nm, int B, int K, int C, bool training) {
@@ -258,54 +265,58 @@ static void plan_dl(Arena& A, DLs& d, const char* nm, int B, int K, int C, bool 
     d.din = A.get<float>((n + ".din").c_str(), (size_t)B * K);
   }
 }
-static void plan_tn(Arena& A, TN& t, const char* nm, int B, int N, long long M, int T, int K, bool training, int prec) {
+static void plan_tn(Arena& A, TN& t, const char* nm, int B, int N, long long M, int T, int K, bool training, int prec, int W = 1) {
   std::string n(nm);
+  const int Bd = B * W;
   const bool s16 = (prec & PN_STORE_BF16) != 0;
   plan_cl(A, t.c1, (n + ".c1").c_str(), M, T, 64, true, training, s16, K == 64 ? 64 : 0);
   plan_cl(A, t.c2, (n + ".c2").c_str(), M, T, 128, true, training, s16, 64);
   plan_cl(A, t.c3, (n + ".c3").c_str(), M, 1, 1024, false, training, s16);            // statistics live in the panel buffers (plan_ml)
-  plan_ml(A, t.m3, (n + ".m3").c_str(), B, N, M, T, 128, 1024, training, prec);
-  plan_dl(A, t.d1, (n + ".d1").c_str(), B, 1024, 512, training);
-  plan_dl(A, t.d2, (n + ".d2").c_str(), B, 512, 256, training);
-  t.R = A.get<float>((n + ".R").c_str(), (size_t)B * K * K);
+  plan_ml(A, t.m3, (n + ".m3").c_str(), B, N, M, T, 128, 1024, training, prec, W);
+  plan_dl(A, t.d1, (n + ".d1").c_str(), Bd, 1024, 512, training);
+  plan_dl(A, t.d2, (n + ".d2").c_str(), Bd, 512, 256, training);
+  t.R = A.get<float>((n + ".R").c_str(), (size_t)Bd * K * K);
   if (training) {
-    t.dR = A.get<float>((n + ".dR").c_str(), (size_t)B * K * K);
-    t.da2 = A.get<float>((n + ".da2").c_str(), (size_t)B * 256);
+    t.dR = A.get<float>((n + ".dR").c_str(), (size_t)Bd * K * K);
+    t.da2 = A.get<float>((n + ".da2").c_str(), (size_t)Bd * 256);
   }
 }
 
 static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool training) {
   const long long M = (long long)B * N;
   const int T = B * cdiv(N, 128);
+  const int W = (training && d.sync_world > 1) ? d.sync_world : 1;     // synchronised BatchNormalization: the dense side holds every rank's rows
+  const int Bd = B * W;
   const bool s16 = (d.prec & PN_STORE_BF16) != 0;
   w.pcn = A.get<float>("pcn", (size_t)M * 3);
   w.cent = A.get<float>("centroid", (size_t)B * 3);
   w.scl = A.get<float>("scale", B);
   if (!d.vanilla) {
-    plan_tn(A, w.iT, "iT", B, N, M, T, 3, training, d.prec);
-    plan_tn(A, w.fT, "fT", B, N, M, T, 64, training, d.prec);
+    plan_tn(A, w.iT, "iT", B, N, M, T, 3, training, d.prec, W);
+    plan_tn(A, w.fT, "fT", B, N, M, T, 64, training, d.prec, W);
   }
   plan_cl(A, w.m11, "m11", M, T, 64, true, training, s16);
   plan_cl(A, w.m12, "m12", M, T, 64, true, training, s16, 64);
   plan_cl(A, w.m21, "m21", M, T, 64, true, training, s16, 64);
   plan_cl(A, w.m22, "m22", M, T, 128, true, training, s16, 64);
   plan_cl(A, w.m23, "m23", M, 1, 1024, false, training, s16);                            // statistics live in the panel buffers (plan_ml)
-  plan_ml(A, w.mm23, "mm23", B, N, M, T, 128, 1024, training, d.prec);
+  plan_ml(A, w.mm23, "mm23", B, N, M, T, 128, 1024, training, d.prec, W);
   plan_cl(A, w.s1, "s1", M, T, 512, true, training, s16, 64);      // the 64 per-point rows of seg_l1's (1088, 512) kernel
   plan_cl(A, w.s2, "s2", M, T, 256, true, training, s16, 512);
   plan_cl(A, w.s3, "s3", M, T, 128, true, training, s16, 256);
   plan_cl(A, w.s4, "s4", M, T, 128, true, training, s16, 128);
-  plan_dl(A, w.c1, "c1", B, 1024, 512, training);
-  plan_dl(A, w.c2, "c2", B, 512, 256, training);
-  plan_dl(A, w.c3, "c3", B, 256, d.ccls, training);
+  plan_dl(A, w.c1, "c1", Bd, 1024, 512, training);
+  plan_dl(A, w.c2, "c2", Bd, 512, 256, training);
+  plan_dl(A, w.c3, "c3", Bd, 256, d.ccls, training);
   w.Weff1 = A.get<float>("Weff1", (size_t)B * 3 * 64);
   w.X64 = d.vanilla ? nullptr : plan_act(A, "X64", (size_t)M * 64, s16);
-  w.gb = A.get<float>("gb", (size_t)B * 512);
-  w.cls_logits = A.get<float>("cls_logits", (size_t)B * d.ccls);
+  w.gb = A.get<float>("gb", (size_t)Bd * 512);
+  w.cls_logits = A.get<float>("cls_logits", (size_t)Bd * d.ccls);
+  w.sync_part = W > 1 ? A.get<float>("sync_part", (size_t)T * 2 * 512) : nullptr;      // all-reduced copy of a layer's per-tile partial sums
   // per 128-row block of seg_out_fwd, or per 64-row tile of the fused frozen head (never straddling clouds)
   w.seg_part = A.get<float>("seg_part", (size_t)std::max<long long>(cdivll(M, seg_out_part_rows()), (long long)B * cdiv(N, seg_head_fused_rows())) *
                                             seg_out_part_stride());
-  w.dense_part = A.get<float>("dense_part", (size_t)8 * B * 4096);          // split-K tiles of the dense layers (<= 8 splits)
+  w.dense_part = A.get<float>("dense_part", (size_t)8 * Bd * 4096);         // split-K tiles of the dense layers (<= 8 splits)
   // their in-launch arrival counters, followed by the three max-pooled layers' column-sum accumulators (B x 256 64-bit words each):
   // ONE block, cleared by the step's first launch
   w.dcount = A.get<unsigned>("dcount", DENSE_MAX_COUNTERS + 3 * (size_t)B * 512);
@@ -326,9 +337,9 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
     w.dX64 = plan_act(A, "dX64", (size_t)M * 64, s16);
     w.tmpA12 = plan_act(A, "tmpA12", (size_t)M * 64, s16);
     w.dgb = A.get<float>("dgb", (size_t)B * 512);
-    w.dGseg = A.get<float>("dGseg", (size_t)B * 1024);
-    w.dGcls = A.get<float>("dGcls", (size_t)B * 1024);
-    w.cls_dlogits = A.get<float>("cls_dlogits", (size_t)B * d.ccls);
+    w.dGseg = A.get<float>("dGseg", (size_t)Bd * 1024);
+    w.dGcls = A.get<float>("dGcls", (size_t)Bd * 1024);
+    w.cls_dlogits = A.get<float>("cls_dlogits", (size_t)Bd * d.ccls);
     w.seg_dlogits = A.get<float>("seg_dlogits", (size_t)M * d.cseg);
     w.bpart = A.get<float>("bpart", (size_t)T * 2 * 512);
     w.s5slab = A.get<float>("s5slab", (size_t)T * 128 * d.cseg);
@@ -375,6 +386,18 @@ struct Run {
   Layout L;
   WS w;
   int B, N, T, tpc, prec;      // prec: PN_PREC_* (| PN_STORE_BF16: what the per-point launchers are given)
+  // Synchronised BatchNormalization (pn_model_desc.sync_world, training): W ranks, this one is rk; the per-cloud dense layers run on
+  // the Bd = B * W rows of all ranks (gathered), every per-point statistic is summed over the ranks (pn_model_io.sync_hook)
+  int W = 1, rk = 0, Bd = 0;
+  template <class Tp> Tp* loc(Tp* all_rows, long long per_row) const { return all_rows ? all_rows + (long long)rk * B * per_row : nullptr; }
+  int sync_call(int op, const void* src, void* dst, long long n, int dtype) {
+    if (!io.sync_hook) { set_error("pn_model: sync_world > 1 needs pn_model_io.sync_hook"); return PN_ERR_INVALID_ARGUMENT; }
+    if (io.sync_hook(io.sync_ctx, op, src, dst, n, dtype, st) != 0) { set_error("pn_model: sync_hook failed (op %d, %lld elements)", op, n); return PN_ERR_LAUNCH; }
+    return PN_OK;
+  }
+  int sync_sum(const void* src, void* dst, long long n, int dtype = 0) { return W > 1 ? sync_call(0, src, dst, n, dtype) : (int)PN_OK; }
+  // local rows (n_local elements at all_rows + rk * n_local) -> every rank's rows, in place
+  int sync_gather_rows(float* all_rows, long long n_local) { return W > 1 ? sync_call(1, all_rows + (long long)rk * n_local, all_rows, n_local, 0) : (int)PN_OK; }
   int s16 = 0;                 // the per-point layer-boundary tensors (Z, dy, X64, dX64, D) are bf16
   long long M;
   hipStream_t st;
@@ -518,7 +541,13 @@ struct Run {
   int bn_fin(const CL& l, const LRef& r, int n_tiles = -1) {
     const int ub = bn_batch(r.block) ? 1 : 0;
     if (!ub) return PN_OK;       // moving statistics: the coefficients were written by the pass's first launch (fwd_prologue)
-    return bn_finalize(l.part, n_tiles < 0 ? T : n_tiles, r.cout, M, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub, ub, l.mean,
+    const int nt = n_tiles < 0 ? T : n_tiles;
+    const float* part = l.part;
+    if (W > 1) {                 // the tiles' sums of every rank, tile by tile (the rank's own partials stay: seg_l1's feed its backward)
+      PN_TRY(sync_sum(l.part, w.sync_part, (long long)nt * 2 * r.cout));
+      part = w.sync_part;
+    }
+    return bn_finalize(part, nt, r.cout, M * W, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub, ub, l.mean,
                        l.invstd, l.scale, l.shift, st);
   }
   int fwd_conv(CL& l, const LRef& r, const pn_operand& x, const float* W, long long wcs, const float* cloud_bias) {
@@ -532,10 +561,23 @@ struct Run {
     if (ev && ev[2 * prof_slot]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot]), st);
     PN_TRY(conv_fwd_max_panel(&x, m.wb_hi, m.wb_lo, B, N, r.cin, r.cout, m.pmax, m.pq, ub ? m.sumsq : nullptr, ub ? m.pa1 : nullptr, prec, st));
     if (ev && ev[2 * prof_slot + 1]) (void)hipEventRecord(reinterpret_cast<hipEvent_t>(ev[2 * prof_slot + 1]), st);
+    if (W > 1 && ub) {           // slot by slot / (cloud, column) by (cloud, column): the finaliser's sums then run over every rank's rows
+      PN_TRY(sync_sum(m.sumsq, m.sumsq, (long long)m.T64 * r.cout));
+      PN_TRY(sync_sum(m.pa1, m.pa1, (long long)B * r.cin * ((prec & ~PN_STORE_BF16) == PN_PREC_BF16X3 ? 2 : 1), 1));
+    }
     // one finaliser: the layer's BatchNormalization coefficients (+ moving statistics) and the reduce_max over each cloud's panels
-    return panel_finalize(m.pmax, m.pq, m.sumsq, m.pa1, m.wb_hi, m.wb_lo, prec, B, N, r.cin, r.cout, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub,
-                          ub, l.mean, l.invstd, l.scale, l.shift, m.g, m.zstar, m.argq, st);
+    PN_TRY(panel_finalize(m.pmax, m.pq, m.sumsq, m.pa1, m.wb_hi, m.wb_lo, prec, B, N, r.cin, r.cout, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub,
+                          ub, l.mean, l.invstd, l.scale, l.shift, W > 1 ? loc(m.g_all, r.cout) : m.g, W > 1 ? loc(m.zstar_all, r.cout) : m.zstar, m.argq, st, W));
+    if (W > 1) {                 // the dense layers behind the pool see every rank's clouds; the backward needs every rank's maxima
+      PN_TRY(sync_gather_rows(m.g_all, (long long)B * r.cout));
+      PN_TRY(sync_gather_rows(m.zstar_all, (long long)B * r.cout));
+    }
+    return PN_OK;
   }
+  // the pooled features as the layers behind them read them: this rank's clouds, or (synchronised BN) the rows of all ranks
+  const float* pooled(const ML& m) const { return W > 1 ? m.g_all : m.g; }
+  const float* pooled_local(const ML& m, int C) const { return W > 1 ? loc(m.g_all, C) : m.g; }
+  const float* zstar_local(const ML& m, int C) const { return W > 1 ? loc(m.zstar_all, C) : m.zstar; }
   // Inference (moving statistics everywhere): a max-pooled chain c1 -> c2 -> c3 + reduce_max as ONE launch (pn_panel.hip: chain_max_kernel),
   // bit-identical to the three launches it replaces.  bf16-storage mode only (it stages the prepared bf16 kernel copies and rounds
   // where that plan's stores round); not when the caller wants every layer's output kept (PN_IO_KEEP_ACTIVATIONS: check_numerics).
@@ -551,20 +593,20 @@ struct Run {
                           d.bn_momentum, d.bn_eps, 0, 0, c3.mean, c3.invstd, c3.scale, c3.shift, m.g, m.zstar, m.argq, st);
   }
   // out (B, C) = x (B, K) . W (+ bias): one launch (pn_dense.hip); trans reads W^T from the same (C, K)-major... kernel
-  int dense_plain(const float* x, int ldx, const float* W, int ldw, bool trans, int K, int C, const float* bias, float* out) {
-    return dense_layer(x, ldx, W, ldw, trans, B, K, C, w.dense_part, w.dcount, bias, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0,
+  int dense_plain(const float* x, int ldx, const float* Wk, int ldw, bool trans, int K, int C, const float* bias, float* out, int rows = -1) {
+    return dense_layer(x, ldx, Wk, ldw, trans, rows < 0 ? Bd : rows, K, C, w.dense_part, w.dcount, bias, nullptr, nullptr, nullptr, nullptr, 0.f, 0.f, 0, 0,
                        nullptr, 1.f, out, nullptr, nullptr, nullptr, st);
   }
   int fwd_dense(DLs& dl, const LRef& r, const float* x, int act, const unsigned char* keep) {
     const int mode = r.has_bn ? (bn_batch(r.block) ? 1 : 2) : 0;
     const float ks = 1.f / (1.f - d.dropout_rate);
-    return dense_layer(x, r.cin, p(r.kernel), r.cout, false, B, r.cin, r.cout, w.dense_part, w.dcount, p(r.bias), p(r.gamma), p(r.beta),
+    return dense_layer(x, r.cin, p(r.kernel), r.cout, false, Bd, r.cin, r.cout, w.dense_part, w.dcount, p(r.bias), p(r.gamma), p(r.beta),
                        p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, mode, act, keep, ks, dl.z, dl.a, dl.mean, dl.invstd, st);
   }
   int fwd_tnet(TN& t, const TRef& r, const pn_operand* x) {
     if (fused_chain(t.c2) && (r.K == 3 || t.c1.wt16)) {
       PN_TRY(fwd_chain(r.K == 3 ? nullptr : x, r.K == 3 ? p(r.c1.kernel) : nullptr, t.c1, t.c2, t.c3, t.m3, r.c3));
-      PN_TRY(fwd_dense(t.d1, r.d1, t.m3.g, 1, nullptr));
+      PN_TRY(fwd_dense(t.d1, r.d1, pooled(t.m3), 1, nullptr));
       PN_TRY(fwd_dense(t.d2, r.d2, t.d1.a, 1, nullptr));
       return dense_plain(t.d2.a, 256, p(r.w), r.K * r.K, false, 256, r.K * r.K, p(r.b), t.R);
     }
@@ -576,9 +618,9 @@ struct Run {
     }
     PN_TRY(fwd_conv(t.c2, r.c2, lazy(t.c1), p(r.c2.kernel), 0, nullptr));
     PN_TRY(fwd_max(t.c3, t.m3, r.c3, lazy(t.c2), r.K == 3 ? 0 : 1));
-    PN_TRY(fwd_dense(t.d1, r.d1, t.m3.g, 1, nullptr));
+    PN_TRY(fwd_dense(t.d1, r.d1, pooled(t.m3), 1, nullptr));
     PN_TRY(fwd_dense(t.d2, r.d2, t.d1.a, 1, nullptr));
-    return dense_plain(t.d2.a, 256, p(r.w), r.K * r.K, false, 256, r.K * r.K, p(r.b), t.R);
+    return dense_plain(t.d2.a, 256, p(r.w), r.K * r.K, false, 256, r.K * r.K, p(r.b), t.R);      // (Bd, K, K): this rank's clouds at loc(t.R, K * K)
   }
 
   pn_operand x64op() const { return d.vanilla ? lazy(w.m12) : plain_act(w.X64, 64); }
@@ -630,14 +672,14 @@ struct Run {
       const bool zg = training && G && io.zero_grads_in_forward;
       const bool dm = training && io.dropout_step && io.keep1 && io.keep2 && d.dropout_rate > 0.f;
       PN_TRY(fwd_prologue(io.pc, B, N, w.pcn, w.cent, w.scl, ws, sgs, Ks, Cs, his, los, w.dcount, DENSE_MAX_COUNTERS + 3 * B * 512, zg ? G : nullptr,
-                          zg ? L.total : 0, dm ? const_cast<unsigned char*>(io.keep1) : nullptr, dm ? (long long)B * 512 : 0,
-                          dm ? const_cast<unsigned char*>(io.keep2) : nullptr, dm ? (long long)B * 256 : 0, d.dropout_rate, io.dropout_seed,
+                          zg ? L.total : 0, dm ? const_cast<unsigned char*>(io.keep1) : nullptr, dm ? (long long)Bd * 512 : 0,
+                          dm ? const_cast<unsigned char*>(io.keep2) : nullptr, dm ? (long long)Bd * 256 : 0, d.dropout_rate, io.dropout_seed,
                           dm ? io.dropout_step : nullptr, wc, nwc, fz, nfz, d.bn_eps, st));
     }
     if (!d.vanilla) {
       PN_TRY(fwd_tnet(w.iT, L.iT, nullptr));
       // tf.matmul(pc, R) (PointNet.py:207) folded into mlp_1_1's kernel inside the launch; it also leaves W_eff and the third output
-      PN_TRY(conv3_fwd(w.pcn, p(L.m11.kernel), 0, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st, s16, w.iT.R, w.Weff1,
+      PN_TRY(conv3_fwd(w.pcn, p(L.m11.kernel), 0, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st, s16, loc(w.iT.R, 9), w.Weff1,
                        io.out_R));
     } else {
       PN_TRY(conv3_fwd(w.pcn, p(L.m11.kernel), 0, B, N, 64, w.m11.Z, bn_batch(BLK_M11) ? w.m11.part : nullptr, st, s16));
@@ -647,7 +689,7 @@ struct Run {
     if (!d.vanilla) {
       const pn_operand a12 = lazy(w.m12);
       PN_TRY(fwd_tnet(w.fT, L.fT, &a12));
-      PN_TRY(conv_fwd(&a12, w.fT.R, 4096, B, N, 64, 64, nullptr, w.X64, nullptr, prec, st));
+      PN_TRY(conv_fwd(&a12, loc(w.fT.R, 4096), 4096, B, N, 64, 64, nullptr, w.X64, nullptr, prec, st));
     }
     const pn_operand x64 = x64op();
     if (fused_chain(w.m22) && w.m21.wt16) {
@@ -657,13 +699,13 @@ struct Run {
       PN_TRY(fwd_conv(w.m22, L.m22, lazy(w.m21), p(L.m22.kernel), 0, nullptr));
       PN_TRY(fwd_max(w.m23, w.mm23, L.m23, lazy(w.m22), 2));
     }
-    const float* Gf = w.mm23.g;
+    const float* Gf = pooled(w.mm23);             // (Bd, 1024)
 
     // classification head (PointNet.py:252-263)
     {   // + in the same launch the global-feature half of seg_l1's kernel applied to the pooled vector (PointNet.py:268-275): w.gb
       const LRef& r = L.c1;
       const int mode = r.has_bn ? (bn_batch(r.block) ? 1 : 2) : 0;
-      PN_TRY(dense_layer_with_plain(Gf, r.cin, p(r.kernel), r.cout, B, r.cin, r.cout, w.dense_part, w.dcount, p(r.bias), p(r.gamma), p(r.beta),
+      PN_TRY(dense_layer_with_plain(Gf, r.cin, p(r.kernel), r.cout, Bd, r.cin, r.cout, w.dense_part, w.dcount, p(r.bias), p(r.gamma), p(r.beta),
                                     p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, mode, 1, training ? io.keep1 : nullptr,
                                     1.f / (1.f - d.dropout_rate), w.c1.z, w.c1.a, w.c1.mean, w.c1.invstd, p(L.s1.kernel) + 64 * 512, 512, w.gb,
                                     st));
@@ -678,13 +720,13 @@ struct Run {
     if (fused_seg_head()) {
       // frozen head, no gradient through it: one launch, activations stay on chip (pn_segout.hip: seg_head_fused)
       seg_parts = B * cdiv(N, seg_head_fused_rows());
-      PN_TRY(seg_head_fused(&x64, w.gb, w.s1.wt16, w.s2.wt16, w.s3.wt16, w.s4.wt16, w.s1.scale, w.s1.shift, w.s2.scale, w.s2.shift, w.s3.scale,
+      PN_TRY(seg_head_fused(&x64, loc(w.gb, 512), w.s1.wt16, w.s2.wt16, w.s3.wt16, w.s4.wt16, w.s1.scale, w.s1.shift, w.s2.scale, w.s2.shift, w.s3.scale,
                             w.s3.shift, w.s4.scale, w.s4.shift, p(L.s5.kernel), p(L.s5.bias), B, N, d.cseg, s16, io.labels_seg,
                             fseg ? io.loss_weights[1] / (float)M : 0.f, io.out_seg, nullptr, fseg ? w.seg_part : nullptr, st));
     } else {
     const float* Ws1 = p(L.s1.kernel);
     // seg_l1 always emits its forward partials: the backward needs the per-cloud sums of z
-    PN_TRY(conv_fwd(&x64, Ws1, 0, B, N, 64, 512, w.gb, w.s1.Z, w.s1.part, prec, st, w.s1.wt16));
+    PN_TRY(conv_fwd(&x64, Ws1, 0, B, N, 64, 512, loc(w.gb, 512), w.s1.Z, w.s1.part, prec, st, w.s1.wt16));
     PN_TRY(bn_fin(w.s1, L.s1));
     PN_TRY(fwd_conv(w.s2, L.s2, lazy(w.s1), p(L.s2.kernel), 0, nullptr));
     PN_TRY(fwd_conv(w.s3, L.s3, lazy(w.s2), p(L.s3.kernel), 0, nullptr));
@@ -700,21 +742,21 @@ struct Run {
       }
     }
     {   // one launch: classification softmax (+ loss, d logits), the segmentation loss / accuracy sums, the rotation loss value
-      const float* Rp = (io.se3 && io.scalars) ? (d.vanilla ? io.out_R : w.iT.R) : nullptr;
+      const float* Rp = (io.se3 && io.scalars) ? (d.vanilla ? io.out_R : loc(w.iT.R, 9)) : nullptr;
       const bool sums = fseg && io.scalars;
-      PN_TRY(loss_tail(w.cls_logits, B, d.ccls, io.labels_cls, fused ? io.loss_weights[0] / (float)B : 0.f, io.out_cls,
-                       (fused && training) ? w.cls_dlogits : nullptr, io.scalars ? io.scalars + 0 : nullptr,
+      PN_TRY(loss_tail(loc(w.cls_logits, d.ccls), B, d.ccls, io.labels_cls, fused ? io.loss_weights[0] / (float)B : 0.f, io.out_cls,
+                       (fused && training) ? loc(w.cls_dlogits, d.ccls) : nullptr, io.scalars ? io.scalars + 0 : nullptr,
                        io.scalars ? io.scalars + 1 : nullptr, sums ? w.seg_part : nullptr, sums ? seg_parts : 0,
                        seg_out_part_stride(), sums ? 2 : 0, sums ? io.scalars + 2 : nullptr, Rp, io.se3, B * 9, Rp ? io.scalars + 4 : nullptr,
                        st));
     }
     if (io.scalars && !d.vanilla) {
       if (d.reg_in) {
-        PN_TRY(orth_reg(w.iT.R, B, 3, 1e-3f, nullptr, w.regpart, st));
+        PN_TRY(orth_reg(loc(w.iT.R, 9), B, 3, 1e-3f, nullptr, w.regpart, st));
         PN_TRY(sum_partials(w.regpart, B, 1, 1, io.scalars + 5, st));
       }
       if (d.reg_feat) {
-        PN_TRY(orth_reg(w.fT.R, B, 64, 1e-3f, nullptr, w.regpart + B, st));
+        PN_TRY(orth_reg(loc(w.fT.R, 4096), B, 64, 1e-3f, nullptr, w.regpart + B, st));
         PN_TRY(sum_partials(w.regpart + B, B, 1, 1, io.scalars + 6, st));
       }
     }
@@ -768,7 +810,11 @@ struct Run {
   }
   int bn_bwd_fin(const CL& l, const LRef& r, const float* part) {
     const int bs = bn_batch(r.block) ? 1 : 0;
-    return bn_bwd_finalize(part, T, r.cout, M, p(r.gamma), l.mean, l.invstd, bs, bs ? gr(r.gamma) : nullptr, bs ? gr(r.beta) : nullptr,
+    if (W > 1 && bs) {           // sum dy_hat, sum dy_hat * z over every rank's rows (out of place: seg_l1's own partials feed cloud_bias_grad)
+      PN_TRY(sync_sum(part, w.sync_part, (long long)T * 2 * r.cout));
+      part = w.sync_part;
+    }
+    return bn_bwd_finalize(part, T, r.cout, M * W, p(r.gamma), l.mean, l.invstd, bs, bs ? gr(r.gamma) : nullptr, bs ? gr(r.beta) : nullptr,
                            l.ca, l.cb, l.cc, st);
   }
   // standard interior step: given cur.dy (+ w.bpart holding its stats) produce prev.dy and cur's weight gradient
@@ -791,11 +837,21 @@ struct Run {
     const bool wg = tr(r.block) && G;
     // + the channel-major copies Wt, We = -e (.) Wt used below, and -- in the same launch, on workgroups of their own -- the rows of
     // the maxima (m.argq, left by the forward pass, -> m.arg: pn_maxbwd.hip)
+    if (W > 1) {
+      // synchronised BN: dG / dG2 hold every rank's clouds (Bd rows), and so do the pooled maxima: hs for all of them, the batch terms
+      // e, f (and dgamma, dbeta) from the sums over ALL clouds; the rows of the maxima are resolved for this rank's clouds only
+      PN_TRY(maxbwd_prep(dG, dG2, m.g_all, m.zstar_all, Bd, C, l.mean, l.invstd, l.scale, bs, M * W, m.hs, m.e, m.nege, m.f, wg ? gr(r.gamma) : nullptr,
+                         wg ? gr(r.beta) : nullptr, p(r.kernel), K, m.Wt, m.We, st));
+      PN_TRY(max_resolve(&xop, m.wb_hi, m.wb_lo, prec, m.argq, B, N, K, C, m.arg, st));
+    } else {
     PN_TRY(maxbwd_prep_resolve(dG, dG2, m.g, m.zstar, B, C, l.mean, l.invstd, l.scale, bs, M, m.hs, m.e, m.nege, m.f, wg ? gr(r.gamma) : nullptr,
                                wg ? gr(r.beta) : nullptr, p(r.kernel), K, m.Wt, m.We, &xop, m.wb_hi, m.wb_lo, prec, m.argq, N, m.arg, st));
+    }
+    const float* hs_loc = W > 1 ? loc(m.hs, C) : m.hs;       // this rank's clouds
     // the parameter-gradient branch forks here: it needs m.arg, hs, e, f of the launch above and nothing of what follows
     if (wg) {
-      const ML mm = m;
+      ML mm = m;
+      mm.hs = const_cast<float*>(hs_loc);
       float* dw = gr(r.kernel);
       const float* Wk = p(r.kernel);
       // this whole branch feeds only dW: the Gram slabs are reduced with the other deferred jobs and the two consumers follow them
@@ -840,7 +896,7 @@ struct Run {
       PN_TRY(conv_wgrad_batch(&pmd, 1, st));
       PN_TRY(slab_reduce_q(sl, spc, (long long)K * K, m.Pm, p(r.kernel), m.f, K, C, m.q, st));
     }
-    PN_TRY(maxbwd_scatter(m.arg, m.hs, m.Wt, m.q, B, N, K, C, m.D, s16, st));
+    PN_TRY(maxbwd_scatter(m.arg, hs_loc, m.Wt, m.q, B, N, K, C, m.D, s16, st));
     PN_TRY(conv_bwd_data(&xop, m.Pm, 0, B, N, K, K, m.D, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st));
     return PN_OK;
   }
@@ -852,17 +908,18 @@ struct Run {
     float* dgam = (wg && mode == 1) ? gr(r.gamma) : nullptr;
     float* dbet = (wg && mode == 1) ? gr(r.beta) : nullptr;
     float* dbia = (wg && mode == 0) ? gr(r.bias) : nullptr;
-    if (B <= 32) {
+    if (Bd <= 32) {
       // dropout/relu/BN backward fused into the weight gradient: one launch
-      PN_TRY(dense_bwd_fused(da, dl.z, xin, r.cin, B, r.cin, r.cout, p(r.gamma), p(r.beta), dl.mean, dl.invstd, mode, act, keep, ks, dl.dz,
+      PN_TRY(dense_bwd_fused(da, dl.z, xin, r.cin, Bd, r.cin, r.cout, p(r.gamma), p(r.beta), dl.mean, dl.invstd, mode, act, keep, ks, dl.dz,
                              dgam, dbet, dbia, wg ? gr(r.kernel) : nullptr, st));
     } else {
-      PN_TRY(dense_bwd_pre(da, dl.z, B, r.cout, p(r.gamma), p(r.beta), dl.mean, dl.invstd, mode, act, keep, ks, dl.dz, dgam, dbet, dbia, st));
+      PN_TRY(dense_bwd_pre(da, dl.z, Bd, r.cout, p(r.gamma), p(r.beta), dl.mean, dl.invstd, mode, act, keep, ks, dl.dz, dgam, dbet, dbia, st));
       if (wg) {
         const float* dzp = dl.dz;
         float* out = gr(r.kernel);
         const int ci = r.cin, cj = r.cout;
-        PN_TRY(side([=] { return dense_wgrad(xin, ci, dzp, B, ci, cj, out, st); }));
+        const int rows = Bd;
+        PN_TRY(side([=] { return dense_wgrad(xin, ci, dzp, rows, ci, cj, out, st); }));
         PN_TRY(flush());
       }
     }
@@ -877,11 +934,11 @@ struct Run {
   // dbeta.  The weight gradients x^T . dz (and the top bias gradient) are nobody's input before the optimizer: collected in
   // dense_jobs, one launch per pass (flush_jobs).  Round 2's form took two launches per layer (dz + dW, then dx).
   struct ChainLayer { DLs* dl; const LRef* r; const float* xin; int act; const unsigned char* keep; };
-  bool chain_ok() const { return B <= 32; }      // (with or without an auxiliary stream: both step layouts must give the same bits)
+  bool chain_ok() const { return Bd <= 32; }      // (with or without an auxiliary stream: both step layouts must give the same bits)
   int bwd_chain(const float* dtop, int Ctop, const float* Wtop, const float* a_below_top, float* dWtop, float* dbtop, float* da_top,
                 ChainLayer* ls, int n, float* dx_out) {
     // top product: its own weight gradient is a plain job on dtop
-    if (dWtop) dense_jobs.push_back(DenseWgradJob{a_below_top, ls[0].r->cout, dtop, B, ls[0].r->cout, Ctop, dWtop, dbtop});
+    if (dWtop) dense_jobs.push_back(DenseWgradJob{a_below_top, ls[0].r->cout, dtop, Bd, ls[0].r->cout, Ctop, dWtop, dbtop});
     const float* dz_above = dtop;
     int c_above = Ctop;
     const float* w_above = Wtop;
@@ -900,32 +957,34 @@ struct Run {
       t.dgamma = (wg && mode == 1) ? gr(r.gamma) : nullptr;
       t.dbeta = (wg && mode == 1) ? gr(r.beta) : nullptr;
       t.dbias = (wg && mode == 0) ? gr(r.bias) : nullptr;
-      PN_TRY(dense_trans_tail(dz_above, c_above, w_above, c_above, B, c_above, r.cout, w.dense_part, w.dcount, dx_above, &t, st));
-      if (wg) dense_jobs.push_back(DenseWgradJob{ls[q].xin, r.cin, dl.dz, B, r.cin, r.cout, gr(r.kernel), nullptr});
+      PN_TRY(dense_trans_tail(dz_above, c_above, w_above, c_above, Bd, c_above, r.cout, w.dense_part, w.dcount, dx_above, &t, st));
+      if (wg) dense_jobs.push_back(DenseWgradJob{ls[q].xin, r.cin, dl.dz, Bd, r.cin, r.cout, gr(r.kernel), nullptr});
       dz_above = dl.dz; c_above = r.cout; w_above = p(r.kernel); dx_above = dl.din;
     }
     // below the last layer: a plain product
-    return dense_trans_tail(dz_above, c_above, w_above, c_above, B, c_above, ls[n - 1].r->cin, w.dense_part, w.dcount, dx_out, nullptr, st);
+    return dense_trans_tail(dz_above, c_above, w_above, c_above, Bd, c_above, ls[n - 1].r->cin, w.dense_part, w.dcount, dx_out, nullptr, st);
   }
   // T-Net backward from dR (B,K*K); leaves c1's dz coefficients ready (c1.dy + c1.ca/cb/cc)
   int bwd_tnet(TN& t, const TRef& r, const pn_operand* x) {
     const int KK = r.K * r.K;
     const bool wg = tr(r.c1.block) && G;
+    PN_TRY(sync_gather_rows(t.dR, (long long)B * KK));      // synchronised BN: the tail runs backward on every rank's clouds
     if (chain_ok()) {
-      ChainLayer ls[2] = {{&t.d2, &r.d2, t.d1.a, 1, nullptr}, {&t.d1, &r.d1, t.m3.g, 1, nullptr}};
+      ChainLayer ls[2] = {{&t.d2, &r.d2, t.d1.a, 1, nullptr}, {&t.d1, &r.d1, pooled(t.m3), 1, nullptr}};
       PN_TRY(bwd_chain(t.dR, KK, p(r.w), t.d2.a, wg ? gr(r.w) : nullptr, wg ? gr(r.b) : nullptr, t.da2, ls, 2, t.m3.dG));
     } else {
     if (wg) {
       const float *dR = t.dR, *a2 = t.d2.a;
       float *gb = gr(r.b), *gw = gr(r.w);
+      const int rows = Bd;
       PN_TRY(side([=] {
-        return dense_wgrad(a2, 256, dR, B, 256, KK, gw, st, gb);           // dw = a2^T dR and db = sum_b dR in one launch
+        return dense_wgrad(a2, 256, dR, rows, 256, KK, gw, st, gb);        // dw = a2^T dR and db = sum_b dR in one launch
       }));
       PN_TRY(flush());
     }
     PN_TRY(dense_plain(t.dR, KK, p(r.w), KK, true, KK, 256, nullptr, t.da2));
     PN_TRY(bwd_dense(t.d2, r.d2, t.d1.a, t.da2, 1, nullptr, t.d2.din));
-    PN_TRY(bwd_dense(t.d1, r.d1, t.m3.g, t.d2.din, 1, nullptr, t.m3.dG));
+    PN_TRY(bwd_dense(t.d1, r.d1, pooled(t.m3), t.d2.din, 1, nullptr, t.m3.dG));
     }
     PN_TRY(bwd_max(t.c3, t.m3, r.c3, lazy(t.c2), t.c2, t.m3.dG));
     // c2 -> c1
@@ -1001,11 +1060,12 @@ struct Run {
       if (tr(BLK_S1)) {
         PN_TRY(side([=] {
           PN_TRY(wgrad_to(x64, dz1, 64, 512, gr(L.s1.kernel), false, true));
-          return dense_wgrad(w.mm23.g, 1024, w.dgb, B, 1024, 512, gr(L.s1.kernel) + 64 * 512, st);
+          return dense_wgrad(pooled_local(w.mm23, 1024), 1024, w.dgb, B, 1024, 512, gr(L.s1.kernel) + 64 * 512, st);
         }));
         PN_TRY(flush());
       }
-      PN_TRY(dense_plain(w.dgb, 512, Ws1 + 64 * 512, 512, true, 512, 1024, nullptr, w.dGseg));
+      PN_TRY(dense_plain(w.dgb, 512, Ws1 + 64 * 512, 512, true, 512, 1024, nullptr, loc(w.dGseg, 1024), B));      // this rank's clouds
+      PN_TRY(sync_gather_rows(w.dGseg, (long long)B * 1024));
       have_dGseg = true;
       PN_TRY(conv_bwd_data(&dz1, Ws1, 0, B, N, 512, 64, nullptr, nullptr, nullptr, nullptr, w.dX64, nullptr, prec, st, w.s1.w16));
       have_dx64 = true;
@@ -1014,17 +1074,18 @@ struct Run {
     // ---- classification head ----
     bool have_dGcls = false;
     if (has_cls) {
-      if (d_cls) PN_TRY(softmax_bwd_rows(io.out_cls, d_cls, B, d.ccls, w.cls_dlogits, st));
+      if (d_cls) PN_TRY(softmax_bwd_rows(io.out_cls, d_cls, B, d.ccls, loc(w.cls_dlogits, d.ccls), st));
+      PN_TRY(sync_gather_rows(w.cls_dlogits, (long long)B * d.ccls));      // synchronised BN: the head runs backward on every rank's clouds
       if (chain_ok()) {
         // the logits layer is the chain's top product (bias, no BatchNormalization, no activation: dz = d logits)
         const bool wg3 = tr(BLK_C3) && G;
-        ChainLayer ls[2] = {{&w.c2, &L.c2, w.c1.a, 1, io.keep2}, {&w.c1, &L.c1, w.mm23.g, 1, io.keep1}};
+        ChainLayer ls[2] = {{&w.c2, &L.c2, w.c1.a, 1, io.keep2}, {&w.c1, &L.c1, pooled(w.mm23), 1, io.keep1}};
         PN_TRY(bwd_chain(w.cls_dlogits, d.ccls, p(L.c3.kernel), w.c2.a, wg3 ? gr(L.c3.kernel) : nullptr, wg3 ? gr(L.c3.bias) : nullptr,
                          w.c3.din, ls, 2, w.dGcls));
       } else {
       PN_TRY(bwd_dense(w.c3, L.c3, w.c2.a, w.cls_dlogits, 0, nullptr, w.c3.din));
       PN_TRY(bwd_dense(w.c2, L.c2, w.c1.a, w.c3.din, 1, io.keep2, w.c2.din));
-      PN_TRY(bwd_dense(w.c1, L.c1, w.mm23.g, w.c2.din, 1, io.keep1, w.dGcls));
+      PN_TRY(bwd_dense(w.c1, L.c1, pooled(w.mm23), w.c2.din, 1, io.keep1, w.dGcls));
       }
       have_dGcls = true;
     }
@@ -1056,13 +1117,15 @@ struct Run {
       // ---- feature transform: X_64 = A_12 . R_64 ----
       const pn_operand a12 = lazy(w.m12);
       const bool have_dx = has_seg || has_cls;
-      if (!have_dx) PN_TRY(zero_fill(w.fT.dR, (long long)B * 4096, st));     // otherwise the slab reduction below is its first writer
+      float* fdR = loc(w.fT.dR, 4096);                     // this rank's clouds (bwd_tnet gathers the others')
+      const float* fR = loc(w.fT.R, 4096);
+      if (!have_dx) PN_TRY(zero_fill(fdR, (long long)B * 4096, st));     // otherwise the slab reduction below is its first writer
       if (have_dx) {
         const pn_operand dx = plain_act(w.dX64, 64);
-        PN_TRY(wgrad_to(a12, dx, 64, 64, w.fT.dR, true));
-        PN_TRY(conv_bwd_data(&dx, w.fT.R, 4096, B, N, 64, 64, nullptr, nullptr, nullptr, nullptr, w.tmpA12, nullptr, prec, st));
+        PN_TRY(wgrad_to(a12, dx, 64, 64, fdR, true));
+        PN_TRY(conv_bwd_data(&dx, fR, 4096, B, N, 64, 64, nullptr, nullptr, nullptr, nullptr, w.tmpA12, nullptr, prec, st));
       }
-      if (d.reg_feat) PN_TRY(orth_reg(w.fT.R, B, 64, 1e-3f, w.fT.dR, nullptr, st));
+      if (d.reg_feat) PN_TRY(orth_reg(fR, B, 64, 1e-3f, fdR, nullptr, st));
       PN_TRY(bwd_tnet(w.fT, L.fT, &a12));
       const pn_operand dzf1 = dzop(w.fT.c1);
       PN_TRY(conv_bwd_data(&dzf1, p(L.fT.c1.kernel), 0, B, N, 64, 64, have_dx ? w.tmpA12 : nullptr, w.m12.Z, w.m12.scale, w.m12.shift,
@@ -1081,12 +1144,14 @@ struct Run {
     }
     PN_TRY(conv3_wgrad(w.pcn, &dz11, B, N, 64, cur_slabs(), st));
     // d(W_eff) per cloud = sum of its tiles' slabs; dR and dW of W_eff[b] = R[b] W follow in the same launch
-    PN_TRY(fold3_bwd_slabs(cur_slabs(), T, tpc, w.iT.R, p(L.m11.kernel), B, 64, w.iT.dR, tr(BLK_M11) ? gr(L.m11.kernel) : nullptr, st));
+    float* idR = loc(w.iT.dR, 9);
+    const float* iR = loc(w.iT.R, 9);
+    PN_TRY(fold3_bwd_slabs(cur_slabs(), T, tpc, iR, p(L.m11.kernel), B, 64, idR, tr(BLK_M11) ? gr(L.m11.kernel) : nullptr, st));
     // ---- input transform ----
-    if (d_R) PN_TRY(axpy(d_R, 1.f, w.iT.dR, (long long)B * 9, st));
+    if (d_R) PN_TRY(axpy(d_R, 1.f, idR, (long long)B * 9, st));
     if (io.se3 && io.loss_weights[2] != 0.f && !d_R)
-      PN_TRY(mse(w.iT.R, io.se3, B * 9, 2.f * io.loss_weights[2] / (float)(B * 9), w.iT.dR, nullptr, st));
-    if (d.reg_in) PN_TRY(orth_reg(w.iT.R, B, 3, 1e-3f, w.iT.dR, nullptr, st));
+      PN_TRY(mse(iR, io.se3, B * 9, 2.f * io.loss_weights[2] / (float)(B * 9), idR, nullptr, st));
+    if (d.reg_in) PN_TRY(orth_reg(iR, B, 3, 1e-3f, idR, nullptr, st));
     return bwd_tnet(w.iT, L.iT, nullptr);
   }
 };
@@ -1096,6 +1161,7 @@ static int check_desc(const pn_model_desc* d) {
   PN_CHECK_ARG(d->ccls >= 1 && d->ccls <= 4096, "pn_model: classification width %d out of range", d->ccls);
   PN_CHECK_ARG(d->cseg >= 1 && d->cseg <= 16, "pn_model: segmentation width %d not in [1,16]", d->cseg);
   PN_CHECK_ARG(d->dropout_rate >= 0.f && d->dropout_rate < 1.f, "pn_model: dropout rate must be in [0,1)");
+  PN_CHECK_ARG(d->sync_world >= 0 && d->sync_world <= 64, "pn_model: sync_world %d out of range", d->sync_world);
   PN_CHECK_ARG(d->prec == PN_PREC_BF16 || d->prec == PN_PREC_BF16X3 || d->prec == (PN_PREC_BF16 | PN_STORE_BF16),
                "pn_model: bad prec %d (PN_PREC_BF16, PN_PREC_BF16X3 or PN_PREC_BF16 | PN_STORE_BF16)", d->prec);
   return PN_OK;
@@ -1110,6 +1176,19 @@ static int make_run(const pn_model_desc* d, const pn_model_io* io, hipStream_t s
   r->L = make_layout(*d);
   r->B = io->B; r->N = io->N; r->M = (long long)io->B * io->N;
   r->tpc = cdiv(io->N, 128); r->T = io->B * r->tpc;
+  r->W = (io->training && d->sync_world > 1) ? d->sync_world : 1;
+  r->rk = r->W > 1 ? io->sync_rank : 0;
+  r->Bd = io->B * r->W;
+  if (r->W > 1 && (io->sync_rank < 0 || io->sync_rank >= r->W || !io->sync_hook)) {
+    set_error("pn_model: sync_world %d needs 0 <= sync_rank < sync_world and a sync_hook", r->W);
+    delete r;
+    return PN_ERR_INVALID_ARGUMENT;
+  }
+  if (r->W > 1 && io->aux_stream) {
+    set_error("pn_model: synchronised BatchNormalization runs on one stream (no aux_stream)");
+    delete r;
+    return PN_ERR_INVALID_ARGUMENT;
+  }
   r->prec = d->prec; r->s16 = (d->prec & PN_STORE_BF16) ? 1 : 0; r->st = st; r->training = io->training != 0;
   r->P = io->params; r->G = io->grads;
   r->aux = reinterpret_cast<hipStream_t>(io->aux_stream);

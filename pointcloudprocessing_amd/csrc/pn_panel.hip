@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs 
 int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const long long* colacc, const void* wf_hi, const void* wf_lo, int prec,
                    int B, int N, int K, int C, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps,
                    int use_batch, int update, float* mean, float* invstd, float* scale, float* shift, float* g, float* zstar, int* argq,
-                   hipStream_t st) {
+                   hipStream_t st, int count_mult) {
   PN_CHECK_ARG(pmax && pq && gamma && beta && mm && mv && mean && invstd && scale && shift && g, "pn_panel_finalize: null pointer");
   prec &= ~PN_STORE_BF16;
   PN_CHECK_ARG(!use_batch || (sumsq && colacc && wf_hi && (prec != PN_PREC_BF16X3 || wf_lo)),
@@ -1061,7 +1061,7 @@ int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const l
   a.K = K; a.NT = prec == PN_PREC_BF16X3 ? 2 : 1;
   a.tpc = panel_slots_per_cloud(B, N); a.T = B * a.tpc; a.B = B; a.C = C;
   a.n_blocks32 = cdiv(N, 32);
-  a.inv_count = 1.0 / ((double)B * (double)N);
+  a.inv_count = 1.0 / ((double)B * (double)N * (double)(count_mult > 0 ? count_mult : 1));
   a.gamma = gamma; a.beta = beta; a.mm = mm; a.mv = mv; a.momentum = momentum; a.eps = eps; a.use_batch = use_batch; a.update = update;
   a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.g = g; a.zstar = zstar; a.argq = argq;
   const int slices = B >= 32 ? 4 : (B >= 16 ? 2 : 1);      // the statistics are recomputed per slice: a few, for parallelism over the clouds

@@ -212,6 +212,184 @@ __global__ __launch_bounds__(FPS_T) void fps_kernel(const float* __restrict__ xy
   }
 }
 
+// ------------------------------------------------------------------------------------------------------
+// FPS with EXACT spatial pruning (round 3): clouds of 4097 .. 20480 points (BASELINE config 5: the voxel grid's ~20 k centroids).
+// A sampling round changes the running minimum distance of a point only if the new sample is closer to it than its nearest earlier
+// sample -- late in a run a small neighbourhood.  The block keeps, per GROUP of 64 consecutive points (lane j of a wave holds group j of
+// that wave): the group's bounding box and the maximum of its points' minimum distances (gm).  Round: every lane j computes the squared
+// distance from the new sample to ITS group's box -- with the very operations a point uses, in the same order, each of them monotone
+// in fp32, so the box value is <= the value every point of the group would get, exactly -- and a group whose box value is >= gm cannot
+// change: it is skipped, result identical.  A wave owns 40 CONSECUTIVE groups (2560 consecutive points: a compact region when the
+// input is spatially ordered, as the voxel grid's (kz, ky, kx) order is), so most waves skip a round entirely and republish their
+// cached candidate.  One barrier per round: every wave publishes {max min-distance, lowest index holding it, that point's
+// coordinates} into a parity-double-buffered LDS slot; after the barrier every wave reduces the eight slots itself.
+// Inputs in no spatial order (every box spans the cloud) make every test fail: a wave that found nothing to skip for 64 rounds in a
+// row stops testing (plain update of all its points from then on; the group maxima are no longer maintained).
+// Bit-exact against oracle/sampling_oracle.py like the plain kernel: same distances, ties -> lowest index.
+// ------------------------------------------------------------------------------------------------------
+constexpr int FPS_PR_T = 512, FPS_PR_PPT = 40;
+__device__ __forceinline__ float wave_min_f32(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+#define PN_FPS40(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) \
+  X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39)
+__global__ __launch_bounds__(FPS_PR_T) void fps_pruned_kernel(const float* __restrict__ xyz, int N, int M, int start_idx,
+                                                              int* __restrict__ idx_out, float* __restrict__ mindist) {
+#pragma clang fp contract(off)   // the distance is specified without fused multiply-add (bit-exact vs the oracle)
+  constexpr int PPT = FPS_PR_PPT, T = FPS_PR_T, NW = T / 64;
+  __shared__ __attribute__((aligned(16))) int s_cand[2][NW][2];      // [round parity][wave] {max min-distance (bit pattern), lowest index}
+  __shared__ __attribute__((aligned(16))) float s_cxyz[2][NW][4];    // that point's coordinates
+  const int cloud = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float* p = xyz + (long long)cloud * N * 3;
+  const int wbase = wave * (64 * PPT);                   // point j of this thread = cloud index wbase + 64 * j + lane
+  fps_v2f px[PPT / 2], py[PPT / 2], pz[PPT / 2];
+  int md[PPT];
+  constexpr int MD_PAD = (int)0xbf800000u, MD_INF = 0x7f800000;   // -1.0f, +inf
+  float blx = INFINITY, bly = INFINITY, blz = INFINITY, bhx = -INFINITY, bhy = -INFINITY, bhz = -INFINITY;
+  int gm = MD_PAD;                                       // lane j: max of the running minimum distances of group j (bit pattern)
+#pragma unroll
+  for (int j = 0; j < PPT; ++j) {
+    const int i = wbase + 64 * j + lane;
+    float x = 0.f, y = 0.f, z = 0.f;
+    md[j] = MD_PAD;
+    const bool v = i < N;
+    if (v) { x = p[3 * i]; y = p[3 * i + 1]; z = p[3 * i + 2]; md[j] = MD_INF; }
+    if (j & 1) { px[j / 2].y = x; py[j / 2].y = y; pz[j / 2].y = z; }
+    else       { px[j / 2].x = x; py[j / 2].x = y; pz[j / 2].x = z; }
+    const float lx = wave_min_f32(v ? x : INFINITY), ly = wave_min_f32(v ? y : INFINITY), lz = wave_min_f32(v ? z : INFINITY);
+    const float hx = wave_max_f32(v ? x : -INFINITY), hy = wave_max_f32(v ? y : -INFINITY), hz = wave_max_f32(v ? z : -INFINITY);
+    const int g0 = wave_max_i32(md[j]);
+    if (lane == j) { blx = lx; bly = ly; blz = lz; bhx = hx; bhy = hy; bhz = hz; gm = g0; }
+  }
+  int cur = start_idx;
+  float cx = p[3 * cur], cy = p[3 * cur + 1], cz = p[3 * cur + 2];
+  // this wave's candidate (wave-uniform): recomputed only in rounds that changed one of its points
+  int c_val = MD_PAD, c_idx = 0x7fffffff;
+  float c_x = 0.f, c_y = 0.f, c_z = 0.f;
+  bool have_cand = false;
+  bool plain = false;                                    // wave-uniform: no longer testing (nothing was ever skipped)
+  int full_run = 0;
+  const unsigned long long all_groups = (1ull << PPT) - 1ull;
+  for (int it = 0; it < M; ++it) {
+    if (tid == 0) idx_out[(long long)cloud * M + it] = cur;
+    if (it == M - 1) break;
+    const float ux = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cx)));
+    const float uy = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cy)));
+    const float uz = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(cz)));
+    // (0) the groups the new sample can change
+    unsigned long long mask = all_groups;
+    if (!plain) {
+      const float tlx = blx - ux, thx = bhx - ux, tly = bly - uy, thy = bhy - uy, tlz = blz - uz, thz = bhz - uz;
+      const float ax = tlx > 0.f ? tlx : (thx < 0.f ? thx : 0.f);
+      const float ay = tly > 0.f ? tly : (thy < 0.f ? thy : 0.f);
+      const float az = tlz > 0.f ? tlz : (thz < 0.f ? thz : 0.f);
+      const float bound = (ax * ax + ay * ay) + az * az;              // <= the distance of every point of the group, exactly
+      mask = __ballot(__float_as_int(bound) < gm) & all_groups;       // (an empty group has gm = -1.0f: never)
+      full_run = mask == all_groups ? full_run + 1 : 0;
+      if (full_run >= 64) plain = true;
+    }
+    if (mask != 0ull || !have_cand) {
+      const fps_v2f c_xv = {ux, ux}, c_yv = {uy, uy}, c_zv = {uz, uz};
+      int best = MD_PAD;
+#pragma unroll
+      for (int q = 0; q < PPT / 2; ++q) {
+        if ((mask >> (2 * q)) & 3ull) {                  // wave-uniform
+          const fps_v2f dx = px[q] - c_xv, dy = py[q] - c_yv, dz = pz[q] - c_zv;
+          const fps_v2f d = (dx * dx + dy * dy) + dz * dz;
+          md[2 * q] = min(md[2 * q], __float_as_int(d.x));
+          md[2 * q + 1] = min(md[2 * q + 1], __float_as_int(d.y));
+          if (!plain) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+              const int j = 2 * q + u;
+              const int old = __builtin_amdgcn_readlane(gm, j);
+              if (__ballot(md[j] == old) == 0ull) {      // the point that held the group's maximum moved: take the maximum again
+                const int nm = wave_max_i32(md[j]);
+                gm = lane == j ? nm : gm;
+              }
+            }
+          }
+        }
+        if (plain) best = max(best, max(md[2 * q], md[2 * q + 1]));
+      }
+      // (1) this wave's candidate: its largest minimum distance and the lowest index holding it
+      const int wmax = plain ? wave_max_i32(best) : wave_max_i32(lane < PPT ? gm : MD_PAD);
+      int jw = PPT;
+      if (plain) {
+#pragma unroll
+        for (int j = PPT - 1; j >= 0; --j) jw = (md[j] == wmax) ? j : jw;
+      }
+      int js, ls;
+      if (plain) {
+        const int cand = jw < PPT ? 64 * jw + lane : 0x7fffffff;
+        const int wi = wave_min_i32(cand);
+        js = wi >> 6; ls = wi & 63;
+        if (wi == 0x7fffffff) { js = 0; ls = 0; }
+      } else {
+        const unsigned long long gj = __ballot(lane < PPT && gm == wmax);
+        js = __builtin_amdgcn_readfirstlane(gj ? __ffsll((long long)gj) - 1 : 0);
+        int vsel = MD_PAD;
+        switch (js) {
+#define PN_FPS_SEL(J) case J: vsel = md[J]; break;
+          PN_FPS40(PN_FPS_SEL)
+#undef PN_FPS_SEL
+          default: break;
+        }
+        const unsigned long long gl = __ballot(vsel == wmax);
+        ls = __builtin_amdgcn_readfirstlane(gl ? __ffsll((long long)gl) - 1 : 0);
+      }
+      js = __builtin_amdgcn_readfirstlane(js);
+      ls = __builtin_amdgcn_readfirstlane(ls);
+      float bx = 0.f, by = 0.f, bz = 0.f;
+      switch (js) {
+#define PN_FPS_XYZ(J) case J: bx = (J & 1) ? px[J / 2].y : px[J / 2].x; by = (J & 1) ? py[J / 2].y : py[J / 2].x; \
+                              bz = (J & 1) ? pz[J / 2].y : pz[J / 2].x; break;
+        PN_FPS40(PN_FPS_XYZ)
+#undef PN_FPS_XYZ
+        default: break;
+      }
+      c_val = wmax;
+      c_idx = wmax == MD_PAD ? 0x7fffffff : wbase + 64 * js + ls;     // a wave without points never wins
+      c_x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bx), ls));
+      c_y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(by), ls));
+      c_z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(bz), ls));
+      have_cand = true;
+    }
+    // (2) publish, one barrier, every wave reduces the NW slots itself
+    const int par = it & 1;
+    if (lane == 0) {
+      s_cand[par][wave][0] = c_val; s_cand[par][wave][1] = c_idx;
+      s_cxyz[par][wave][0] = c_x; s_cxyz[par][wave][1] = c_y; s_cxyz[par][wave][2] = c_z;
+    }
+    __syncthreads();
+    const int wl = lane < NW ? lane : 0;
+    int v = s_cand[par][wl][0], ix = s_cand[par][wl][1];
+    if (lane >= NW) { v = MD_PAD; ix = 0x7fffffff; }
+    const int gmax = wave_max_i32(v);
+    const int bi = wave_min_i32(v == gmax ? ix : 0x7fffffff);
+    const unsigned long long who = __ballot(v == gmax && ix == bi);
+    const int bw = who ? __ffsll((long long)who) - 1 : 0;
+    cx = s_cxyz[par][bw][0]; cy = s_cxyz[par][bw][1]; cz = s_cxyz[par][bw][2];
+    cur = bi;
+  }
+  if (mindist) {
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) {
+      const int i = wbase + 64 * j + lane;
+      if (i < N) mindist[(long long)cloud * N + i] = __int_as_float(md[j]);
+    }
+  }
+}
+#undef PN_FPS40
+
 static inline int fps_blocks_per_cloud(int N) { return N <= FPS_T_WIDE * FPS_PPT_WIDE ? 1 : cdiv(N, FPS_PER_BLOCK); }
 
 size_t fps_workspace_bytes(int B, int N) {
@@ -246,6 +424,12 @@ int fps(const float* xyz, int B, int N, int M, int start_idx, int* idx_out, floa
     unsigned long long* c0 = xchg + (long long)b0 * 2 * bpc;
     // a round costs a fixed ~1 us of reductions and barriers plus the distance update: small clouds take fewer waves
     // (cheaper barriers, one wave per SIMD) and fewer points per thread
+    static const bool prune = !(getenv("PN_FPS_PRUNE") && atoi(getenv("PN_FPS_PRUNE")) == 0);
+    if (bpc == 1 && prune && N > 256 * 16 && N <= FPS_PR_T * FPS_PR_PPT) {
+      hipLaunchKernelGGL(fps_pruned_kernel, dim3(nb), dim3(FPS_PR_T), 0, st, x0, N, M, start_idx, i0, m0);
+      PN_CHECK_LAUNCH();
+      continue;
+    }
     if (bpc > 1) fps_launch<FPS_PPT_MULTI, FPS_T_MULTI>(nb * bpc, st, x0, N, M, start_idx, bpc, i0, m0, c0, err);
     else if (N <= 256 * 4) fps_launch<4, 256>(nb, st, x0, N, M, start_idx, 1, i0, m0, c0, err);
     else if (N <= 256 * 16) fps_launch<16, 256>(nb, st, x0, N, M, start_idx, 1, i0, m0, c0, err);

@@ -51,13 +51,26 @@ class TrainStep:
         self.overlap = os.environ.get("PN_DDP_OVERLAP", "1") != "0"
         dev = model.params_flat.device
         self.dev = dev
+        # Synchronised BatchNormalization (PointNet(sync_bn_world=W)): the native plan exchanges statistics and the dense layers' rows
+        # INSIDE the forward / backward pass (pn_model_io.sync_hook), so the step is launched eagerly, in one piece; the gradients are
+        # summed (not averaged: every rank already seeds the global mean loss) after the slots every rank computed in full have been
+        # zeroed on every rank but the first.
+        self.sync_bn = getattr(model, "_sync_world", 1) > 1
+        rows = batch * (model._sync_world if self.sync_bn else 1)
+        if self.sync_bn:
+            self.split, use_graph = False, False
+            self._rep_mask = model.replicated_grad_mask() if self.dist.get_rank(model._sync_group) != 0 else None
         # static inputs: a graph replays fixed addresses
         self.pc = torch.zeros(batch, points, 3, device=dev)
         self.y_cls = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.y_seg = torch.zeros(batch, points, dtype=torch.int32, device=dev)
         self.se3 = torch.zeros(batch, 3, 3, device=dev)
-        self.keep = (torch.ones(batch, 512, dtype=torch.uint8, device=dev), torch.ones(batch, 256, dtype=torch.uint8, device=dev))
+        self.keep = (torch.ones(rows, 512, dtype=torch.uint8, device=dev), torch.ones(rows, 256, dtype=torch.uint8, device=dev))
         self._mask_seed = int(torch.randint(0, 2**62, (1,)).item()) ^ (rank_salt() << 20)   # per process / rank
+        if self.sync_bn:                # one mask stream for the whole batch: every rank draws the rows of all ranks
+            t = torch.tensor([self._mask_seed & (2**62 - 1)], dtype=torch.int64, device=dev if dev.type == "cuda" else "cpu")
+            self.dist.broadcast(t, src=self.dist.get_global_rank(model._sync_group, 0) if model._sync_group is not None else 0, group=model._sync_group)
+            self._mask_seed = int(t.item())
         self._mask_step = torch.zeros(1, dtype=torch.int32, device=dev)
         self.mode = "eager"
         self.capture_error = None     # set when hipGraph capture failed and the step fell back to eager launches (the trainer logs it)
@@ -147,6 +160,15 @@ class TrainStep:
             self.opt.step(self.model.grads_flat, scale, lo, hi)
 
     def _eager(self):
+        if self.sync_bn:
+            self._fwd_bwd()
+            g = self.model.grads_flat
+            if self._rep_mask is not None:
+                g.mul_(self._rep_mask)
+            lo, _, hi = self._buckets()
+            self.dist.all_reduce(g[lo:hi] if hi > lo else g, group=self.model._sync_group)
+            self._opt_step(1.0)
+            return
         if not self.split:
             self._fwd_bwd()
         else:

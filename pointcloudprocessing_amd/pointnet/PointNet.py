@@ -396,7 +396,11 @@ class PointNet(torch.nn.Module):
     def __init__(self, classification_output_width: int, segmentation_output_width: int, dropout_rate: float,
                  random_seed: int, debugging: bool = False, vanilla: bool = False,
                  regularize_input_transform: bool = False, regularize_feature_transform: bool = False,
-                 precision: str = "bf16x3", device=None, **kwargs):
+                 precision: str = "bf16x3", device=None, sync_bn_world: int = 1, sync_bn_rank: int = 0, sync_bn_group=None, **kwargs):
+        """``sync_bn_world`` > 1 (data parallel, numerics-parity mode): every training-mode BatchNormalization takes its statistics over
+        the clouds of ALL ranks, as the reference does on its one device (PointNet.py:528,559,623,647) -- a step on W ranks of B clouds
+        is then the reference's step on the B*W clouds.  The collectives go through ``torch.distributed`` (``sync_bn_group`` or the
+        default group); see include/pointnet_hip.h (pn_model_io.sync_hook) for what is exchanged and engine.TrainStep for the step."""
         super().__init__()
         self._classification_output_width = classification_output_width
         self._segmentation_output_width = segmentation_output_width
@@ -409,6 +413,10 @@ class PointNet(torch.nn.Module):
         if precision not in _lib.PREC:
             raise PointNetHipError(f"precision must be one of {list(_lib.PREC)}")
         self._precision = precision
+        self._sync_world = int(sync_bn_world) if sync_bn_world and int(sync_bn_world) > 1 else 1
+        self._sync_rank = int(sync_bn_rank) if self._sync_world > 1 else 0
+        self._sync_group = sync_bn_group
+        self._sync_error = None
         self._custom_layers = []
         self.input_names = ['pointnet_input']
         self.output_names = ['classification_output', 'segmentation_output', 'se3']
@@ -448,7 +456,7 @@ class PointNet(torch.nn.Module):
         self._desc = pn_model_desc(ccls=classification_output_width, cseg=segmentation_output_width, vanilla=int(vanilla),
                                    reg_in=int(regularize_input_transform), reg_feat=int(regularize_feature_transform),
                                    prec=_lib.PREC[precision], dropout_rate=float(dropout_rate), bn_momentum=BN_MOMENTUM,
-                                   bn_eps=BN_EPS)
+                                   bn_eps=BN_EPS, sync_world=self._sync_world if self._sync_world > 1 else 0)
         if device is None:
             device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
         self._weights = _Weights(self._desc, torch.device(device))
@@ -648,10 +656,19 @@ class PointNet(torch.nn.Module):
         aux = getattr(self, "_aux_stream", None)       # engine.TrainStep: parameter gradients on a second stream
         io.aux_stream = aux.cuda_stream if (aux is not None and training) else None
         keep = None
+        W = self._sync_world if training else 1
+        if W > 1:
+            io.sync_rank = self._sync_rank
+            io.sync_hook = C.cast(self._sync_hook_c(), C.c_void_p)
+            self._sync_ws = ws
         if training and self._dropout_rate > 0:
             if fused is not None and fused.get("keep") is not None:
                 keep = fused["keep"]
+                if keep[0].shape[0] != B * W:
+                    raise PointNetHipError(f"dropout keep masks need {B * W} rows (synchronised BatchNormalization: the rows of all ranks)")
             else:
+                if W > 1:
+                    raise PointNetHipError("synchronised BatchNormalization needs the dropout keep masks of all ranks' rows (engine.TrainStep draws them)")
                 keep = ((torch.rand(B, 512, device=dev) >= self._dropout_rate).to(torch.uint8),
                         (torch.rand(B, 256, device=dev) >= self._dropout_rate).to(torch.uint8))
             io.keep1, io.keep2 = keep[0].data_ptr(), keep[1].data_ptr()
@@ -670,8 +687,56 @@ class PointNet(torch.nn.Module):
             io.labels_seg = fused["labels_seg"].data_ptr()
             io.se3 = fused["se3"].data_ptr()
             lw = fused["loss_weights"]
-            io.loss_weights[0], io.loss_weights[1], io.loss_weights[2] = float(lw[0]), float(lw[1]), float(lw[2])
+            # synchronised BatchNormalization: every rank seeds the gradient of the GLOBAL mean loss (pn_model_io.sync_hook)
+            io.loss_weights[0], io.loss_weights[1], io.loss_weights[2] = float(lw[0]) / W, float(lw[1]) / W, float(lw[2]) / W
         return io, keep
+
+    # ------------------------------------------------------------------ synchronised BatchNormalization
+    def _sync_hook_c(self):
+        """the C callback the native plan calls between two of its launches (pn_model_io.sync_hook): op 0 all-reduce (sum), op 1 all-gather,
+        on ranges of the workspace, through torch.distributed on the current stream"""
+        if getattr(self, "_sync_cb", None) is None:
+            import torch.distributed as dist
+
+            def hook(ctx, op, src, dst, n, dtype, stream):
+                try:
+                    ws = self._sync_ws
+                    base, es = ws.data_ptr(), (4 if dtype == 0 else 8)
+                    tdt = torch.float32 if dtype == 0 else torch.int64
+
+                    def view(ptr_, count):
+                        off = ptr_ - base
+                        if off < 0 or off + count * es > ws.numel():
+                            raise PointNetHipError("sync_hook: range outside the workspace")
+                        return ws[off: off + count * es].view(tdt)
+                    W = self._sync_world
+                    if op == 0:
+                        d = view(dst, n)
+                        if src != dst:
+                            d.copy_(view(src, n))
+                        dist.all_reduce(d, group=self._sync_group)
+                    else:
+                        out, mine = view(dst, n * W), view(src, n).clone()
+                        dist.all_gather([out[i * n:(i + 1) * n] for i in range(W)], mine, group=self._sync_group)
+                    return 0
+                except Exception as e:      # never let an exception cross the C frame
+                    self._sync_error = f"{type(e).__name__}: {e}"
+                    return 1
+            self._sync_cb = _lib.SYNC_HOOK(hook)
+        return self._sync_cb
+
+    def replicated_grad_mask(self) -> torch.Tensor:
+        """synchronised BatchNormalization: 0.0 where every rank computes a gradient slot IN FULL (all bn.gamma / bn.beta -- formed from
+        the sums over all ranks; the per-cloud dense layers' kernels and bias and the T-Nets' w / b -- run on all ranks' rows), 1.0 where
+        a rank holds its clouds' share.  Every rank but one multiplies its gradients by this before they are summed."""
+        m = torch.ones_like(self._weights.flat)
+        dense_blocks = ("mlp_cls_1", "mlp_cls_2", "mlp_cls_3")
+        for name, s in self._weights.slots.items():
+            k = s["kind"]
+            rep = k in (1, 2, 6, 7) or (k in (0, 5) and (name.split(".")[0] in dense_blocks or ".dense" in name))
+            if rep:
+                m[s["offset"]: s["offset"] + s["rows"] * s["cols"]] = 0.0
+        return m
 
     def _run_forward(self, pc, training, fused):
         _lib.require_gpu_tensor(pc, "pc", torch.float32)
@@ -686,7 +751,10 @@ class PointNet(torch.nn.Module):
         seg = torch.empty(B, N, self._segmentation_output_width, device=dev, dtype=torch.float32)
         R = torch.empty(B, 3, 3, device=dev, dtype=torch.float32)
         io.out_cls, io.out_seg, io.out_R = cls.data_ptr(), seg.data_ptr(), R.data_ptr()
-        check(lib().pn_model_forward(C.byref(self._desc), C.byref(io), current_stream()), "pn_model_forward")
+        rc = lib().pn_model_forward(C.byref(self._desc), C.byref(io), current_stream())
+        if rc != 0 and self._sync_error:
+            raise PointNetHipError(f"pn_model_forward: collective failed inside sync_hook: {self._sync_error}")
+        check(rc, "pn_model_forward")
         if self._debugging:
             self._check_numerics(pc, cls, seg, training)
         self._last = (cls, seg, R)
@@ -742,8 +810,10 @@ class PointNet(torch.nn.Module):
         def c(t):
             return None if t is None else t.contiguous()
         d_cls, d_seg, d_R = c(d_cls), c(d_seg), c(d_R)
-        check(lib().pn_model_backward(C.byref(self._desc), C.byref(io), ptr(d_cls), ptr(d_seg), ptr(d_R), current_stream()),
-              "pn_model_backward")
+        rc = lib().pn_model_backward(C.byref(self._desc), C.byref(io), ptr(d_cls), ptr(d_seg), ptr(d_R), current_stream())
+        if rc != 0 and self._sync_error:
+            raise PointNetHipError(f"pn_model_backward: collective failed inside sync_hook: {self._sync_error}")
+        check(rc, "pn_model_backward")
         return self.grads_flat
 
     def forward(self, pc, training: Optional[bool] = None):

@@ -120,12 +120,15 @@ class HipEngine:
             self.model = PN.PointNet.from_config(mc)
             self.model.set_weights(payload["weights"])
         else:
+            # params.sync_batchnorm (not a reference key; default false): with more than one rank, every training-mode BatchNormalization
+            # takes its statistics over the clouds of all ranks -- the reference's single-device batch (PointNet.py:528,559,623,647)
+            sync = dict(sync_bn_world=self.world, sync_bn_rank=self.rank) if (p.get('sync_batchnorm', False) and self.world > 1) else {}
             self.model = PN.PointNet(classification_output_width=n_class, segmentation_output_width=n_part, dropout_rate=0.3,
                                      random_seed=p['random_seed'], debugging=p.get('debugging', False),
                                      vanilla=p.get('vanilla', False),
                                      regularize_input_transform=p.get('regularize_input_transform', False),
                                      regularize_feature_transform=p.get('regularize_feature_transform', False),
-                                     precision=precision)
+                                     precision=precision, **sync)
             self.model.build(input_shape=(None, p['input_width'], 3))
         if self.world > 1:                                  # identical replicas: rank 0's weights everywhere
             dist.broadcast(self.model.params_flat.data, src=0)

@@ -347,6 +347,26 @@ def test_fps_bit_exact_indices(dev, B, N, M):
         assert np.array_equal(md[b].cpu().numpy(), rmd)
 
 
+@pytest.mark.parametrize("N,M", [(8000, 2500), (20480, 1200), (4097, 4097), (12345, 300)])
+def test_fps_pruned_kernel_on_spatially_ordered_clouds(dev, N, M):
+    """the pruned FPS kernel (pn_sample.hip: fps_pruned_kernel, clouds of 4097 .. 20480 points) in the regime it is built for: points in
+    (z, y, x) order as the voxel grid leaves them, so that most 64-point groups are skipped in most rounds -- indices and final minimum
+    distances bit-exact against the NumPy oracle, duplicated points (distance ties -> lowest index) inside one group, across groups of
+    one wave and across waves, M = N (every point drawn once, then ties at distance 0)."""
+    ops = _ops()
+    rng = np.random.default_rng(N + M)
+    side = int(np.ceil(N ** (1.0 / 3.0))) + 1
+    gi = np.stack(np.meshgrid(np.arange(side), np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 3)[:N]     # z, y, x ascending
+    xyz = (gi[:, ::-1] * 0.25 + rng.uniform(-0.1, 0.1, size=(N, 3))).astype(np.float32)
+    xyz[70:75] = xyz[10:15]                         # ties inside a group / between groups of one wave
+    xyz[3000:3004] = xyz[200:204]                   # ... between waves
+    xyz[N - 3:] = xyz[N - 6:N - 3]
+    idx, md = ops.farthest_point_sample(torch.from_numpy(xyz[None]).to(dev), M, start_idx=N // 2, return_mindist=True)
+    ri, rmd = SO.fps(xyz, M, N // 2)
+    assert np.array_equal(idx[0].cpu().numpy(), ri), np.flatnonzero(idx[0].cpu().numpy() != ri)[:5]
+    assert np.array_equal(md[0].cpu().numpy(), rmd)
+
+
 def test_scan_pipeline_c5_matches_oracle(dev):
     """BASELINE config 5 at full size (tools/bench_scan.py's synthetic scan): N = 131072 -> voxel grid 0.25 m -> FPS M = 8192, every
     stage bit-exact against the NumPy oracle; the sampled cloud then goes through PointNet.predict."""

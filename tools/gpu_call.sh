@@ -32,7 +32,8 @@ for s in "$@"; do
         set -- $cfg; t=$1; shift
         step "bench $t" 200 bash -c "python bench.py --steps 100 --warmup 10 --no-cpu-baseline $* > $out/bench_$t.json 2> $out/bench_$t.err"
       done ;;
-    scan) step "scan pipeline" 200 bash -c "python tools/bench_scan.py > $out/scan.json 2> $out/scan.err" ;;
+    scan) n=scan; [ -e $out/scan.json ] && n=scan_$(date +%s | tail -c 4)
+      step "scan pipeline ($n)" 200 bash -c "python tools/bench_scan.py > $out/$n.json 2> $out/$n.err" ;;
     panel) step "panel probe" 200 bash -c "python tools/panel_probe.py > $out/panel_probe.jsonl 2> $out/panel_probe.err" ;;
     prof)
       cd /tmp
