@@ -16,10 +16,12 @@ One JSON line is printed by rank 0.  Extra objects:
                achieved = 2*128*1024 FLOP/point * points per launch / mean launch time, against the dense bf16 MFMA peak
                (2.5 PFLOP/s).  bound = "mfma": with 256 B/point of compulsory input (128 channels stored as bf16; 512 B with
                fp32 storage) this kernel is compute bound (1024 FLOP/B against a ridge of 312).
-               traffic = HBM bytes per launch from the rocprofv3 PMC passes under profiles/round2 (FETCH_SIZE x 2 + WRITE_SIZE,
+               traffic = HBM bytes per launch from the rocprofv3 PMC passes under profiles/round3 (FETCH_SIZE x 2 + WRITE_SIZE,
                MI355X_MICROARCH.md), reported only while pn_panel.hip is the source they were collected on, else null.
   cpu_baseline the CPU oracle (torch-CPU restatement of the reference model; the TF reference itself cannot run
                here) timed on this host for a bounded number of steps of the same workload.
+  fp32_grade   the same step in the 'bf16x3' mode (split MFMA operands: fp32-grade products, fp32 layer-boundary tensors) -- the
+               like-for-like figure against the reference's fp32 arithmetic -- timed after the main loop (N = 1 only; not `value`).
 """
 import argparse
 import json
@@ -205,7 +207,7 @@ def main():
     # HBM bytes per launch from rocprofv3 PMC passes of this same command (profiles/, corrected per MI355X_MICROARCH.md: FETCH_SIZE x 2):
     # reported only while the kernel source is the one the counters were collected on
     traffic = None
-    pmc_file = os.path.join(ROOT, "profiles", "round2", "panel_pmc.json")
+    pmc_file = os.path.join(ROOT, "profiles", "round3", "panel_pmc.json")
     if os.path.exists(pmc_file) and (B, N, args.precision) == (32, 1024, "bf16"):
         import hashlib
         with open(pmc_file) as f:
@@ -247,6 +249,25 @@ def main():
     out["step_roofline"] = {"algorithmic_flop": f_alg, "algorithmic_bytes": b_alg, "t_mfma_us": f_alg / MFMA_BF16_PEAK * 1e6,
                             "t_hbm_us": b_alg / HBM_PEAK * 1e6, "bound": "hbm" if b_alg / HBM_PEAK > f_alg / MFMA_BF16_PEAK else "mfma",
                             "frac": t_roof / (dt / args.steps)}
+    if world == 1 and args.precision == "bf16" and not args.no_cpu_baseline:
+        # the fp32-grade mode beside the headline mode: same workload, same launch form, 60 steps after 10
+        m3 = PointNet(CCLS, CSEG, 0.3, 42, precision="bf16x3", device=dev)
+        m3.thaw_shared_network(); m3.thaw_input_transform()
+        (m3.freeze_classification_head if args.profile == "final" else m3.thaw_classification_head)()
+        (m3.freeze_segmentation_head if args.profile == "classification_pretrain" else m3.thaw_segmentation_head)()
+        ts3 = TrainStep(m3, KerasAdam(m3.params_flat.data, 1e-4, 7000, 0.7), B, N, lw, use_graph=not args.no_graph)
+        ts3.load(pc, y_cls, y_seg, se3)
+        torch.cuda.set_stream(ts3.stream)
+        for _ in range(13):
+            ts3.run()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(60):
+            ts3.run()
+        torch.cuda.synchronize()
+        dt3 = (time.perf_counter() - t1) / 60
+        out["fp32_grade"] = {"precision": "bf16x3", "ms_per_step": dt3 * 1e3, "value": B * N / dt3, "unit": "points/s", "launch": ts3.mode,
+                             "note": "split bf16 MFMA operands (3 products, 16 significant bits), fp32 layer-boundary tensors; inference parity vs the fp64 oracle 7e-6"}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B, N)

@@ -940,10 +940,11 @@ static int launch_wgrad_batch(const WgradBatch& wb, bool b2, int prec, int block
 // jobs of the same tile shape / operand form / precision share a launch (up to WGRAD_BATCH_MAX each)
 int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st) {
   std::vector<char> done(n > 0 ? n : 0, 0);
-  // shape 3 (round 3): 128 x 256 output tiles for the wide jobs of the bf16 mode (seg_l2: 512 x 256) -- a tile re-stages its rows of
-  // both operands, so with 128 x 128 tiles that job read its operands three times over (402 MB for 134 MB at B=32, N=2048); a wave
-  // holds 2 x 4 accumulator blocks (128 registers) and the dz operand's two sources 64 more: bf16 sources only
-  static const bool wide_ok = !(getenv("PN_WGRAD_WIDE") && atoi(getenv("PN_WGRAD_WIDE")) == 0);
+  // shape 3 (round 3, an experiment behind PN_WGRAD_WIDE=1): 128 x 256 output tiles for the wide jobs of the bf16 mode (seg_l2: 512 x
+  // 256) -- a tile re-stages its rows of both operands, so with 128 x 128 tiles that job reads its operands three times over (402 MB
+  // for 134 MB at B=32, N=2048).  Measured at C3: 1.519 ms/step with the wide tiles against 1.503 without -- the re-reads are served
+  // by the L2 / Infinity Cache, and half the workgroups with 227 registers each lose more than the saved staging wins.  Off by default.
+  static const bool wide_ok = getenv("PN_WGRAD_WIDE") && atoi(getenv("PN_WGRAD_WIDE")) == 1;
   auto key = [&](const WgradDesc& q) {
     const bool x3 = (q.prec & ~PN_STORE_BF16) == PN_PREC_BF16X3;
     const bool wide = wide_ok && !q.small_tiles && !x3 && q.a.h16 && q.b.h16 && q.Ci % 128 == 0 && q.Cj % 256 == 0;

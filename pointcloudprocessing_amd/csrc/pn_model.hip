@@ -164,8 +164,7 @@ struct WS {
 };
 
 static long long wgrad_slab_rows(int B, int N, int Ci, int Cj, int* spc_out, int target_override = 0) {
-  // (128 x 256 tiles where the bf16 mode uses them, pn_gemm.hip conv_wgrad_batch; the other modes then launch twice the workgroups)
-  const int bm = (Ci % 128 == 0 && Cj % 128 == 0) ? 128 : 64, bn = (Ci % 128 == 0 && Cj % 256 == 0) ? 256 : ((Cj % 128 == 0) ? 128 : 64);
+  const int bm = (Ci % 128 == 0 && Cj % 128 == 0) ? 128 : 64, bn = (Cj % 128 == 0) ? 128 : 64;
   const int n_out = (Ci / bm) * (Cj / bn);
   // about one workgroup per CU: 512 slabs of 64 rows made the weight-gradient kernels write (and slab_reduce re-read) twice the
   // bytes for no extra parallelism -- 1.40 -> 1.34 ms/step at B=32, N=1024 (sweep: 64: 1.47, 128: 1.38, 192: 1.36, 256-384: 1.34)

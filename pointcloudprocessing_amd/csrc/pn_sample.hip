@@ -241,7 +241,7 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 #define PN_FPS40(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7) X(8) X(9) X(10) X(11) X(12) X(13) X(14) X(15) X(16) X(17) X(18) X(19) \
   X(20) X(21) X(22) X(23) X(24) X(25) X(26) X(27) X(28) X(29) X(30) X(31) X(32) X(33) X(34) X(35) X(36) X(37) X(38) X(39)
 __global__ __launch_bounds__(FPS_PR_T) void fps_pruned_kernel(const float* __restrict__ xyz, int N, int M, int start_idx,
-                                                              int* __restrict__ idx_out, float* __restrict__ mindist) {
+                                                              int* __restrict__ idx_out, float* __restrict__ mindist, int plain_from_start) {
 #pragma clang fp contract(off)   // the distance is specified without fused multiply-add (bit-exact vs the oracle)
   constexpr int PPT = FPS_PR_PPT, T = FPS_PR_T, NW = T / 64;
   __shared__ __attribute__((aligned(16))) int s_cand[2][NW][2];      // [round parity][wave] {max min-distance (bit pattern), lowest index}
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(FPS_PR_T) void fps_pruned_kernel(const float* __res
   int c_val = MD_PAD, c_idx = 0x7fffffff;
   float c_x = 0.f, c_y = 0.f, c_z = 0.f;
   bool have_cand = false;
-  bool plain = false;                                    // wave-uniform: no longer testing (nothing was ever skipped)
+  bool plain = plain_from_start != 0;                    // wave-uniform: no longer testing (nothing was ever skipped)
   int full_run = 0;
   const unsigned long long all_groups = (1ull << PPT) - 1ull;
   for (int it = 0; it < M; ++it) {
@@ -424,9 +424,10 @@ int fps(const float* xyz, int B, int N, int M, int start_idx, int* idx_out, floa
     unsigned long long* c0 = xchg + (long long)b0 * 2 * bpc;
     // a round costs a fixed ~1 us of reductions and barriers plus the distance update: small clouds take fewer waves
     // (cheaper barriers, one wave per SIMD) and fewer points per thread
-    static const bool prune = !(getenv("PN_FPS_PRUNE") && atoi(getenv("PN_FPS_PRUNE")) == 0);
+    // PN_FPS_PRUNE: 0 (default) the plain kernels; 1 the pruned kernel; 2 the pruned kernel's one-barrier round without the test
+    const int prune = getenv("PN_FPS_PRUNE") ? atoi(getenv("PN_FPS_PRUNE")) : 0;      // (read at every call: the tests flip it)
     if (bpc == 1 && prune && N > 256 * 16 && N <= FPS_PR_T * FPS_PR_PPT) {
-      hipLaunchKernelGGL(fps_pruned_kernel, dim3(nb), dim3(FPS_PR_T), 0, st, x0, N, M, start_idx, i0, m0);
+      hipLaunchKernelGGL(fps_pruned_kernel, dim3(nb), dim3(FPS_PR_T), 0, st, x0, N, M, start_idx, i0, m0, prune == 2 ? 1 : 0);
       PN_CHECK_LAUNCH();
       continue;
     }

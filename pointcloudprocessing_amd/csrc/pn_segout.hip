@@ -275,6 +275,53 @@ __device__ __forceinline__ float sh_bnrelu(float z, float sc, float sh, int s16)
   const float zq = s16 ? bf16_bits_f32(f32_bf16_bits(z)) : z;
   return clamp_lo(fmaf(sc, zq, sh), 0.f);
 }
+// Round 3: the accumulators are formed TRANSPOSED -- the kernel fragment is the MFMA's A operand, the activation fragment its B operand
+// (same data, same k order: the same sums) -- so a lane holds ONE POINT's 16 channels c0 + 4h + 8g + {0..3}, g = 0..3, instead of one
+// channel's 16 points.  Adjacent channels are adjacent registers: a group of four is rounded by two v_cvt_pk_bf16_f32 and stored with one
+// 8-byte LDS write, with no cross-lane exchange.  The epilogues were 17 vector instructions per accumulator element (selects on the
+// run-time storage flag, one DPP swap and three selects per pair, two scalar conversions) against 416 MFMAs per wave: the launch was
+// bound by them (47 us at C2 for 6 us of matrix-core time).  Per-channel constants are now per REGISTER: loaded as float4 groups.
+struct sh_coef { float4 v[4]; };                                       // one constant for each of the lane's 16 channels
+__device__ __forceinline__ sh_coef sh_load_coef(const float* __restrict__ p, int c0, int h) {
+  sh_coef c;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) c.v[g] = *reinterpret_cast<const float4*>(p + c0 + 8 * g + 4 * h);
+  return c;
+}
+__device__ __forceinline__ float sh_c(const sh_coef& c, int g, int q) { return q == 0 ? c.v[g].x : (q == 1 ? c.v[g].y : (q == 2 ? c.v[g].z : c.v[g].w)); }
+typedef __attribute__((ext_vector_type(2))) float seg_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 seg_bf16x2;
+// BN + ReLU of the lane's 16 channels (the stored-then-reloaded form: S16 rounds the pre-BN value to bf16 first, as the layer-by-layer
+// plan's 16-bit store does), fp32 results
+template <bool S16, bool BIAS>
+__device__ __forceinline__ void sh_bnrelu16(const seg_f32x16& acc, const sh_coef& bias, const sh_coef& sc, const sh_coef& sh, float (&y)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int q = 0; q < 4; q += 2) {
+      float z0 = acc[4 * g + q], z1 = acc[4 * g + q + 1];
+      if (BIAS) { z0 += sh_c(bias, g, q); z1 += sh_c(bias, g, q + 1); }
+      if (S16) {
+        const seg_f32x2 zz = {z0, z1};
+        const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(zz, seg_bf16x2));
+        z0 = __builtin_bit_cast(float, u << 16);
+        z1 = __builtin_bit_cast(float, u & 0xffff0000u);
+      }
+      y[4 * g + q] = clamp_lo(fmaf(sh_c(sc, g, q), z0, sh_c(sh, g, q)), 0.f);
+      y[4 * g + q + 1] = clamp_lo(fmaf(sh_c(sc, g, q + 1), z1, sh_c(sh, g, q + 1)), 0.f);
+    }
+}
+// ... -> bf16 -> the point's row of an LDS image (operand of the next layer)
+__device__ __forceinline__ void sh_store16(__bf16* img, int pitch, int row, int c0, int h, const float (&y)[16]) {
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    const seg_f32x2 a = {y[4 * g], y[4 * g + 1]}, b = {y[4 * g + 2], y[4 * g + 3]};
+    uint2 w;
+    w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(a, seg_bf16x2));
+    w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(b, seg_bf16x2));
+    *reinterpret_cast<uint2*>(img + row * pitch + c0 + 8 * g + 4 * h) = w;
+  }
+}
 // Kernel fragments are REQUESTED a phase ahead of their use; a compiler-level memory fence (no instruction) after each group of
 // requests keeps the compiler from sinking the loads back to their first use -- a workgroup walks ~80 dependent k-steps, and with
 // the fragment of each step requested at the step the kernel ran at one global-memory round trip per step.  (An empty asm that
@@ -283,7 +330,7 @@ __device__ __forceinline__ float sh_bnrelu(float z, float sc, float sh, int s16)
 // Workgroup barrier for LDS hand-offs only: this wave's LDS traffic is drained, the global loads in flight are NOT (__syncthreads
 // waits for vmcnt(0) too, which would land every prefetched fragment at the next barrier: one memory round trip per barrier)
 #define SH_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-template <int MB>
+template <int MB, bool S16>
 __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(const SegHeadArgs a) {
   constexpr int ROWS = 32 * MB, SH_REGION_A = sh_region_a(ROWS);
   extern __shared__ __attribute__((aligned(16))) unsigned char sh_sm[];
@@ -347,8 +394,8 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
   const int c3 = 32 * wave + r;                             // this lane's seg_l3 / seg_l4 channel
   // Loads return in issue order: a wait for the NEWEST load drains everything requested before it.  So the small per-channel
   // coefficient loads go out BEFORE the fragment prefetches they would otherwise sit behind.
-  const float sc2v[2] = {a.sc2[64 * wave + r], a.sc2[64 * wave + 32 + r]}, sh2v[2] = {a.sh2[64 * wave + r], a.sh2[64 * wave + 32 + r]};
-  const float sc3v = a.sc3[c3], sh3v = a.sh3[c3], sc4v = a.sc4[c3], sh4v = a.sh4[c3];
+  // (a layer's per-channel coefficients -- 16 registers each now -- are requested in front of that layer's MFMAs, not here: held from
+  //  the top of the kernel they cost 128 registers and spills)
   seg_bf16x8 b1[4], b2[8][2];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) { b1[ks] = bfrag(a.w1t, 64, 32 * wave + r, ks * 16); }
@@ -364,13 +411,13 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
     for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc1[m][e] = 0.f;
-    const int c1 = 128 * j + 32 * wave + r;                 // this lane's seg_l1 channel
-    const float bias = a.gb[(long long)cloud * 512 + c1], sc = a.sc1[c1], sh = a.sh1[c1];
+    const int c1 = 128 * j + 32 * wave;                     // this wave's 32 seg_l1 channels of the chunk
+    const sh_coef bias = sh_load_coef(a.gb + (long long)cloud * 512, c1, h), sc = sh_load_coef(a.sc1, c1, h), sh = sh_load_coef(a.sh1, c1, h);
     SH_KEEP_ABOVE();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
-      for (int m = 0; m < MB; ++m) acc1[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(Ain, SH_P64, m, ks * 16), b1[ks], acc1[m], 0, 0, 0);
+      for (int m = 0; m < MB; ++m) acc1[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1[ks], afrag(Ain, SH_P64, m, ks * 16), acc1[m], 0, 0, 0);
     }
     // next chunk's seg_l1 fragments: under this chunk's epilogue and seg_l2 steps.  Unconditional (the last chunk re-requests its
     // own): behind a branch the compiler must assume at the join that the requests were NOT made and waits for everything
@@ -381,9 +428,8 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
       float y[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) y[e] = sh_bnrelu(acc1[m][e] + bias, sc, sh, a.s16);
-      sh_store_block(S1c, SH_P128, m, 32 * wave + r, h, lane, y);
+      sh_bnrelu16<S16, true>(acc1[m], bias, sc, sh, y);
+      sh_store16(S1c, SH_P128, m * 32 + r, 32 * wave, h, y);
     }
     SH_BARRIER();
 #pragma unroll
@@ -392,7 +438,7 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
       for (int m = 0; m < MB; ++m) {
         const seg_bf16x8 af = afrag(S1c, SH_P128, m, ks * 16);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b2[ks][n], acc2[m][n], 0, 0, 0);
+        for (int n = 0; n < 2; ++n) acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2[ks][n], af, acc2[m][n], 0, 0, 0);
       }
       // the registers of this step go straight to the same step of the next chunk (unconditional, as above)
 #pragma unroll
@@ -401,7 +447,9 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
     }
     SH_BARRIER();                                        // the chunk image is overwritten by the next chunk
   }
-  // seg_l3's first eight fragments and all of seg_l4's: requested now, land under seg_l2's epilogue
+  // seg_l2's coefficients, seg_l3's first eight fragments and all of seg_l4's: requested now, land under seg_l2's epilogue
+  const sh_coef sc2v[2] = {sh_load_coef(a.sc2, 64 * wave, h), sh_load_coef(a.sc2, 64 * wave + 32, h)};
+  const sh_coef sh2v[2] = {sh_load_coef(a.sh2, 64 * wave, h), sh_load_coef(a.sh2, 64 * wave + 32, h)};
   seg_bf16x8 b3[8], b4[8];
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks) { b3[ks] = bfrag(a.w3t, 256, c3, ks * 16); b4[ks] = bfrag(a.w4t, 128, c3, ks * 16); }
@@ -409,19 +457,18 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
   // ---- seg_l2 -> LDS ----
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
-    const int c2 = 64 * wave + 32 * n + r;
-    const float sc = sc2v[n], sh = sh2v[n];
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
       float y[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) y[e] = sh_bnrelu(acc2[m][n][e], sc, sh, a.s16);
-      sh_store_block(S2, SH_P256, m, c2, h, lane, y);
+      sh_bnrelu16<S16, false>(acc2[m][n], sc2v[n], sc2v[n], sh2v[n], y);
+      sh_store16(S2, SH_P256, m * 32 + r, 64 * wave + 32 * n, h, y);
     }
   }
   SH_BARRIER();
   // ---- seg_l3 (256 -> 128): 32 columns per wave ----
   {
+    const sh_coef sc3v = sh_load_coef(a.sc3, 32 * wave, h), sh3v = sh_load_coef(a.sh3, 32 * wave, h);
+    SH_KEEP_ABOVE();
     seg_f32x16 acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -430,24 +477,24 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
 #pragma unroll
     for (int ks = 0; ks < 16; ++ks) {
 #pragma unroll
-      for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(S2, SH_P256, m, ks * 16), b3[ks & 7], acc[m], 0, 0, 0);
+      for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3[ks & 7], afrag(S2, SH_P256, m, ks * 16), acc[m], 0, 0, 0);
       if (ks < 8) {                                         // steps 8..15 take over the registers of steps 0..7
         b3[ks] = bfrag(a.w3t, 256, c3, (ks + 8) * 16);
         SH_KEEP_ABOVE();
       }
     }
-    const float sc = sc3v, sh = sh3v;
 #pragma unroll
     for (int m = 0; m < MB; ++m) {                             // region A: the input tile and chunk image are dead
       float y[16];
-#pragma unroll
-      for (int e = 0; e < 16; ++e) y[e] = sh_bnrelu(acc[m][e], sc, sh, a.s16);
-      sh_store_block(S3, SH_P128, m, c3, h, lane, y);
+      sh_bnrelu16<S16, false>(acc[m], sc3v, sc3v, sh3v, y);
+      sh_store16(S3, SH_P128, m * 32 + r, 32 * wave, h, y);
     }
   }
   SH_BARRIER();
   // ---- seg_l4 (128 -> 128) -> the output layer's input, fp32 (it is split hi + lo there, as in seg_out_fwd) ----
   {
+    const sh_coef sc4v = sh_load_coef(a.sc4, 32 * wave, h), sh4v = sh_load_coef(a.sh4, 32 * wave, h);
+    SH_KEEP_ABOVE();
     seg_f32x16 acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -456,16 +503,16 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
 #pragma unroll
-      for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(afrag(S3, SH_P128, m, ks * 16), b4[ks], acc[m], 0, 0, 0);
+      for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b4[ks], afrag(S3, SH_P128, m, ks * 16), acc[m], 0, 0, 0);
     }
-    const float sc = sc4v, sh = sh4v;
 #pragma unroll
-    for (int m = 0; m < MB; ++m)
+    for (int m = 0; m < MB; ++m) {
+      float y[16];
+      sh_bnrelu16<S16, false>(acc[m], sc4v, sc4v, sh4v, y);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int row = m * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        S4f[row * SH_PF + c3] = sh_bnrelu(acc[m][e], sc, sh, a.s16);                 // region B: seg_l2's image is dead
-      }
+      for (int g = 0; g < 4; ++g)                                                    // region B: seg_l2's image is dead
+        *reinterpret_cast<float4*>(S4f + (m * 32 + r) * SH_PF + 32 * wave + 8 * g + 4 * h) = make_float4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3]);
+    }
   }
   SH_BARRIER();                                          // seg_l3's image (region A) is dead from here
   // ---- output layer: kernel image (bf16 hi + lo, channel-major) into region A, logits of a 32-row block per wave (waves 0, 1) ----
@@ -555,14 +602,18 @@ int seg_head_fused(const pn_operand* x, const float* gb, const void* w1t, const 
   static const int force_mb = getenv("PN_SEGHEAD_MB") ? atoi(getenv("PN_SEGHEAD_MB")) : 0;     // experiment switch: 2 or 4
   const bool tall = force_mb ? force_mb == 4 : (long long)B * cdiv(N, 128) >= 256;               // 128-row tiles while they still fill the chip
   if (tall) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_head_fused_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                       sh_region_a(128) + sh_region_b(128));
-    (void)attr;
+    static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_head_fused_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        sh_region_a(128) + sh_region_b(128));
+    static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_head_fused_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        sh_region_a(128) + sh_region_b(128));
+    (void)attr1; (void)attr0;
     a.tiles_per_cloud = cdiv(N, 128);
-    hipLaunchKernelGGL(seg_head_fused_kernel<4>, dim3(B * a.tiles_per_cloud), dim3(256), sh_region_a(128) + sh_region_b(128), st, a);
+    if (s16) hipLaunchKernelGGL((seg_head_fused_kernel<4, true>), dim3(B * a.tiles_per_cloud), dim3(256), sh_region_a(128) + sh_region_b(128), st, a);
+    else hipLaunchKernelGGL((seg_head_fused_kernel<4, false>), dim3(B * a.tiles_per_cloud), dim3(256), sh_region_a(128) + sh_region_b(128), st, a);
   } else {
     a.tiles_per_cloud = cdiv(N, 64);
-    hipLaunchKernelGGL(seg_head_fused_kernel<2>, dim3(B * a.tiles_per_cloud), dim3(256), sh_region_a(64) + sh_region_b(64), st, a);
+    if (s16) hipLaunchKernelGGL((seg_head_fused_kernel<2, true>), dim3(B * a.tiles_per_cloud), dim3(256), sh_region_a(64) + sh_region_b(64), st, a);
+    else hipLaunchKernelGGL((seg_head_fused_kernel<2, false>), dim3(B * a.tiles_per_cloud), dim3(256), sh_region_a(64) + sh_region_b(64), st, a);
   }
   PN_CHECK_LAUNCH();
   return PN_OK;

@@ -19,7 +19,7 @@ def main():
     import parity_harness as H
     from pointcloudprocessing_amd.pointnet.PointNet import PointNet
     dev = torch.device("cuda:0")
-    Bg, N = 8, 200
+    Bg, N = 16, 200
     B = Bg // world
     spec, lw = H.PROFILES[profile]
     params = O.init_params(H.CCLS, H.CSEG, seed=17, randomize_bn=True)
@@ -33,13 +33,36 @@ def main():
     outs = m.fused_loss_step(pc[sl].contiguous().to(dev), y_cls[sl].to(torch.int32).to(dev), y_seg[sl].contiguous().to(torch.int32).to(dev),
                              se3[sl].contiguous().to(dev), lw, keep=kp)
     torch.cuda.synchronize()
+    # per-layer intermediates of this rank's clouds (diagnostics: the parent compares them with the whole-batch run's rows)
+    dump = {}
+    names = []
+    for wn, C_ in (("iT.c1", 64), ("iT.c2", 128), ("m11", 64), ("m12", 64), ("fT.c1", 64), ("fT.c2", 128), ("m21", 64), ("m22", 128), ("s1", 512), ("s2", 256),
+                   ("s3", 128), ("s4", 128)):
+        for suffix in ("Z", "dy"):
+            dump[f"{wn}.{suffix}"] = m.workspace_tensor(f"{wn}.{suffix}", B, N, True, m.activation_dtype).float().cpu().view(-1, C_)
+        for suffix in ("scale", "shift", "ca", "cb", "cc", "mean", "invstd"):
+            dump[f"{wn}.{suffix}"] = m.workspace_tensor(f"{wn}.{suffix}", B, N, True).cpu()
+    for wn in ("iT.m3", "fT.m3", "mm23"):
+        for suffix, rows in (("g_all", Bg), ("zstar_all", Bg), ("hs", Bg), ("dG", Bg)):
+            dump[f"{wn}.{suffix}"] = m.workspace_tensor(f"{wn}.{suffix}", B, N, True).cpu().view(rows, 1024)
+        for suffix in ("e", "f", "q"):
+            dump[f"{wn}.{suffix}"] = m.workspace_tensor(f"{wn}.{suffix}", B, N, True).cpu()
+        dump[f"{wn}.arg"] = m.workspace_tensor(f"{wn}.arg", B, N, True, torch.int32).cpu().view(B, 1024)
+        dump[f"{wn}.D"] = m.workspace_tensor(f"{wn}.D", B, N, True, m.activation_dtype).float().cpu().view(-1, 128)
+        for suffix in ("gram", "GW", "Pm"):      # linear in this rank's rows: the parent compares the SUM over the ranks
+            dump[f"{wn}.{suffix}+"] = m.workspace_tensor(f"{wn}.{suffix}", B, N, True).cpu()
+    for wn, per in (("iT.R", 9), ("fT.R", 4096), ("iT.dR", 9), ("fT.dR", 4096), ("dGcls", 1024), ("dGseg", 1024), ("cls_dlogits", H.CCLS)):
+        dump[wn] = m.workspace_tensor(wn, B, N, True).cpu().view(Bg, per)
+    dump["X64"] = m.workspace_tensor("X64", B, N, True, m.activation_dtype).float().cpu().view(-1, 64)
+    dump["dX64"] = m.workspace_tensor("dX64", B, N, True, m.activation_dtype).float().cpu().view(-1, 64)
     g = m.grads_flat
+    dump["grads_local+"] = g.detach().cpu().clone()
     if rank != 0:
         g.mul_(m.replicated_grad_mask())
     dist.all_reduce(g)
     torch.cuda.synchronize()
     torch.save({"grads": g.cpu(), "weights": {k: v.cpu().clone() for k, v in m.named_weights().items()}, "outs": [o.cpu() for o in outs],
-                "scalars": m.scalars.cpu()}, os.path.join(out, f"rank{rank}.pt"))
+                "scalars": m.scalars.cpu(), "dump": dump}, os.path.join(out, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

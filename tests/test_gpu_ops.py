@@ -347,13 +347,17 @@ def test_fps_bit_exact_indices(dev, B, N, M):
         assert np.array_equal(md[b].cpu().numpy(), rmd)
 
 
+@pytest.mark.parametrize("mode", ["1", "2"])
 @pytest.mark.parametrize("N,M", [(8000, 2500), (20480, 1200), (4097, 4097), (12345, 300)])
-def test_fps_pruned_kernel_on_spatially_ordered_clouds(dev, N, M):
-    """the pruned FPS kernel (pn_sample.hip: fps_pruned_kernel, clouds of 4097 .. 20480 points) in the regime it is built for: points in
+def test_fps_pruned_kernel_on_spatially_ordered_clouds(dev, monkeypatch, N, M, mode):
+    """the pruned FPS kernel (pn_sample.hip: fps_pruned_kernel, clouds of 4097 .. 20480 points; an experiment behind PN_FPS_PRUNE -- on the
+    C5 scan its bounding-box test skips too little to pay, DESIGN.md section 7 -- mode 1 with the test, mode 2 its one-barrier round
+    without it) in the regime it is built for: points in
     (z, y, x) order as the voxel grid leaves them, so that most 64-point groups are skipped in most rounds -- indices and final minimum
     distances bit-exact against the NumPy oracle, duplicated points (distance ties -> lowest index) inside one group, across groups of
     one wave and across waves, M = N (every point drawn once, then ties at distance 0)."""
     ops = _ops()
+    monkeypatch.setenv("PN_FPS_PRUNE", mode)
     rng = np.random.default_rng(N + M)
     side = int(np.ceil(N ** (1.0 / 3.0))) + 1
     gi = np.stack(np.meshgrid(np.arange(side), np.arange(side), np.arange(side), indexing="ij"), -1).reshape(-1, 3)[:N]     # z, y, x ascending

@@ -24,7 +24,7 @@ for s in "$@"; do
     smoke) step "smoke" 200 bash -c "python -c 'import __graft_entry__ as g; g.smoke()' > $out/smoke.log 2>&1" ;;
     bench) n=bench; [ -e $out/bench.json ] && n=bench_$(date +%s | tail -c 4)
       step "bench ($n)" 300 bash -c "python bench.py > $out/$n.json 2> $out/$n.err" ;;
-    bench:*) n=$(echo "${s#bench:}" | tr -c 'A-Za-z0-9_.\n' '_' | cut -c1-40)
+    bench:*) n=$(echo "${s#bench:}" | tr -c 'A-Za-z0-9_.\n' '_' | cut -c1-40)_$(date +%s | tail -c 4)
       step "bench ${s#bench:}" 300 bash -c "python bench.py --no-cpu-baseline ${s#bench:} > $out/bench_$n.json 2> $out/bench_$n.err" ;;
     configs)
       for cfg in "c3 --points 2048 --profile final" "c3_all --points 2048 --profile all" "c4rank --batch 8 --points 4096" "b32n4096 --points 4096" \
