@@ -2,7 +2,19 @@
 single-process step on the 2*B clouds -- the reference computes every BatchNormalization statistic over the whole batch on one device
 (PointNet.py:528,559,623,647).  Two ranks (gloo process group; both on the one GPU of the box) run PointNet(sync_bn_world=2) on the two
 halves of a batch; the parent runs the plain model on the whole batch; gradients (summed over the ranks as engine.TrainStep sums them),
-moving statistics, outputs and loss sums must agree to fp32 rounding (bf16x3: fp32-grade products)."""
+moving statistics, outputs and loss sums must agree.
+
+How "agree" is decided.  The two runs add the same batch statistics in different orders (per-rank partial sums, then the ranks), so
+their BatchNormalization coefficients differ in the last bit, and the hi/lo bf16 split of the next operand turns that into differences of
+1e-5 of a layer's range a few layers on.  That is enough to decide a handful of near-ties differently: the point of a cloud that holds
+a channel's pooled maximum (2-3 of the 49 152 maxima of this step) and per-point ReLU signs.  Each such decision is a legitimate
+other gradient -- it moves one cloud's contribution to a channel of mlp_2_3.kernel to another point, 0.75 of that tensor's largest
+element in one column, 1e-2 .. 1e-1 in everything upstream of it, nothing elsewhere (measured; report lines "rows of the maxima that
+differ").  A whole-run gradient comparison can therefore not be tight.  The discriminating check is teacher-forced instead (tests/teacher_forced.py,
+as for the single-process parity tests): rank 0 presents the ranks' workspaces as ONE whole-batch workspace (syncbn_worker.MergedRun)
+and every layer -- statistics over all 2*B clouds, coefficients, data gradients, the summed parameter gradients -- is recomputed in
+fp64 from the step's own stored inputs with the single-process tolerances.  The whole-run comparison stays as a report, with tight
+bounds where no such decision can interfere (classification head, moving statistics, outputs, loss sums)."""
 import os
 import socket
 import subprocess
@@ -55,44 +67,16 @@ def test_two_rank_sync_bn_step_equals_the_single_process_step_on_the_whole_batch
     B = Bg // world
     # diagnostics first: every stored intermediate of each rank's clouds against the same rows of the whole-batch run (true-convention
     # gradients: the whole-batch run's activation gradients are the ranks' as they are)
-    for k in [k for k in res[0]["dump"] if k.endswith("+")]:
-        tot = sum(res[r]["dump"][k].double() for r in range(world))
-        if k == "grads_local+":
-            for n in m._weights.slots:
-                ref = m.named_grads()[n].cpu().double()
-                parts = [m._weights.view(n, res[r]["dump"][k].to(dev)).cpu().double() for r in range(world)]
-                sc_ = float(ref.abs().max()) + 1e-30
-                H.report(f"sync-BN [{profile}] local grads {n:40s} |ref| {sc_:.3e}  rank0 {float(parts[0].abs().max()):.3e} rank1 {float(parts[1].abs().max()):.3e}"
-                         f"  sum-ref {float((parts[0] + parts[1] - ref).abs().max()) / sc_:.3e}  r0-ref {float((parts[0] - ref).abs().max()) / sc_:.3e}")
-            continue
-        ref = m.workspace_tensor(k[:-1], Bg, N, True).cpu().double()
-        H.report(f"sync-BN [{profile}] summed ws {k:16s} rel diff {float((tot.view(-1) - ref.view(-1)).abs().max()) / (float(ref.abs().max()) + 1e-30):.3e}")
-    def dw_from_pieces(Z, scale, shift, arg, hs, gram, GW, e, f, rows):
-        a = torch.relu(Z.double() * scale.double() + shift.double()).view(rows, N, 128)
-        K_ = 128
-        G_ = gram.double()[:K_ * K_].view(K_, K_)
-        a1 = gram.double()[K_ * K_:K_ * K_ + K_]
-        sel = torch.gather(a, 1, arg.long().view(rows, 1024, 1).expand(rows, 1024, K_))      # (rows, C, K)
-        scat = torch.einsum("bck,bc->kc", sel, hs.double())
-        a1_rows = a.sum((0, 1))
-        return scat + a1[:, None] * f.double()[None, :] - e.double()[None, :] * GW.double().view(K_, 1024), float((a1 - a1_rows).abs().max() / a1_rows.abs().max()), \
-            float((G_ - torch.einsum("bnk,bnj->kj", a, a)).abs().max() / G_.abs().max())
-    wsf = lambda k, dt=torch.float32: m.workspace_tensor(k, Bg, N, True, dt).cpu()
-    ref_dw, ea, eg = dw_from_pieces(wsf("m22.Z", m.activation_dtype).float().view(-1, 128), wsf("m22.scale"), wsf("m22.shift"), wsf("mm23.arg", torch.int32).view(Bg, 1024),
-                                    wsf("mm23.hs").view(Bg, 1024), wsf("mm23.gram"), wsf("mm23.GW"), wsf("mm23.e"), wsf("mm23.f"), Bg)
-    gk = m.named_grads()["mlp_2_3.kernel"].cpu().double()
-    H.report(f"sync-BN [{profile}] whole batch: dW(mlp_2_3) from its stored pieces vs the kernel's: {float((ref_dw - gk).abs().max() / gk.abs().max()):.3e} (a1 {ea:.2e} gram {eg:.2e})")
-    for r in range(world):
-        d_ = res[r]["dump"]
-        dw_r, ea, eg = dw_from_pieces(d_["m22.Z"], d_["m22.scale"], d_["m22.shift"], d_["mm23.arg"], d_["mm23.hs"].view(Bg, 1024)[r * B:(r + 1) * B], d_["mm23.gram+"],
-                                      d_["mm23.GW+"], d_["mm23.e"], d_["mm23.f"], B)
-        got = m._weights.view("mlp_2_3.kernel", d_["grads_local+"].to(dev)).cpu().double()
-        H.report(f"sync-BN [{profile}] rank {r}: dW(mlp_2_3) from its stored pieces vs the kernel's: {float((dw_r - got).abs().max() / gk.abs().max()):.3e} (a1 {ea:.2e} gram {eg:.2e})"
-                 f"  |a1 f| {float((d_['mm23.gram+'].double()[128 * 128:128 * 128 + 128, None] * d_['mm23.f'].double()[None, :]).abs().max()):.3e}")
+    # rows of the maxima that differ between the two runs (near-ties of the pooled maximum decided by the last bits of the forward
+    # pass): each one moves a whole cloud's gradient of that channel to another point -- see the module docstring
+    flips = {}
+    for wn in ("iT.m3", "fT.m3", "mm23"):
+        a_ref = m.workspace_tensor(wn + ".arg", Bg, N, True, torch.int32).cpu().view(Bg, 1024)
+        a_syn = torch.cat([res[r]["dump"][wn + ".arg"].view(B, 1024) for r in range(world)])
+        flips[wn] = int((a_ref != a_syn).sum()) if int(a_ref.min()) >= 0 else None
+    H.report(f"sync-BN [{profile}] rows of the maxima that differ between the two-rank run and the whole-batch run: {flips}")
     for r in range(world):
         for k, v in res[r]["dump"].items():
-            if k.endswith("+"):
-                continue
             wn = k
             if k.endswith(("_all",)):
                 ref = m.workspace_tensor(k[:-4], Bg, N, True).cpu().view(Bg, -1)
@@ -132,8 +116,13 @@ def test_two_rank_sync_bn_step_equals_the_single_process_step_on_the_whole_batch
         H.report(f"sync-BN [{profile}] grad {n:44s} rel diff {e:.3e} (max |ref| {scale:.3e})")
     H.report(f"sync-BN [{profile}]: worst relative gradient difference between 2 ranks x {B} clouds and 1 x {Bg} clouds: {worst:.3e}")
     errs.sort(reverse=True)
-    assert worst < 1e-2, errs[:5]
-    assert errs[len(errs) // 2][0] < 1e-3, errs[len(errs) // 2]                     # the median layer
+    # the discriminating check: every layer of the merged two-rank run against its fp64 recomputation (whole-batch semantics)
+    assert not res[0]["forced_fails"], res[0]["forced_fails"][:8]
+    # the classification head sees no arg-max or per-point ReLU: its gradients agree to rounding
+    for e, n in errs:
+        if n.startswith("mlp_cls_"):
+            assert e < 1e-3, (n, e)
+    assert errs[len(errs) // 2][0] < 2e-2, errs[len(errs) // 2]                     # the median tensor (see the module docstring)
     # moving statistics: the whole batch's on every rank
     nw = m.named_weights()
     for n, v in nw.items():
@@ -149,3 +138,55 @@ def test_two_rank_sync_bn_step_equals_the_single_process_step_on_the_whole_batch
     # loss / metric sums add up; the regulariser sums too
     sc = sum(res[r]["scalars"].double() for r in range(world))
     assert torch.allclose(sc[:7], m.scalars.cpu().double()[:7], rtol=1e-4, atol=1e-4), (sc[:7].tolist(), m.scalars.cpu()[:7].tolist())
+
+
+def test_two_rank_sync_bn_trainer_step_follows_the_whole_batch_run(dev, tmp_path):
+    """engine.TrainStep with PointNet(sync_bn_world=2) (what pointnet_train.py builds for params.sync_batchnorm): dropout masks for all
+    ranks' rows from one seed, gradients summed with the redundantly computed slots counted once, Adam on every rank.  The ranks must
+    hold bit-identical parameters after every step, the first step's loss sums must be the whole-batch run's, and the run must descend
+    with it (Adam's first updates are ~lr * sign(gradient): the trajectories decorrelate at rounding-level gradient differences, so the
+    later steps are held to the band tests/test_gpu_train.py uses for two precision modes of one model)."""
+    from pointcloudprocessing_amd.engine import TrainStep
+    from pointcloudprocessing_amd.optim import KerasAdam
+    from pointcloudprocessing_amd.pointnet.PointNet import PointNet
+    precision, world, Bg, N, steps = "bf16x3", 2, 16, 200, 14
+    port = _free_port()
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "syncbn_worker.py"), str(r), str(world), port, str(tmp_path), precision, "all",
+                               "engine", str(steps)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    spec, lw = H.PROFILES["all"]
+    params = O.init_params(H.CCLS, H.CSEG, seed=17, randomize_bn=True)
+    pc, y_cls, y_seg, se3, _ = H.make_inputs(Bg, N, 33, "shapes")
+    m = PointNet(H.CCLS, H.CSEG, 0.3, 42, precision=precision, device=dev, regularize_input_transform=True, regularize_feature_transform=True)
+    m.set_weights(params)
+    H.apply_profile(m, spec)
+    opt = KerasAdam(m.params_flat.data, 1e-3, 7000, 0.7)
+    ts = TrainStep(m, opt, Bg, N, lw, use_graph=False)
+    ts._mask_seed = 1234
+    ref = []
+    a = (pc.to(dev), y_cls.to(torch.int32).to(dev), y_seg.to(torch.int32).to(dev), se3.to(dev))
+    for _ in range(steps):
+        ts(*a)
+        ref.append(m.scalars.cpu().double()[:2].clone())
+    torch.cuda.synchronize()
+    ref = torch.stack(ref)
+    for p in procs:
+        try:
+            log, _ = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            log, _ = p.communicate()
+        assert p.returncode == 0, log[-3000:]
+    res = [torch.load(os.path.join(str(tmp_path), f"engine{r}.pt"), weights_only=True) for r in range(world)]
+    assert torch.equal(res[0]["params"], res[1]["params"]), "the ranks' parameters diverged"
+    assert res[0]["iterations"] == steps
+    got = res[0]["sums"] + res[1]["sums"]
+    H.report("sync-BN trainer: classification loss sum per step, 2 ranks x 8 clouds: " + " ".join(f"{float(v):.3f}" for v in got[:, 0]))
+    H.report("sync-BN trainer: classification loss sum per step, 1 x 16 clouds:       " + " ".join(f"{float(v):.3f}" for v in ref[:, 0]))
+    assert torch.allclose(got[0], ref[0], rtol=1e-4), (got[0].tolist(), ref[0].tolist())            # same weights, same masks, whole-batch statistics
+    for i in range(1, min(10, steps)):
+        assert abs(float(got[i, 0] - ref[i, 0])) < 0.35 * float(ref[0, 0]), (i, got[:, 0].tolist(), ref[:, 0].tolist())
+    assert float(got[-3:, 0].min()) < 0.6 * float(got[0, 0]), got[:, 0].tolist()
+    moved = (m.params_flat.data.cpu() - res[0]["params"]).abs()
+    start = torch.cat([torch.as_tensor(v, dtype=torch.float32).reshape(-1) for v in params.values()])
+    H.report(f"sync-BN trainer: parameters after {steps} steps, two-rank vs whole-batch: median |difference| {float(moved.median()):.2e}, "
+             f"99th percentile {float(moved.kthvalue(int(0.99 * moved.numel())).values):.2e} (each run moved its parameters by up to {steps} x 1e-3)")
