@@ -61,6 +61,9 @@ struct WCopyDesc {
   const float* w;
   void *nat, *tr;
   int K, C;
+  int frag;       // 0: tr = [C][K];  1: tr = the same values FRAGMENT-MAJOR for 32x32x16 MFMAs (the fused segmentation head): the 16 bytes
+                  // of lane (h, r) of fragment (cb = c / 32, ks = k / 16) -- column c = 32 cb + r, k = 16 ks + 8 h .. + 8 -- at element
+                  // ((cb * K/16 + ks) * 64 + 32 h + r) * 8;  needs C % 32 == 0, K % 16 == 0
 };
 int fwd_prologue(const float* xyz, int B, int N, float* out, float* centroid, float* scale, const float* const* w, const float* const* sgn,
                  const int* K, const int* C, void* const* hi, void* const* lo, unsigned* zero_u, int zero_u_n, float* grads, long long n_grads,

@@ -638,9 +638,9 @@ struct Run {
       WCopyDesc wc[PN_WCOPY_MAX];
       int nwc = 0;
       bool dropped = false;      // a layer that does not fit the launch's tables must fail the call, not run on stale copies / coefficients
-      auto add_wc = [&](const CL& l, const float* Wk) {
+      auto add_wc = [&](const CL& l, const float* Wk, int frag = 0) {
         if (!l.w16) return;
-        if (nwc < PN_WCOPY_MAX) wc[nwc++] = WCopyDesc{Wk, l.w16, l.wt16, l.K, l.C};
+        if (nwc < PN_WCOPY_MAX) wc[nwc++] = WCopyDesc{Wk, l.w16, l.wt16, l.K, l.C, frag};
         else dropped = true;
       };
       if (!d.vanilla) {
@@ -649,7 +649,9 @@ struct Run {
         add_wc(w.fT.c2, p(L.fT.c2.kernel));
       }
       add_wc(w.m12, p(L.m12.kernel)); add_wc(w.m21, p(L.m21.kernel)); add_wc(w.m22, p(L.m22.kernel));
-      add_wc(w.s1, p(L.s1.kernel)); add_wc(w.s2, p(L.s2.kernel)); add_wc(w.s3, p(L.s3.kernel)); add_wc(w.s4, p(L.s4.kernel));
+      // the fused frozen head reads its kernels as MFMA fragments (pn_segout.hip); the layer-by-layer plan as [C][K] rows
+      const int sf = fused_seg_head() ? 1 : 0;
+      add_wc(w.s1, p(L.s1.kernel), sf); add_wc(w.s2, p(L.s2.kernel), sf); add_wc(w.s3, p(L.s3.kernel), sf); add_wc(w.s4, p(L.s4.kernel), sf);
       // + the coefficients of every per-point layer whose BatchNormalization uses its moving statistics (bn_fin skips those layers)
       FrozenBnDesc fz[PN_FROZEN_MAX];
       int nfz = 0;

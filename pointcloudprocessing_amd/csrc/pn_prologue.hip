@@ -210,6 +210,7 @@ struct WCopyJobs {
   unsigned short* tr[PN_WCOPY_MAX];
   int K[PN_WCOPY_MAX], C[PN_WCOPY_MAX];
   int end[PN_WCOPY_MAX];          // running element count
+  unsigned char frag[PN_WCOPY_MAX];   // layout of the transposed copy (WCopyDesc.frag)
   int n;
 };
 // work item = eight consecutive outputs of one of the two copies: items [0, E/8) write `nat` (8 consecutive elements of the kernel:
@@ -242,7 +243,8 @@ __device__ __forceinline__ void wcopy_body(const WCopyJobs& j, int blk) {
     *reinterpret_cast<pr_bf16x8*>(j.nat[q] + (long long)local8 * 8) = h;
   } else {
     const int c = local8 % C, k0 = (local8 / C) * 8;
-    *reinterpret_cast<pr_bf16x8*>(j.tr[q] + (long long)c * K + k0) = h;
+    const long long at = j.frag[q] ? ((((long long)(c >> 5) * (K >> 4) + (k0 >> 4)) * 64 + 32 * ((k0 >> 3) & 1) + (c & 31)) * 8) : ((long long)c * K + k0);
+    *reinterpret_cast<pr_bf16x8*>(j.tr[q] + at) = h;
   }
 }
 // the same copies as a launch of their own (op-level ABI: pn_weights_copy16; the model plan makes them in its first launch)
@@ -346,6 +348,8 @@ int fwd_prologue(const float* xyz, int B, int N, float* out, float* centroid, fl
     PN_CHECK_ARG(q.w && q.nat && q.tr && q.K > 0 && q.C > 0 && q.K % 8 == 0 && q.C % 8 == 0, "fwd_prologue: bad kernel-copy job");
     a.wc.w[i] = q.w; a.wc.nat[i] = reinterpret_cast<unsigned short*>(q.nat); a.wc.tr[i] = reinterpret_cast<unsigned short*>(q.tr);
     a.wc.K[i] = q.K; a.wc.C[i] = q.C;
+    PN_CHECK_ARG(!q.frag || (q.K % 16 == 0 && q.C % 32 == 0), "fwd_prologue: a fragment-major kernel copy needs K %% 16 == 0, C %% 32 == 0");
+    a.wc.frag[i] = q.frag ? 1 : 0;
     total += q.K * q.C;
     a.wc.end[i] = total;
   }

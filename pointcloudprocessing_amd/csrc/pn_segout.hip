@@ -20,15 +20,12 @@ constexpr int SEG_WP = 128 + 8;   // LDS pitch (bf16) of the weight image: confl
 
 // logits of one point -> softmax, keras SparseCategoricalCrossentropy (probabilities clipped to [1e-7, 1 - 1e-7]), accuracy and
 // d(loss)/d(logits); shared by the stand-alone output kernel and the fused frozen head below
-__device__ __forceinline__ void seg_row_tail(const float (&acc)[SEG_CM], int C, long long row, const int* __restrict__ labels, float grad_scale,
-                                             float* __restrict__ probs, float* __restrict__ dlogits, float& loss, float& corr,
-                                             float (&dl)[SEG_CM]) {
+__device__ __forceinline__ void seg_row_probs(const float (&acc)[SEG_CM], int C, float (&p)[SEG_CM], int& am) {
     float mx = -INFINITY;
-    int am = 0;
+    am = 0;
 #pragma unroll
     for (int c = 0; c < SEG_CM; ++c)
       if (c < C && acc[c] > mx) { mx = acc[c]; am = c; }
-    float p[SEG_CM];
     float sum = 0.f;
 #pragma unroll
     for (int c = 0; c < SEG_CM; ++c) {
@@ -38,6 +35,27 @@ __device__ __forceinline__ void seg_row_tail(const float (&acc)[SEG_CM], int C, 
     const float inv = 1.f / sum;
 #pragma unroll
     for (int c = 0; c < SEG_CM; ++c) p[c] *= inv;
+}
+// loss and accuracy of one point from its probabilities; qs = sum of the clipped probabilities (the gradient needs it)
+__device__ __forceinline__ void seg_row_loss(const float (&p)[SEG_CM], int C, int y, int am, float& loss, float& corr, float& qs) {
+    float py = 1.f;
+    qs = 0.f;
+#pragma unroll
+    for (int c = 0; c < SEG_CM; ++c)
+      if (c < C) {
+        const float pc = clip_nan(p[c], 1e-7f, 1.f - 1e-7f);
+        qs += pc;
+        if (c == y) py = pc;
+      }
+    loss = -(logf(py) - logf(qs));
+    corr = (am == y) ? 1.f : 0.f;
+}
+__device__ __forceinline__ void seg_row_tail(const float (&acc)[SEG_CM], int C, long long row, const int* __restrict__ labels, float grad_scale,
+                                             float* __restrict__ probs, float* __restrict__ dlogits, float& loss, float& corr,
+                                             float (&dl)[SEG_CM]) {
+    float p[SEG_CM];
+    int am;
+    seg_row_probs(acc, C, p, am);
     if (probs) {
       float* po = probs + row * C;
 #pragma unroll
@@ -46,16 +64,8 @@ __device__ __forceinline__ void seg_row_tail(const float (&acc)[SEG_CM], int C, 
     }
     if (labels) {
       const int y = labels[row];
-      float qs = 0.f, py = 1.f;
-#pragma unroll
-      for (int c = 0; c < SEG_CM; ++c)
-        if (c < C) {
-          const float pc = clip_nan(p[c], 1e-7f, 1.f - 1e-7f);
-          qs += pc;
-          if (c == y) py = pc;
-        }
-      loss = -(logf(py) - logf(qs));
-      corr = (am == y) ? 1.f : 0.f;
+      float qs;
+      seg_row_loss(p, C, y, am, loss, corr, qs);
       float dp[SEG_CM];
       float dot = 0.f;
 #pragma unroll
@@ -236,19 +246,17 @@ __global__ __launch_bounds__(SEG_RPB) void seg_out_fwd_kernel(const pn_operand x
 constexpr int SH_ROWS = 64;                                               // rows per loss / accuracy partial (and per tile of the 64-row form)
 constexpr int SH_P64 = 64 + 8, SH_P128 = 128 + 8, SH_P256 = 256 + 8;     // LDS pitches (bf16 elements): conflict-free 16-byte rows
 constexpr int SH_PF = 128 + 4;                                            // fp32 pitch of the output layer's input
-// A workgroup takes MB 32-row blocks: 64 rows (two workgroups per CU), or 128 rows (one per CU) -- every workgroup streams ALL of the
-// head's kernels (424 KB of bf16 fragments) from L2 whatever its height, and at 64 rows that traffic (217 MB at B*N = 32,768) is what
-// bounds the launch; 128 rows halve it.  The taller form is used when it still fills the chip (seg_head_fused).
+// A workgroup takes MB 32-row blocks: 64 rows (two workgroups per CU; the default), or 128 rows (one per CU; PN_SEGHEAD_MB=4) -- every
+// workgroup streams ALL of the head's kernels (424 KB of bf16 fragments) from L2 whatever its height (seg_head_fused has the timings).
 constexpr int sh_region_a(int rows) { return (rows * SH_P64 + rows * SH_P128) * 2; }   // input tile + seg_l1 chunk; later seg_l3's output, then the
                                                                           // output layer's kernel image and logit tile
 constexpr int sh_region_b(int rows) { return rows * SH_P256 * 2; }                      // seg_l2's output; later the output layer's fp32 input
 static_assert(64 * SH_PF * 4 <= sh_region_b(64) && 128 * SH_PF * 4 <= sh_region_b(128), "region B holds the fp32 input of the output layer");
-static_assert(2 * 32 * SEG_WP * 2 + 64 * (SEG_CM + 1) * 4 <= sh_region_a(64) && 2 * 32 * SEG_WP * 2 + 128 * (SEG_CM + 1) * 4 <= sh_region_a(128),
-              "region A holds the output kernel image and the logit tile");
+static_assert(64 * (SEG_CM + 1) * 4 <= sh_region_a(64) && 128 * (SEG_CM + 1) * 4 <= sh_region_a(128), "region A holds the logit tile");
 struct SegHeadArgs {
   pn_operand x;                                     // (B*N, 64) lazy operand: X_64 (or relu(bn(mlp_1_2)) for the vanilla model)
   const float* gb;                                  // (B, 512) global-feature half of seg_l1, per cloud
-  const unsigned short *w1t, *w2t, *w3t, *w4t;      // bf16 transposed kernels [Cout][K]
+  const unsigned short *w1t, *w2t, *w3t, *w4t;      // bf16 kernels as MFMA fragments (WCopyDesc.frag = 1)
   const float *sc1, *sh1, *sc2, *sh2, *sc3, *sh3, *sc4, *sh4;   // BatchNormalization scale / shift (moving statistics)
   const float *w5, *b5;                             // output layer (128, C) fp32, bias (C)
   int N, C, tiles_per_cloud, s16;                   // s16: the layer-by-layer plan stores z as bf16 -- round the same way
@@ -330,23 +338,93 @@ __device__ __forceinline__ void sh_store16(__bf16* img, int pitch, int row, int 
 // Workgroup barrier for LDS hand-offs only: this wave's LDS traffic is drained, the global loads in flight are NOT (__syncthreads
 // waits for vmcnt(0) too, which would land every prefetched fragment at the next barrier: one memory round trip per barrier)
 #define SH_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-template <int MB, bool S16>
+// DBG (PN_SEGHEAD_DBG=16, tools/seghead_stamps.py): the product kernel + s_memtime stamps of wave 0 at its phase boundaries, left over
+// the tile's first 24 output probabilities
+#define SH_STAMP(i) do { if (DBG) stamp[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+// Per-channel constants of the whole head, staged once per workgroup (10 KB of LDS): the epilogues read them at LDS latency instead of
+// waiting a memory round trip behind the fragment prefetches (measured with the stamps: seg_l2's epilogue 8.9 k cycles for 8 blocks
+// against seg_l1's 2.2 k for 4 -- its 64 coefficients were requested where they were used)
+constexpr int SH_CO_GB = 0, SH_CO_SC1 = 512, SH_CO_SH1 = 1024, SH_CO_SC2 = 1536, SH_CO_SH2 = 1792, SH_CO_SC3 = 2048, SH_CO_SH3 = 2176, SH_CO_SC4 = 2304,
+              SH_CO_SH4 = 2432, SH_CO_B5 = 2560, SH_CO_FLOATS = 2560 + SEG_CM;
+// the output layer's kernel image (hi, lo: SEG_CM class rows each), built in the prologue.  The logit MFMAs read 32 "class" rows: rows
+// SEG_CM..31 of the lo image lie in the coefficient table behind it -- finite or not, those columns of the product are never stored
+constexpr int sh_region_c(int) { return 2 * SEG_CM * SEG_WP * 2; }
+static_assert((32 - SEG_CM) * SEG_WP * 2 <= SH_CO_FLOATS * 4, "the unused class rows of the lo image stay inside the allocation");
+constexpr int sh_region_d() { return SH_CO_FLOATS * 4; }
+constexpr int sh_lds_bytes(int rows) { return sh_region_a(rows) + sh_region_b(rows) + sh_region_c(rows) + sh_region_d(); }
+static_assert(sh_lds_bytes(128) <= 160 * 1024 && 2 * sh_lds_bytes(64) <= 160 * 1024, "one 128-row workgroup or two 64-row workgroups per CU");
+template <int MB, bool S16, bool DBG = false>
 __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(const SegHeadArgs a) {
-  constexpr int ROWS = 32 * MB, SH_REGION_A = sh_region_a(ROWS);
+  constexpr int ROWS = 32 * MB, SH_REGION_A = sh_region_a(ROWS), SH_REGION_B = sh_region_b(ROWS), SH_REGION_C = sh_region_c(ROWS);
+  unsigned stamp[DBG ? 24 : 1];
+  SH_STAMP(0);
   extern __shared__ __attribute__((aligned(16))) unsigned char sh_sm[];
   __bf16* Ain = reinterpret_cast<__bf16*>(sh_sm);
   __bf16* S1c = Ain + ROWS * SH_P64;
   __bf16* S3 = reinterpret_cast<__bf16*>(sh_sm);
   __bf16* S2 = reinterpret_cast<__bf16*>(sh_sm + SH_REGION_A);
   float* S4f = reinterpret_cast<float*>(sh_sm + SH_REGION_A);
-  __bf16* W5hi = reinterpret_cast<__bf16*>(sh_sm);
-  __bf16* W5lo = W5hi + 32 * SEG_WP;
-  float* lgt = reinterpret_cast<float*>(sh_sm + 2 * 32 * SEG_WP * 2);
+  float* prob_s = reinterpret_cast<float*>(sh_sm + SH_REGION_A);                                     // after the logits: region B is dead
+  __bf16* W5hi = reinterpret_cast<__bf16*>(sh_sm + SH_REGION_A + SH_REGION_B);
+  __bf16* W5lo = W5hi + SEG_CM * SEG_WP;
+  float* lgt = reinterpret_cast<float*>(sh_sm);                                                       // region A once seg_l3's image is dead
+  float* coef = reinterpret_cast<float*>(sh_sm + SH_REGION_A + SH_REGION_B + SH_REGION_C);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int cloud = blockIdx.x / a.tiles_per_cloud, tin = blockIdx.x - cloud * a.tiles_per_cloud;
   const int r0 = tin * ROWS, nrows = min(ROWS, a.N - r0);
   const long long row0 = (long long)cloud * a.N + r0;
+
+  auto afrag = [&](const __bf16* img, int pitch, int m, int k0) {
+    return *reinterpret_cast<const seg_bf16x8*>(img + (m * 32 + r) * pitch + k0 + 8 * h);
+  };
+  // kernel fragments come FRAGMENT-MAJOR (pn_prologue.hip, WCopyDesc.frag): the 64 lanes of fragment (32-column block cb, k-step ks)
+  // read 1 KB of consecutive bytes.  From the plain transposed copy [Cout][K] the same load touched 32 cache lines for 32 bytes each
+  // (rows K * 2 bytes apart): 2048 line requests per CU and K-chunk of seg_l2, and the stamps showed that phase at 62 cycles per MFMA
+  auto bfrag = [&](const unsigned short* wt, int K, int cb, int ks) {
+    return __builtin_bit_cast(seg_bf16x8, *reinterpret_cast<const uint4*>(wt + (((long long)cb * (K >> 4) + ks) * 64 + lane) * 8));
+  };
+
+  // ---- everything that depends on nothing is requested first: one memory round trip for all of it ----
+  // (a) the first kernel fragments of seg_l1 / seg_l2
+  seg_bf16x8 b1[4], b2[8][2];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) { b1[ks] = bfrag(a.w1t, 64, wave, ks); }
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) b2[ks][n] = bfrag(a.w2t, 512, 2 * wave + n, ks);
+  // (b) the per-channel constants (640 float4 groups + the output bias)
+  float4 cf[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int i = tid + 256 * q;                       // float4 index in the table
+    const float* src = a.gb + (long long)cloud * 512;
+    int off = i;
+    if (i >= 128) { src = a.sc1; off = i - 128; }
+    if (i >= 256) { src = a.sh1; off = i - 256; }
+    if (i >= 384) { src = a.sc2; off = i - 384; }
+    if (i >= 448) { src = a.sh2; off = i - 448; }
+    if (i >= 512) { src = a.sc3; off = i - 512; }
+    if (i >= 544) { src = a.sh3; off = i - 544; }
+    if (i >= 576) { src = a.sc4; off = i - 576; }
+    if (i >= 608) { src = a.sh4; off = i - 608; }
+    cf[q] = i < 640 ? *reinterpret_cast<const float4*>(src + 4 * off) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float b5v = (tid < SEG_CM && tid < a.C && a.b5) ? a.b5[tid] : 0.f;
+  // (c) this thread's label (the tail: waves 0 (, 1), one point per lane)
+  const int prow = 64 * wave + lane;
+  const int ylab = (a.labels && wave < MB / 2 && prow < nrows) ? a.labels[row0 + prow] : 0;
+  // (d) the output layer's kernel: two adjacent k of one class per item (one 4-byte LDS store for each image)
+  float w5v[SEG_CM * 128 / 256];
+#pragma unroll
+  for (int q = 0; q < SEG_CM * 64 / 256; ++q) {
+    const int t = tid + 256 * q, c = t >> 6, k = 2 * (t & 63);
+    w5v[2 * q] = c < a.C ? a.w5[(long long)k * a.C + c] : 0.f;
+    w5v[2 * q + 1] = c < a.C ? a.w5[(long long)(k + 1) * a.C + c] : 0.f;
+  }
+  SH_KEEP_ABOVE();
+  SH_STAMP(22);
 
   // ---- the tile's 64 input channels -> LDS (bf16 operand precision; rows past the cloud are zero rows) ----
 #pragma unroll
@@ -374,14 +452,22 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
     *reinterpret_cast<seg_bf16x8*>(Ain + row * SH_P64 + c0) = o0;
     *reinterpret_cast<seg_bf16x8*>(Ain + row * SH_P64 + c0 + 8) = o1;
   }
+  SH_STAMP(23);
+#pragma unroll
+  for (int q = 0; q < 3; ++q)
+    if (tid + 256 * q < 640) *reinterpret_cast<float4*>(coef + 4 * (tid + 256 * q)) = cf[q];
+  if (tid < SEG_CM) coef[SH_CO_B5 + tid] = b5v;
+#pragma unroll
+  for (int q = 0; q < SEG_CM * 64 / 256; ++q) {
+    const int t = tid + 256 * q, c = t >> 6, k = 2 * (t & 63);
+    const __bf16 h0 = (__bf16)w5v[2 * q], h1 = (__bf16)w5v[2 * q + 1];
+    const seg_bf16x2 hi = {h0, h1}, lo = {(__bf16)(w5v[2 * q] - (float)h0), (__bf16)(w5v[2 * q + 1] - (float)h1)};
+    *reinterpret_cast<seg_bf16x2*>(W5hi + c * SEG_WP + k) = hi;
+    *reinterpret_cast<seg_bf16x2*>(W5lo + c * SEG_WP + k) = lo;
+  }
+  SH_STAMP(1);
   SH_BARRIER();
-
-  auto afrag = [&](const __bf16* img, int pitch, int m, int k0) {
-    return *reinterpret_cast<const seg_bf16x8*>(img + (m * 32 + r) * pitch + k0 + 8 * h);
-  };
-  auto bfrag = [&](const unsigned short* wt, int K, int col, int k0) {
-    return __builtin_bit_cast(seg_bf16x8, *reinterpret_cast<const uint4*>(wt + (long long)col * K + k0 + 8 * h));
-  };
+  SH_STAMP(2);
 
   // ---- seg_l1 in four 128-channel chunks, each at once a K-chunk of seg_l2 ----
   seg_f32x16 acc2[MB][2];
@@ -391,29 +477,16 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
     for (int n = 0; n < 2; ++n)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc2[m][n][e] = 0.f;
-  const int c3 = 32 * wave + r;                             // this lane's seg_l3 / seg_l4 channel
-  // Loads return in issue order: a wait for the NEWEST load drains everything requested before it.  So the small per-channel
-  // coefficient loads go out BEFORE the fragment prefetches they would otherwise sit behind.
-  // (a layer's per-channel coefficients -- 16 registers each now -- are requested in front of that layer's MFMAs, not here: held from
-  //  the top of the kernel they cost 128 registers and spills)
-  seg_bf16x8 b1[4], b2[8][2];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks) { b1[ks] = bfrag(a.w1t, 64, 32 * wave + r, ks * 16); }
-#pragma unroll
-  for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-    for (int n = 0; n < 2; ++n) b2[ks][n] = bfrag(a.w2t, 512, 64 * wave + 32 * n + r, ks * 16);
-  SH_KEEP_ABOVE();
 #pragma unroll 1
   for (int j = 0; j < 4; ++j) {
+    if (j == 0) SH_STAMP(3);
+    if (j == 1) SH_STAMP(4);
     seg_f32x16 acc1[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc1[m][e] = 0.f;
     const int c1 = 128 * j + 32 * wave;                     // this wave's 32 seg_l1 channels of the chunk
-    const sh_coef bias = sh_load_coef(a.gb + (long long)cloud * 512, c1, h), sc = sh_load_coef(a.sc1, c1, h), sh = sh_load_coef(a.sh1, c1, h);
-    SH_KEEP_ABOVE();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
@@ -423,52 +496,66 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
     // own): behind a branch the compiler must assume at the join that the requests were NOT made and waits for everything
     const int jn = j < 3 ? j + 1 : 3;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) b1[ks] = bfrag(a.w1t, 64, 128 * jn + 32 * wave + r, ks * 16);
+    for (int ks = 0; ks < 4; ++ks) b1[ks] = bfrag(a.w1t, 64, 4 * jn + wave, ks);
     SH_KEEP_ABOVE();
+    const sh_coef bias = sh_load_coef(coef + SH_CO_GB, c1, h), sc = sh_load_coef(coef + SH_CO_SC1, c1, h), sh = sh_load_coef(coef + SH_CO_SH1, c1, h);
+    if (j == 1) SH_STAMP(5);
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
       float y[16];
       sh_bnrelu16<S16, true>(acc1[m], bias, sc, sh, y);
       sh_store16(S1c, SH_P128, m * 32 + r, 32 * wave, h, y);
     }
+    if (j == 1) SH_STAMP(6);
     SH_BARRIER();
+    if (j == 1) SH_STAMP(7);
+    // seg_l2 over this K-chunk: the activation fragments of step ks + 1 are read while the matrix cores run step ks
+    seg_bf16x8 af[2][MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) af[0][m] = afrag(S1c, SH_P128, m, 0);
 #pragma unroll
     for (int ks = 0; ks < 8; ++ks) {
+      if (ks < 7) {
+#pragma unroll
+        for (int m = 0; m < MB; ++m) af[(ks + 1) & 1][m] = afrag(S1c, SH_P128, m, (ks + 1) * 16);
+      }
 #pragma unroll
       for (int m = 0; m < MB; ++m) {
-        const seg_bf16x8 af = afrag(S1c, SH_P128, m, ks * 16);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2[ks][n], af, acc2[m][n], 0, 0, 0);
+        for (int n = 0; n < 2; ++n) acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b2[ks][n], af[ks & 1][m], acc2[m][n], 0, 0, 0);
       }
       // the registers of this step go straight to the same step of the next chunk (unconditional, as above)
 #pragma unroll
-      for (int n = 0; n < 2; ++n) b2[ks][n] = bfrag(a.w2t, 512, 64 * wave + 32 * n + r, 128 * jn + ks * 16);
+      for (int n = 0; n < 2; ++n) b2[ks][n] = bfrag(a.w2t, 512, 2 * wave + n, 8 * jn + ks);
       SH_KEEP_ABOVE();
     }
+    if (j == 1) SH_STAMP(8);
     SH_BARRIER();                                        // the chunk image is overwritten by the next chunk
+    if (j == 1) SH_STAMP(9);
   }
-  // seg_l2's coefficients, seg_l3's first eight fragments and all of seg_l4's: requested now, land under seg_l2's epilogue
-  const sh_coef sc2v[2] = {sh_load_coef(a.sc2, 64 * wave, h), sh_load_coef(a.sc2, 64 * wave + 32, h)};
-  const sh_coef sh2v[2] = {sh_load_coef(a.sh2, 64 * wave, h), sh_load_coef(a.sh2, 64 * wave + 32, h)};
+  SH_STAMP(10);
+  // seg_l3's first eight fragments and all of seg_l4's: requested now, land under seg_l2's epilogue
   seg_bf16x8 b3[8], b4[8];
 #pragma unroll
-  for (int ks = 0; ks < 8; ++ks) { b3[ks] = bfrag(a.w3t, 256, c3, ks * 16); b4[ks] = bfrag(a.w4t, 128, c3, ks * 16); }
+  for (int ks = 0; ks < 8; ++ks) { b3[ks] = bfrag(a.w3t, 256, wave, ks); b4[ks] = bfrag(a.w4t, 128, wave, ks); }
   SH_KEEP_ABOVE();
   // ---- seg_l2 -> LDS ----
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
+    const sh_coef sc2v = sh_load_coef(coef + SH_CO_SC2, 64 * wave + 32 * n, h), sh2v = sh_load_coef(coef + SH_CO_SH2, 64 * wave + 32 * n, h);
 #pragma unroll
     for (int m = 0; m < MB; ++m) {
       float y[16];
-      sh_bnrelu16<S16, false>(acc2[m][n], sc2v[n], sc2v[n], sh2v[n], y);
+      sh_bnrelu16<S16, false>(acc2[m][n], sc2v, sc2v, sh2v, y);
       sh_store16(S2, SH_P256, m * 32 + r, 64 * wave + 32 * n, h, y);
     }
   }
+  SH_STAMP(11);
   SH_BARRIER();
+  SH_STAMP(12);
   // ---- seg_l3 (256 -> 128): 32 columns per wave ----
   {
-    const sh_coef sc3v = sh_load_coef(a.sc3, 32 * wave, h), sh3v = sh_load_coef(a.sh3, 32 * wave, h);
-    SH_KEEP_ABOVE();
+    const sh_coef sc3v = sh_load_coef(coef + SH_CO_SC3, 32 * wave, h), sh3v = sh_load_coef(coef + SH_CO_SH3, 32 * wave, h);
     seg_f32x16 acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -479,7 +566,7 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
 #pragma unroll
       for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b3[ks & 7], afrag(S2, SH_P256, m, ks * 16), acc[m], 0, 0, 0);
       if (ks < 8) {                                         // steps 8..15 take over the registers of steps 0..7
-        b3[ks] = bfrag(a.w3t, 256, c3, (ks + 8) * 16);
+        b3[ks] = bfrag(a.w3t, 256, wave, ks + 8);
         SH_KEEP_ABOVE();
       }
     }
@@ -490,11 +577,12 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
       sh_store16(S3, SH_P128, m * 32 + r, 32 * wave, h, y);
     }
   }
+  SH_STAMP(13);
   SH_BARRIER();
+  SH_STAMP(14);
   // ---- seg_l4 (128 -> 128) -> the output layer's input, fp32 (it is split hi + lo there, as in seg_out_fwd) ----
   {
-    const sh_coef sc4v = sh_load_coef(a.sc4, 32 * wave, h), sh4v = sh_load_coef(a.sh4, 32 * wave, h);
-    SH_KEEP_ABOVE();
+    const sh_coef sc4v = sh_load_coef(coef + SH_CO_SC4, 32 * wave, h), sh4v = sh_load_coef(coef + SH_CO_SH4, 32 * wave, h);
     seg_f32x16 acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -514,16 +602,12 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
         *reinterpret_cast<float4*>(S4f + (m * 32 + r) * SH_PF + 32 * wave + 8 * g + 4 * h) = make_float4(y[4 * g], y[4 * g + 1], y[4 * g + 2], y[4 * g + 3]);
     }
   }
+  SH_STAMP(15);
   SH_BARRIER();                                          // seg_l3's image (region A) is dead from here
-  // ---- output layer: kernel image (bf16 hi + lo, channel-major) into region A, logits of a 32-row block per wave (waves 0, 1) ----
-  for (int t = tid; t < 32 * 128; t += 256) {
-    const int c = t >> 7, k = t & 127;
-    const float v = c < a.C ? a.w5[(long long)k * a.C + c] : 0.f;
-    const __bf16 hi = (__bf16)v;
-    W5hi[c * SEG_WP + k] = hi;
-    W5lo[c * SEG_WP + k] = (__bf16)(v - (float)hi);
-  }
-  SH_BARRIER();
+  SH_STAMP(16);
+  // ---- output layer: logits of a 32-row block per wave (waves 0 .. MB-1) from the kernel image the prologue built ----
+  SH_STAMP(17);
+  SH_STAMP(18);
   if (wave < MB) {
     seg_f32x16 acc;
 #pragma unroll
@@ -551,35 +635,55 @@ __global__ __launch_bounds__(256, MB == 2 ? 2 : 1) void seg_head_fused_kernel(co
       for (int e = 0; e < 16; ++e) lgt[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * (SEG_CM + 1) + r] = acc[e];
     }
   }
+  SH_STAMP(19);
   SH_BARRIER();
-  // ---- softmax, loss, accuracy, d(logits): one thread per point (wave 0) ----
-  if (wave < MB / 2) {                                   // waves 0 (, 1): rows 64 * wave + lane
-    const int prow = 64 * wave + lane;
+  SH_STAMP(20);
+  // ---- softmax, loss, accuracy: one thread per point (waves 0 (, 1)); no gradient leaves this kernel (frozen head), so none is formed.
+  // The probabilities go to LDS in the layout of the output and leave as whole 16-byte stores from all threads (one thread's twelve
+  // 4-byte stores 48 bytes apart were, with the gradient arithmetic and its 12 wave reductions, 27 % of the launch: 25.8 k cycles) ----
+  if (wave < MB / 2) {                                   // rows 64 * wave + lane
     float loss = 0.f, corr = 0.f;
-    float dl[SEG_CM];
-#pragma unroll
-    for (int c = 0; c < SEG_CM; ++c) dl[c] = 0.f;
     if (prow < nrows) {
-      float acc[SEG_CM];
+      float acc[SEG_CM], p[SEG_CM];
 #pragma unroll
       for (int c = 0; c < SEG_CM; ++c) {
-        acc[c] = (c < a.C && a.b5) ? a.b5[c] : 0.f;
+        acc[c] = (c < a.C && a.b5) ? coef[SH_CO_B5 + c] : 0.f;
         acc[c] += lgt[prow * (SEG_CM + 1) + c];
       }
-      seg_row_tail(acc, a.C, row0 + prow, a.labels, a.grad_scale, a.probs, a.dlogits, loss, corr, dl);
+      int am;
+      seg_row_probs(acc, a.C, p, am);
+#pragma unroll
+      for (int c = 0; c < SEG_CM; ++c)
+        if (c < a.C) prob_s[prow * a.C + c] = p[c];
+      if (a.labels) {
+        float qs;
+        seg_row_loss(p, a.C, ylab, am, loss, corr, qs);
+      }
     }
     if (a.part && r0 + 64 * wave < a.N) {             // one partial per 64 rows of a cloud, whatever the tile height
-      float* p = a.part + ((long long)cloud * ((a.N + 63) / 64) + (r0 >> 6) + wave) * (2 + SEG_CM);
+      float* pp = a.part + ((long long)cloud * ((a.N + 63) / 64) + (r0 >> 6) + wave) * (2 + SEG_CM);
       const float l = wave_sum(loss), cr = wave_sum(corr);
-      if (lane == 0) { p[0] = l; p[1] = cr; }
+      if (lane == 0) { pp[0] = l; pp[1] = cr; }
+    }
+  }
+  if (a.probs) {
+    SH_BARRIER();
+    const int n = nrows * a.C;
+    float* dst = a.probs + row0 * a.C;                  // row0 is a multiple of 64: 16-byte aligned
+    for (int i = 4 * tid; i + 3 < n; i += 1024) *reinterpret_cast<float4*>(dst + i) = *reinterpret_cast<const float4*>(prob_s + i);
+    if (tid < (n & 3)) dst[(n & ~3) + tid] = prob_s[(n & ~3) + tid];
+  }
+  if (DBG) {
+    SH_STAMP(21);
+    __syncthreads();
+    if (tid == 0 && a.probs && nrows * a.C >= 24) {                     // over the tile's first probabilities
+      unsigned* p = reinterpret_cast<unsigned*>(a.probs + row0 * a.C);
 #pragma unroll
-      for (int c = 0; c < SEG_CM; ++c) {
-        const float sdl = wave_sum(dl[c]);
-        if (lane == 0) p[2 + c] = sdl;
-      }
+      for (int i = 0; i < 24; ++i) p[i] = stamp[i];
     }
   }
 }
+#undef SH_STAMP
 #undef SH_KEEP_ABOVE
 #undef SH_BARRIER
 int seg_head_fused_rows() { return SH_ROWS; }
@@ -600,20 +704,41 @@ int seg_head_fused(const pn_operand* x, const float* gb, const void* w1t, const 
   a.w5 = w5; a.b5 = b5; a.N = N; a.C = C; a.s16 = s16;
   a.labels = labels; a.grad_scale = grad_scale; a.probs = probs; a.dlogits = dlogits; a.part = part;
   static const int force_mb = getenv("PN_SEGHEAD_MB") ? atoi(getenv("PN_SEGHEAD_MB")) : 0;     // experiment switch: 2 or 4
-  const bool tall = force_mb ? force_mb == 4 : (long long)B * cdiv(N, 128) >= 256;               // 128-row tiles while they still fill the chip
+  static const bool dbg = getenv("PN_SEGHEAD_DBG") && atoi(getenv("PN_SEGHEAD_DBG")) == 16;
+  // Two 64-row workgroups per CU (8 waves, out of phase with each other) beat one 128-row workgroup since the kernels arrive as whole
+  // fragments: 27.4 vs 30.9 us at B*N = 32,768, 93 vs 106 us at 131,072 (round 2, [C][K] copies: 52 vs 48 us -- the 64-row form streams
+  // the 424 KB of kernels twice as often and was bound by the 32-line gathers of every fragment load)
+  const bool tall = force_mb == 4;
   if (tall) {
     static const hipError_t attr1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_head_fused_kernel<4, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        sh_region_a(128) + sh_region_b(128));
+                                                        sh_lds_bytes(128));
     static const hipError_t attr0 = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_head_fused_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                        sh_region_a(128) + sh_region_b(128));
-    (void)attr1; (void)attr0;
+                                                        sh_lds_bytes(128));
+    PN_CHECK_ARG(attr1 == hipSuccess && attr0 == hipSuccess, "seg_head_fused: dynamic LDS attribute");
     a.tiles_per_cloud = cdiv(N, 128);
-    if (s16) hipLaunchKernelGGL((seg_head_fused_kernel<4, true>), dim3(B * a.tiles_per_cloud), dim3(256), sh_region_a(128) + sh_region_b(128), st, a);
-    else hipLaunchKernelGGL((seg_head_fused_kernel<4, false>), dim3(B * a.tiles_per_cloud), dim3(256), sh_region_a(128) + sh_region_b(128), st, a);
+    if (dbg && s16 && N % 128 == 0) {
+      static const hipError_t attrd = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_head_fused_kernel<4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                          sh_lds_bytes(128));
+      PN_CHECK_ARG(attrd == hipSuccess, "seg_head_fused: dynamic LDS attribute");
+      hipLaunchKernelGGL((seg_head_fused_kernel<4, true, true>), dim3(B * a.tiles_per_cloud), dim3(256), sh_lds_bytes(128), st, a);
+    } else
+    if (s16) hipLaunchKernelGGL((seg_head_fused_kernel<4, true>), dim3(B * a.tiles_per_cloud), dim3(256), sh_lds_bytes(128), st, a);
+    else hipLaunchKernelGGL((seg_head_fused_kernel<4, false>), dim3(B * a.tiles_per_cloud), dim3(256), sh_lds_bytes(128), st, a);
   } else {
     a.tiles_per_cloud = cdiv(N, 64);
-    if (s16) hipLaunchKernelGGL((seg_head_fused_kernel<2, true>), dim3(B * a.tiles_per_cloud), dim3(256), sh_region_a(64) + sh_region_b(64), st, a);
-    else hipLaunchKernelGGL((seg_head_fused_kernel<2, false>), dim3(B * a.tiles_per_cloud), dim3(256), sh_region_a(64) + sh_region_b(64), st, a);
+    static const hipError_t attr3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_head_fused_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        sh_lds_bytes(64));
+    static const hipError_t attr2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_head_fused_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                        sh_lds_bytes(64));
+    PN_CHECK_ARG(attr3 == hipSuccess && attr2 == hipSuccess, "seg_head_fused: dynamic LDS attribute");
+    if (dbg && s16 && N % 64 == 0) {
+      static const hipError_t attrd = hipFuncSetAttribute(reinterpret_cast<const void*>(&seg_head_fused_kernel<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                          sh_lds_bytes(64));
+      PN_CHECK_ARG(attrd == hipSuccess, "seg_head_fused: dynamic LDS attribute");
+      hipLaunchKernelGGL((seg_head_fused_kernel<2, true, true>), dim3(B * a.tiles_per_cloud), dim3(256), sh_lds_bytes(64), st, a);
+    } else
+    if (s16) hipLaunchKernelGGL((seg_head_fused_kernel<2, true>), dim3(B * a.tiles_per_cloud), dim3(256), sh_lds_bytes(64), st, a);
+    else hipLaunchKernelGGL((seg_head_fused_kernel<2, false>), dim3(B * a.tiles_per_cloud), dim3(256), sh_lds_bytes(64), st, a);
   }
   PN_CHECK_LAUNCH();
   return PN_OK;
