@@ -381,73 +381,139 @@ __global__ __launch_bounds__(256) void maxbwd_prep_resolve_kernel(const PrepArgs
 __global__ __launch_bounds__(256) void maxbwd_prep_kernel(const PrepArgs pa) { maxbwd_prep_body(pa, blockIdx.x); }
 
 // D[m][k] = q[k] + sum_{c : arg[b][c] == m} hs[b][c] * Wt[c][k]        one block per 32-row quarter tile.
-// Critical points are few: the 1024 arg-max rows of a cloud concentrate on a handful of points, so a tile can
-// receive anything from 0 to C contributions, many of them on the same row.  Contributions are therefore accumulated
-// with LDS atomics in 2^-40 FIXED POINT (int64): integer addition is associative, so the result does not depend on
-// the order in which the four waves process the hits -> full parallelism AND bitwise reproducibility.
-// |hs*W| < 2^22 is assumed (the products are gradient-sized).  K <= 128, K % 4 == 0.
+// Critical points are few: the 1024 arg-max rows of a cloud concentrate on a handful of points (bench.py's clouds: ~290 distinct rows,
+// the heaviest row 140 hits, the heaviest 32-row tile 170-280, the median tile 22 -- tools/scatter_probe.py), so the launch lasts as
+// long as its heaviest tile.  Round 3 form: the tile's sum is a small matrix product on the matrix cores,
+//     D_tile (32 x K) = S (32 x H) . Wg (H x K),   S[m][j] = hs of hit j if its row is m, else 0;   Wg[j] = row c_j of Wt,
+// H = the tile's hits, compacted IN CHANNEL ORDER (thread t examines channels t, t + 256, ...: one ballot per pass places every hit, 16
+// counters order the passes and waves).  Wave w owns columns 32 w .. + 31: a lane's B fragment of a 16-hit step is eight 4-byte
+// loads, each coalesced over the 32 columns (one row of Wt per half-wave), four steps' loads in flight at a time.  Both operands are split bf16 hi + lo (three products: fp32-grade, as everywhere), the k order is fixed:
+// bitwise reproducible with no atomics.  The round-1 form accumulated 2^-40 fixed-point int64 with LDS atomics (fp64 arithmetic to
+// enter and leave fixed point, ~560 same-address 64-bit atomics per wave in the heaviest tile).
+// Measured (C2, us per launch): round 1 form 15.9; one owner thread per element walking the list 34.5 (the heaviest row is a serial
+// chain); this form 14.2; with two steps per group and the next group's loads requested ahead 16.9; eight waves splitting the hit
+// list (166 registers: one workgroup per CU) 21.8.  Ablations of this form (PN_SCATTER_DBG): launch + workgroup scheduling 4.6, the
+// list 0.2, the stores 3-4.6, the hits 6.5-9 -- the heaviest tile's chain of dependent groups, with the other tiles long finished.
+// K <= 128, K % 32 == 0.
 __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restrict__ arg, const float* __restrict__ hs,
                                                              const float* __restrict__ wt, const float* __restrict__ q, int N,
-                                                             int K, int C, int quarters_per_cloud, float* __restrict__ D, int store16) {
+                                                             int K, int C, int quarters_per_cloud, float* __restrict__ D, int store16, int dbg) {
   constexpr int CHUNK = 1024;                  // channels examined per round (4 per thread)
-  constexpr double FX = 1099511627776.0;       // 2^40
-  __shared__ unsigned long long tile[32][128]; // 32 KB
-  __shared__ int hit_pk[CHUNK];                // (row << 16) | channel-in-chunk, unordered
-  __shared__ int nhit;
+  constexpr int PAD = 64;                      // the list is padded with hits of row -1 (match nothing) to whole groups
+  constexpr int GS = 4;                        // 16-hit steps per group: 32 loads per lane in flight
+  __shared__ __attribute__((aligned(16))) int s_out[32 * 128];      // the finished tile (fp32 or bf16), then:
+  int* s_row = s_out;                                               // the hit list lives in the same 16 KB while it is needed
+  int* s_c = s_out + (CHUNK + PAD);
+  float* s_h = reinterpret_cast<float*>(s_out + 2 * (CHUNK + PAD));
+  static_assert(3 * (CHUNK + PAD) <= 32 * 128, "the hit list fits the output tile's LDS");
+  __shared__ int cnt[16];                      // hits of (pass, wave)
   const int bx = blockIdx.x, cloud = bx / quarters_per_cloud, qin = bx - cloud * quarters_per_cloud;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m = lane & 31, kh = lane >> 5;
   const int rbase = qin * 32, nr = min(32, N - rbase);
   const int* ab = arg + (long long)cloud * C;
   const float* hb = hs + (long long)cloud * C;
-  for (int i = t; i < 32 * 128; i += 256) (&tile[0][0])[i] = 0ull;
-  if (t == 0) nhit = 0;
-  __syncthreads();
+  const bool wave_on = 32 * wave < K;          // this wave's 32 columns exist
+  const int kcol = wave_on ? 32 * wave + m : m;
+  const float qk = q[kcol];                    // requested with the first rows of the maxima
+  mb_f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   for (int c0 = 0; c0 < C; c0 += CHUNK) {
+    int mrow[4];
+    float hv[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c = c0 + 4 * t + i;
-      const int m = (c < C) ? (ab[c] - rbase) : -1;
-      if (m >= 0 && m < nr) hit_pk[atomicAdd(&nhit, 1)] = (m << 16) | (4 * t + i);
+      const int c = c0 + 256 * i + t;
+      mrow[i] = (c < C && !(dbg & 4)) ? ab[c] - rbase : -1;
+      hv[i] = (c < C && !(dbg & 4)) ? hb[c] : 0.f;
+    }
+    unsigned long long bal[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bal[i] = __ballot(mrow[i] >= 0 && mrow[i] < nr);
+      if (lane == 0) cnt[4 * i + wave] = __popcll(bal[i]);
     }
     __syncthreads();
-    const int total = nhit;
-    // wave w takes hits w, w+4, ...; eight of them (16 row loads per lane) are in flight at a time: the arg-max rows of a cloud
-    // concentrate on a few points, so some tiles carry hundreds of hits and the launch lasts as long as its heaviest tile
-    constexpr int UF = 8;                      // 16 in flight measured no better
-    for (int i0 = wave; i0 < total; i0 += 4 * UF) {
-      int pk[UF];
-      float h[UF], w0[UF], w1[UF];
+    int cn[16], total = 0;
 #pragma unroll
-      for (int u = 0; u < UF; ++u) {
-        const int i = min(i0 + 4 * u, total - 1);
-        pk[u] = hit_pk[i];
-        const int c = c0 + (pk[u] & 0xffff);
-        h[u] = hb[c];
-        w0[u] = wt[(long long)c * K + min(lane, K - 1)];
-        w1[u] = wt[(long long)c * K + min(lane + 64, K - 1)];
+    for (int j = 0; j < 16; ++j) { cn[j] = cnt[j]; total += cn[j]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int before = 0;                          // a pass-i hit of this wave goes behind every (pass, wave) pair that precedes (i, wave)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) before += (j < 4 * i + wave) ? cn[j] : 0;
+      if (mrow[i] >= 0 && mrow[i] < nr) {
+        const int at = before + __popcll(bal[i] & ((1ull << lane) - 1ull));
+        s_row[at] = mrow[i]; s_c[at] = 256 * i + t; s_h[at] = hv[i];
       }
+    }
+    if (t < PAD) { s_row[total + t] = -1; s_c[total + t] = 0; s_h[total + t] = 0.f; }
+    __syncthreads();
+    if (wave_on && total > 0 && !(dbg & 1)) {
+      auto load_group = [&](int j0, float (&bv)[GS][8]) {          // hits j0 + 16 s + 8 kh + e (past the list: padding)
 #pragma unroll
-      for (int u = 0; u < UF; ++u) {
-        if (i0 + 4 * u < total) {              // wave-uniform
-          const int m = pk[u] >> 16;
-          if (lane < K) atomicAdd(&tile[m][lane], (unsigned long long)__double2ll_rn((double)(h[u] * w0[u]) * FX));
-          if (lane + 64 < K) atomicAdd(&tile[m][lane + 64], (unsigned long long)__double2ll_rn((double)(h[u] * w1[u]) * FX));
+        for (int s2 = 0; s2 < GS; ++s2) {
+          const int jb = j0 + 16 * s2 + 8 * kh;
+          const int4 c0v = *reinterpret_cast<const int4*>(s_c + jb), c1v = *reinterpret_cast<const int4*>(s_c + jb + 4);
+          const int cj[8] = {c0v.x, c0v.y, c0v.z, c0v.w, c1v.x, c1v.y, c1v.z, c1v.w};
+#pragma unroll
+          for (int e = 0; e < 8; ++e) bv[s2][e] = wt[(long long)(c0 + cj[e]) * K + kcol];
         }
+      };
+      auto compute_group = [&](int j0, const float (&bv)[GS][8]) {
+#pragma unroll
+        for (int s2 = 0; s2 < GS; ++s2) {
+          if (j0 + 16 * s2 < total) {            // wave-uniform
+            const int jb = j0 + 16 * s2 + 8 * kh;
+            const int4 r0v = *reinterpret_cast<const int4*>(s_row + jb), r1v = *reinterpret_cast<const int4*>(s_row + jb + 4);
+            const float4 h0v = *reinterpret_cast<const float4*>(s_h + jb), h1v = *reinterpret_cast<const float4*>(s_h + jb + 4);
+            const int rj[8] = {r0v.x, r0v.y, r0v.z, r0v.w, r1v.x, r1v.y, r1v.z, r1v.w};
+            const float hj[8] = {h0v.x, h0v.y, h0v.z, h0v.w, h1v.x, h1v.y, h1v.z, h1v.w};
+            mb_bf16x8 ah, al, bh, bl;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              const float av = rj[e] == m ? hj[e] : 0.f;
+              ah[e] = (__bf16)av;
+              al[e] = (__bf16)(av - (float)ah[e]);
+              bh[e] = (__bf16)bv[s2][e];
+              bl[e] = (__bf16)(bv[s2][e] - (float)bh[e]);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+          }
+        }
+      };
+      constexpr int GH = 16 * GS;                // hits per group
+      for (int j0 = 0; j0 < total; j0 += GH) {
+        float bv[GS][8];
+        load_group(j0, bv);
+        compute_group(j0, bv);
       }
     }
-    __syncthreads();
-    if (t == 0) nhit = 0;
-    __syncthreads();
+    __syncthreads();                           // the list and the counters are rewritten by the next chunk
   }
-  {
-    const int k = t & 127, r0 = (t >> 7) * 16;
-    if (k < K) {
-      const float qk = q[k];
-      act_switch(store16, [&](auto h) {
-        for (int r = r0; r < min(r0 + 16, nr); ++r)
-          act_st<decltype(h)::value>(D, ((long long)cloud * N + rbase + r) * K + k, (float)((double)(long long)tile[r][k] * (1.0 / FX)) + qk);
-      });
-    }
+  // the tile leaves through LDS (over the hit list) so that every lane stores 16 contiguous bytes and a wave whole rows: the
+  // accumulator layout (a lane = one column, two rows per instruction) gave 2-byte stores, 4.6 us of the launch at B*N = 32,768
+  __syncthreads();
+  float* ot = reinterpret_cast<float*>(s_out);
+  if (wave_on) {
+    act_switch(store16, [&](auto h) {
+      constexpr bool H = decltype(h)::value;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int r = (e & 3) + 8 * (e >> 2) + 4 * kh;
+        act_st<H>(ot, (long long)r * K + kcol, acc[e] + qk);
+      }
+    });
+  }
+  __syncthreads();
+  if (!(dbg & 2)) {
+    const int es = store16 ? 2 : 4;                                   // bytes per element
+    const int row_bytes = K * es, n16 = nr * row_bytes / 16;          // K % 32 == 0: whole 16-byte pieces
+    unsigned char* dst = reinterpret_cast<unsigned char*>(D) + ((long long)cloud * N + rbase) * row_bytes;
+    for (int i = t; i < n16; i += 256) *reinterpret_cast<uint4*>(dst + 16ll * i) = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(ot) + 16 * i);
   }
 }
 
@@ -536,9 +602,11 @@ int maxbwd_q(const float* w, const float* f, int K, int C, float* q, hipStream_t
 int maxbwd_scatter(const int* arg, const float* hs, const float* wt, const float* q, int B, int N, int K, int C, float* D,
                    int store16, hipStream_t st) {
   PN_CHECK_ARG(arg && hs && wt && q && D, "maxbwd_scatter: null pointer");
-  PN_CHECK_ARG(K <= 128, "maxbwd_scatter: K must be <= 128 (K=%d)", K);
+  PN_CHECK_ARG(K <= 128 && K % 32 == 0, "maxbwd_scatter: K must be a multiple of 32, at most 128 (K=%d)", K);
   const int qpc = cdiv(N, 32);
-  hipLaunchKernelGGL(maxbwd_scatter_kernel, dim3(B * qpc), dim3(256), 0, st, arg, hs, wt, q, N, K, C, qpc, D, store16);
+  // PN_SCATTER_DBG (timing ablations, WRONG results): 1 = no hit processing, 2 = no stores, 4 = no rows of the maxima read
+  static const int dbg = getenv("PN_SCATTER_DBG") ? atoi(getenv("PN_SCATTER_DBG")) : 0;
+  hipLaunchKernelGGL(maxbwd_scatter_kernel, dim3(B * qpc), dim3(256), 0, st, arg, hs, wt, q, N, K, C, qpc, D, store16, dbg);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
