@@ -48,6 +48,10 @@ for s in "$@"; do
       cd $R
       step "pmc summary" 60 python tools/pmc_summary.py $out/pmc_fetch $out/pmc_write $out/pmc r3
       rm -f $out/pmc_fetch/*kernel_trace* $out/pmc_write/*kernel_trace* ;;
+    rprof:*) a="${s#rprof:}"; n="${a%%:*}"; sc="${a#*:}"
+      cd /tmp
+      step "rprof $n" 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/rprof -o $n -- python3 $R/$sc
+      cd $R; rm -f $out/rprof/*kernel_trace* ;;
     env:*) export "${s#env:}"; echo "env ${s#env:}" | tee -a $R/$out/summary.txt ;;
     unset:*) unset "${s#unset:}" ;;
     py:*) n=$(echo "${s#py:}" | tr -c 'A-Za-z0-9_.\n' '_' | cut -c1-40)

@@ -29,7 +29,7 @@ for B, N in ((32, 1024), (32, 4096)):
     for _ in range(3):
         outs = m.fused_loss_step(pc, y_cls, y_seg, se3, (1.0, 0.0, 0.0))
     torch.cuda.synchronize()
-    rows_per_tile = 64 if os.environ.get("PN_SEGHEAD_MB", "4") == "2" else 128
+    rows_per_tile = 64 if os.environ.get("PN_SEGHEAD_MB", "2") == "2" else 128
     raw = outs[1].contiguous().view(torch.int32).cpu().numpy().astype(np.int64) & 0xffffffff
     rows = raw.reshape(B * (N // rows_per_tile), rows_per_tile * 12)[:, :24]
     pro = np.stack([(rows[:, 22] - rows[:, 0]) & 0xffffffff, (rows[:, 23] - rows[:, 22]) & 0xffffffff, (rows[:, 1] - rows[:, 23]) & 0xffffffff], 1)
