@@ -664,7 +664,7 @@ class PointNet(torch.nn.Module):
         if training and self._dropout_rate > 0:
             if fused is not None and fused.get("keep") is not None:
                 keep = fused["keep"]
-                if keep[0].shape[0] != B * W:
+                if keep[0].numel() != B * W * 512 or keep[1].numel() != B * W * 256:
                     raise PointNetHipError(f"dropout keep masks need {B * W} rows (synchronised BatchNormalization: the rows of all ranks)")
             else:
                 if W > 1:
