@@ -268,6 +268,22 @@ def main():
         dt3 = (time.perf_counter() - t1) / 60
         out["fp32_grade"] = {"precision": "bf16x3", "ms_per_step": dt3 * 1e3, "value": B * N / dt3, "unit": "points/s", "launch": ts3.mode,
                              "note": "split bf16 MFMA operands (3 products, 16 significant bits), fp32 layer-boundary tensors; inference parity vs the fp64 oracle 7e-6"}
+        # how far the headline mode's TRAINING-mode forward is from the fp32-grade mode's on the same weights, clouds and dropout masks
+        # (batch-statistics BatchNormalization amplifies operand rounding; inference with moving statistics: 1e-4 .. 9e-4)
+        with torch.no_grad():
+            m3.params_flat.data.copy_(model.params_flat.data)
+            gk = torch.Generator().manual_seed(11)
+            keep = ((torch.rand(B, 512, generator=gk) >= 0.3).to(torch.uint8).to(dev), (torch.rand(B, 256, generator=gk) >= 0.3).to(torch.uint8).to(dev))
+            o16 = model._run_forward(pc, True, {"keep": keep})
+            o32 = m3._run_forward(pc, True, {"keep": keep})
+            torch.cuda.synchronize()
+            out["fp32_grade"]["headline_mode_vs_this_mode_training_forward"] = {
+                "classification_probability_max_abs_diff": float((o16[0] - o32[0]).abs().max()),
+                "segmentation_probability_max_abs_diff": float((o16[1] - o32[1]).abs().max()),
+                "classification_probability_rms_diff": float((o16[0] - o32[0]).pow(2).mean().sqrt()),
+                "segmentation_probability_rms_diff": float((o16[1] - o32[1]).pow(2).mean().sqrt()),
+                "class_argmax_agreement": float((o16[0].argmax(-1) == o32[0].argmax(-1)).float().mean()),
+                "part_argmax_agreement": float((o16[1].argmax(-1) == o32[1].argmax(-1)).float().mean())}
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(B, N)
