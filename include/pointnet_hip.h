@@ -168,6 +168,16 @@ int pn_weights_copy16(const float* w, int K, int C, void* w16, void* wt16, pn_st
 int pn_max_resolve(const pn_operand* x, const void* wf_hi, const void* wf_lo, const int32_t* arg_block, int B, int N, int K, int C,
                    int32_t* arg, int prec, pn_stream stream);
 
+/* the sparse term of the backward pass of ConvLayer + BatchNormalization + tf.reduce_max (pointnet/PointNet.py:242-248, 425-429; the
+ * gradient TensorFlow's tape sends to the arg-max point of every (cloud, channel), here with the layer's kernel already applied):
+ *     D[b][n][k] = q[k] + sum over the channels c with arg[b][c] == n of hs[b][c] * wt[c][k]
+ * arg (B, C) rows of the maxima (pn_max_resolve), hs (B, C) the pooled gradients already scaled by the BatchNormalization scale,
+ * wt (C, K) the kernel transposed (fp32), q (K); D (B*N, K) written in full, fp32 or bf16 (store16).  K a multiple of 32, at most 128.
+ * The sum of a row runs in ascending channel order on the matrix cores with both operands split into bf16 hi + lo (three products):
+ * exact for operands of at most 16 significant bits, bitwise reproducible. */
+int pn_maxbwd_scatter(const int32_t* arg, const float* hs, const float* wt, const float* q, int B, int N, int K, int C, float* D, int store16,
+                      pn_stream stream);
+
 /* --- data gradient of a ConvLayer: out = [relu-mask] (dz . W^T + addend), plus the two partial sums
  * BatchNormalization's backward needs (sum dy_hat, sum dy_hat*z) per channel.
  *   dz      lazy operand over (B*N, K)   (K = the layer's output width)

@@ -99,6 +99,7 @@ SIGNATURES = {
     "pn_chain_fwd_max": (_I, [_OP, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "pn_weights_copy16": (_I, [_P, _I, _I, _P, _P, _P]),
     "pn_max_resolve": (_I, [_OP, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
+    "pn_maxbwd_scatter": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I, _P]),
     "pn_conv_bwd_data": (_I, [_OP, _P, _I64, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _I, _P]),
     "pn_conv_wgrad": (_I, [_OP, _OP, _I, _I, _I, _I, _I, _P, _I, _P]),
     "pn_slab_reduce": (_I, [_P, _I, _I, _I64, _P, _P]),

@@ -63,6 +63,11 @@ int pn_max_resolve(const pn_operand* x, const void* wf_hi, const void* wf_lo, co
                    int32_t* arg, int prec, pn_stream stream) {
   return max_resolve(x, wf_hi, wf_lo, prec, arg_block, B, N, K, C, arg, S(stream));
 }
+int pn_maxbwd_scatter(const int32_t* arg, const float* hs, const float* wt, const float* q, int B, int N, int K, int C, float* D, int store16,
+                      pn_stream stream) {
+  PN_CHECK_ARG(B > 0 && N > 0 && C > 0, "pn_maxbwd_scatter: bad sizes");
+  return maxbwd_scatter(arg, hs, wt, q, B, N, K, C, D, store16, S(stream));
+}
 int pn_conv_bwd_data(const pn_operand* dz, const float* w, int64_t wcs, int B, int N, int K, int C, const float* addend,
                      const float* zmask, const float* msc, const float* msh, float* out, float* part, int prec, pn_stream stream) {
   return conv_bwd_data(dz, w, wcs, B, N, K, C, addend, zmask, msc, msh, out, part, prec, S(stream));

@@ -137,6 +137,13 @@ def max_resolve(x_op, wf, argb, B, N, K, C_, prec):
     return arg
 
 
+def maxbwd_scatter(arg, hs, wt, q, B, N, K, C_, store16=False):
+    """D[b][n][:] = q + sum over the channels whose maximum sits at row n of hs[b][c] * wt[c][:]   (fp32, or bf16 with store16)"""
+    D = torch.empty(B * N, K, device=hs.device, dtype=torch.bfloat16 if store16 else torch.float32)
+    check(lib().pn_maxbwd_scatter(ptr(arg), ptr(hs), ptr(wt), ptr(q), B, N, K, C_, ptr(D), int(store16), current_stream()), "pn_maxbwd_scatter")
+    return D
+
+
 def conv_bwd_data(dz_op, w, B, N, K, C_, prec, w_cloud_stride=0, addend=None, zmask=None, msc=None, msh=None,
                   want_stats=True):
     """prec | _lib.PN_STORE_BF16: out comes back as a bf16 tensor and addend / zmask must be bf16 tensors"""

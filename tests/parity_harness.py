@@ -154,7 +154,9 @@ def check_training_step(dev, B, N, profile, vanilla=False, precision="bf16x3", r
     kp = (keep["dropout_1"].to(torch.uint8).to(dev), keep["dropout_2"].to(torch.uint8).to(dev))
     max_ws = {"mlp_2_3": ("mm23", "m22")} if vanilla else {"mlp_2_3": ("mm23", "m22"), "input_transform": ("iT.m3", "iT.c2"),
                                                            "feature_transform": ("fT.m3", "fT.c2")}
-    m._workspace(B, N, True)
+    # every workspace byte is poisoned first (0xFF: NaN as fp32 and as bf16, -1 as an index): an entry this step does not write cannot be
+    # read back as a plausible value left by another test -- a check that touches one fails on the NaN
+    m._workspace(B, N, True).fill_(255)
     for wn, _ in max_ws.values():      # the rows of the maxima are resolved by the backward pass: mark them unwritten first
         m.workspace_tensor(wn + ".arg", B, N, True, torch.int32).fill_(-1)
     outs_g = m.fused_loss_step(pc.to(dev), y_cls.to(torch.int32).to(dev), y_seg.to(torch.int32).to(dev), se3.to(dev), lw, keep=kp)
@@ -199,6 +201,7 @@ def check_training_step(dev, B, N, profile, vanilla=False, precision="bf16x3", r
         seg_src = build_model(dev, params, vanilla, precision=precision, reg=reg)
         apply_profile(seg_src, spec)
         seg_src.keep_activations = True
+        seg_src._workspace(B, N, True).fill_(255)
         outs_k = seg_src.fused_loss_step(pc.to(dev), y_cls.to(torch.int32).to(dev), y_seg.to(torch.int32).to(dev), se3.to(dev), lw, keep=kp)
         torch.cuda.synchronize()
         assert all(torch.equal(a_, b_) for a_, b_ in zip(outs_g, outs_k)), "fused frozen head differs from the layer-by-layer plan"

@@ -408,6 +408,31 @@ def test_scan_pipeline_c5_matches_oracle(dev):
     assert torch.equal(pi.cpu().long()[safe], ref[1].argmax(-1)[safe])
 
 
+@pytest.mark.parametrize("B,N,K,C_", [(3, 1000, 128, 1024), (2, 200, 64, 1024), (2, 2048, 128, 2048), (1, 31, 128, 256)])
+@pytest.mark.parametrize("store16", [False, True])
+def test_maxbwd_scatter_is_exact_on_integer_operands(dev, B, N, K, C_, store16):
+    """pn_maxbwd_scatter (the sparse arg-max term of the max-pooled layers' data gradient, PointNet.py:242-248 under tf.GradientTape):
+    D[b][n] = q + sum of hs[b][c] * wt[c] over the channels whose maximum sits at row n.  Small-integer operands are exact in the split
+    bf16 products and in the fp32 accumulator, so the result must equal the integer sum BIT FOR BIT whatever the kernel's order --
+    ragged last tile, two 1024-channel chunks, a row that holds a third of a cloud's maxima, rows with none, both storage types."""
+    from pointcloudprocessing_amd import ops
+    g = torch.Generator().manual_seed(B * N + K + C_ + int(store16))
+    arg = torch.randint(0, N, (B, C_), generator=g, dtype=torch.int32)
+    arg[0, : C_ // 3] = N - 1                       # one heavy row in the (ragged) last tile of cloud 0
+    arg[B - 1, C_ // 2:] = arg[B - 1, C_ // 2]      # ... and one in the last cloud: half of its channels on one row
+    hs = torch.randint(-7, 8, (B, C_), generator=g).float()
+    wt = torch.randint(-9, 10, (C_, K), generator=g).float()
+    q = torch.randint(-5, 6, (K,), generator=g).float()
+    D = ops.maxbwd_scatter(arg.to(dev), hs.to(dev), wt.to(dev), q.to(dev), B, N, K, C_, store16=store16)
+    ref = q.double().expand(B * N, K).clone()
+    contrib = hs.double()[:, :, None] * wt.double()[None, :, :]                     # (B, C, K)
+    rows = (torch.arange(B)[:, None] * N + arg.long()).reshape(-1)
+    ref.index_add_(0, rows, contrib.reshape(-1, K))
+    want = ref.float().to(torch.bfloat16) if store16 else ref.float()
+    assert float(ref.abs().max()) < 2.0 ** 24
+    assert torch.equal(D.cpu(), want)
+
+
 @pytest.mark.parametrize("front", ["xyz", "x64_plain", "x64_lazy"])
 @pytest.mark.parametrize("B,N", [(3, 200), (32, 1024), (2, 4099)])
 def test_chain_kernel_equals_the_layered_launches(dev, front, B, N):
