@@ -168,6 +168,17 @@ __global__ __launch_bounds__(128) void maxbwd_dw_kernel(const DwBatch jb, int B,
   const int c = blockIdx.x;
   const float fc = J.f[c], ec = J.e[c];
   float acc[2] = {0.f, 0.f};        // K <= 256
+  // what the result needs besides the gathered rows does not depend on them: requested first (behind the loop it was one more memory
+  // round trip of a launch that is nothing but round trips)
+  float a1v[2], gwv[2], cav[2], ccv[2];
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const int k = min((int)threadIdx.x + 128 * kk, K - 1);
+    a1v[kk] = J.a1[k];
+    gwv[kk] = J.GW[(long long)k * C + c];
+    cav[kk] = x.ca ? x.ca[k] : 1.f;
+    ccv[kk] = x.cc ? x.cc[k] : 0.f;
+  }
   for (int b0 = 0; b0 < B; b0 += 128) {
     const int nb = min(128, B - b0);
     __syncthreads();
@@ -181,15 +192,16 @@ __global__ __launch_bounds__(128) void maxbwd_dw_kernel(const DwBatch jb, int B,
     for (int kk = 0; kk < 2; ++kk) {
       const int k = threadIdx.x + 128 * kk;
       if (k < K) {
-        const float ca = x.ca ? x.ca[k] : 1.f, cc = x.cc ? x.cc[k] : 0.f;
+        const float ca = cav[kk], cc = ccv[kk];
         act_switch(x.h16, [&](auto h) {
           constexpr bool H = decltype(h)::value;
-          for (int bb = 0; bb < nb; bb += 8) {
-            float v[8];
+          // 32 gathered rows in flight at a time (a batch of 32 clouds is ONE round trip; eight at a time were four), summed in the same order
+          for (int bb = 0; bb < nb; bb += 32) {
+            float v[32];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = act_ld<H>(x.s1, srow[min(bb + u, nb - 1)] + k);
+            for (int u = 0; u < 32; ++u) v[u] = act_ld<H>(x.s1, srow[min(bb + u, nb - 1)] + k);
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
+            for (int u = 0; u < 32; ++u)
               if (bb + u < nb) acc[kk] = fmaf(clamp_lo(fmaf(ca, v[u], cc), x.lo), sw[bb + u], acc[kk]);
           }
         });
@@ -200,8 +212,8 @@ __global__ __launch_bounds__(128) void maxbwd_dw_kernel(const DwBatch jb, int B,
   for (int kk = 0; kk < 2; ++kk) {
     const int k = threadIdx.x + 128 * kk;
     if (k < K) {
-      float a = fmaf(J.a1[k], fc, acc[kk]);
-      a = fmaf(-ec, J.GW[(long long)k * C + c], a);
+      float a = fmaf(a1v[kk], fc, acc[kk]);
+      a = fmaf(-ec, gwv[kk], a);
       J.dW[(long long)k * C + c] = a;
     }
   }
