@@ -162,7 +162,7 @@ int loss_tail(const float* logits, int R, int C, const int* labels, float grad_s
 // pn_maxbwd.hip
 int maxbwd_prep(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean, const float* invstd,
                 const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege, float* f, float* dgamma,
-                float* dbeta, const float* W, int K, float* Wt, float* We, hipStream_t st);
+                float* dbeta, const float* W, int K, float* Wt, float* We, hipStream_t st, float* pm_slabs = nullptr);
 int colsum_lazy(const pn_operand* x, int B, int N, int C, float* part, hipStream_t st);
 // dW of a max-pooled layer (see pn_maxbwd.hip); the layers of one pass can share a launch
 struct DwJob {
@@ -184,7 +184,7 @@ int maxbwd_scatter(const int* arg, const float* hs, const float* wt, const float
 int maxbwd_prep_resolve(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean,
                         const float* invstd, const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege,
                         float* f, float* dgamma, float* dbeta, const float* W, int K, float* Wt, float* We, const pn_operand* x,
-                        const void* wf_hi, const void* wf_lo, int prec, const int* argq, int N, int* arg, hipStream_t st);
+                        const void* wf_hi, const void* wf_lo, int prec, const int* argq, int N, int* arg, hipStream_t st, float* pm_slabs = nullptr);
 int max_resolve(const pn_operand* x, const void* wf_hi, const void* wf_lo, int prec, const int* argq, int B, int N, int K, int C, int* arg,
                 hipStream_t st);
 

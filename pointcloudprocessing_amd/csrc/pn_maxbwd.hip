@@ -19,7 +19,10 @@
 namespace pn {
 
 // block = 32 channels x 8 partitions of the clouds: h, S1, S2 -> hs (B,C), e, f, dgamma, dbeta
+typedef __attribute__((ext_vector_type(8))) __bf16 mb_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float mb_f32x16;
 struct PrepArgs {
+  float* pm_slabs;        // optional (K = 128): workgroup bx leaves its 32 channels' share of Pm = sum_c (-e_c) W[:,c] W[:,c]^T here
   const float *dg, *dg2, *g, *zstar;
   int B, C;
   const float *mean, *invstd, *scale;
@@ -125,6 +128,49 @@ __device__ __forceinline__ void maxbwd_prep_body(const PrepArgs& a, int bx) {
         }
       }
     }
+  }
+  // Round 3: this workgroup's share of Pm[k'][k] = sum_c (-e_c) W[k'][c] W[k][c] over its 32 channels, from the kernel block it already
+  // holds in LDS: A = (-e_c W[k'][c]) (the values of We), B = W[k][c], contraction over c in two 16-wide steps, both operands split
+  // into bf16 hi + lo (three products, as the weight-gradient launch that formed Pm did).  32 slabs of K x K, reduced by the launch
+  // that forms q -- the launch in between (wgrad_batch<64,64,3>, 6.6-8 us at the dependent-launch floor, three per step) is gone;
+  // these workgroups finished long before the row resolution's did.
+  if (a.pm_slabs && K == 128) {
+    __syncthreads();                              // tt: the whole block (the copy loop above only read it)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane & 31, kh = lane >> 5;
+    mb_f32x16 acc[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[kb][q] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      mb_bf16x8 ah, al;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int cc = 16 * ks + 8 * kh + q;
+        const float av = neg_s[cc] * tt[32 * wave + r][cc];
+        ah[q] = (__bf16)av;
+        al[q] = (__bf16)(av - (float)ah[q]);
+      }
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) {
+        mb_bf16x8 bh, bl;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float bv = tt[32 * kb + r][16 * ks + 8 * kh + q];
+          bh[q] = (__bf16)bv;
+          bl[q] = (__bf16)(bv - (float)bh[q]);
+        }
+        acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[kb], 0, 0, 0);
+        acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[kb], 0, 0, 0);
+        acc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[kb], 0, 0, 0);
+      }
+    }
+    float* ps = a.pm_slabs + (long long)bx * 128 * 128;
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) ps[(32 * wave + (q & 3) + 8 * (q >> 2) + 4 * kh) * 128 + 32 * kb + r] = acc[kb][q];
   }
 }
 
@@ -531,8 +577,9 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restri
 
 static PrepArgs make_prep(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean,
                           const float* invstd, const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege,
-                          float* f, float* dgamma, float* dbeta, const float* W, int K, float* Wt, float* We) {
+                          float* f, float* dgamma, float* dbeta, const float* W, int K, float* Wt, float* We, float* pm_slabs = nullptr) {
   PrepArgs a;
+  a.pm_slabs = pm_slabs;
   a.dg = dg; a.dg2 = dg2; a.g = g; a.zstar = zstar; a.B = B; a.C = C; a.mean = mean; a.invstd = invstd; a.scale = scale;
   a.batch_stats = batch_stats; a.inv_count = 1.0 / (double)count; a.hs = hs; a.e = e; a.nege = nege; a.f = f; a.dgamma = dgamma;
   a.dbeta = dbeta; a.W = W; a.K = K; a.Wt = Wt; a.We = We;
@@ -540,10 +587,11 @@ static PrepArgs make_prep(const float* dg, const float* dg2, const float* g, con
 }
 int maxbwd_prep(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean, const float* invstd,
                 const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege, float* f, float* dgamma,
-                float* dbeta, const float* W, int K, float* Wt, float* We, hipStream_t st) {
+                float* dbeta, const float* W, int K, float* Wt, float* We, hipStream_t st, float* pm_slabs) {
   PN_CHECK_ARG((dg || dg2) && g && zstar && mean && invstd && scale && hs && e && nege && f, "maxbwd_prep: null pointer");
   PN_CHECK_ARG(!W || (Wt && We && K > 0), "maxbwd_prep: the transposed copies need Wt and We");
-  const PrepArgs a = make_prep(dg, dg2, g, zstar, B, C, mean, invstd, scale, batch_stats, count, hs, e, nege, f, dgamma, dbeta, W, K, Wt, We);
+  PN_CHECK_ARG(!pm_slabs || (W && K == 128 && C % 32 == 0), "maxbwd_prep: the Pm slabs need the kernel, K = 128, C %% 32 == 0");
+  const PrepArgs a = make_prep(dg, dg2, g, zstar, B, C, mean, invstd, scale, batch_stats, count, hs, e, nege, f, dgamma, dbeta, W, K, Wt, We, pm_slabs);
   hipLaunchKernelGGL(maxbwd_prep_kernel, dim3(cdiv(C, 32)), dim3(256), 0, st, a);
   PN_CHECK_LAUNCH();
   return PN_OK;
@@ -552,8 +600,9 @@ int maxbwd_prep(const float* dg, const float* dg2, const float* g, const float* 
 int maxbwd_prep_resolve(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean,
                         const float* invstd, const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege,
                         float* f, float* dgamma, float* dbeta, const float* W, int K, float* Wt, float* We, const pn_operand* x,
-                        const void* wf_hi, const void* wf_lo, int prec, const int* argq, int N, int* arg, hipStream_t st) {
+                        const void* wf_hi, const void* wf_lo, int prec, const int* argq, int N, int* arg, hipStream_t st, float* pm_slabs) {
   PN_CHECK_ARG((dg || dg2) && g && zstar && mean && invstd && scale && hs && e && nege && f, "maxbwd_prep: null pointer");
+  PN_CHECK_ARG(!pm_slabs || (W && K == 128 && C % 32 == 0), "maxbwd_prep: the Pm slabs need the kernel, K = 128, C %% 32 == 0");
   PN_CHECK_ARG(!W || (Wt && We && K > 0), "maxbwd_prep: the transposed copies need Wt and We");
   PN_CHECK_ARG(x && x->s1 && !x->s2 && wf_hi && argq && arg, "maxbwd_prep_resolve: null pointer");
   PN_CHECK_ARG(K <= RS_KMAX && K % 16 == 0 && C % 32 == 0, "maxbwd_prep_resolve: K must be a multiple of 16, at most 128, C a multiple of 32");
@@ -561,7 +610,7 @@ int maxbwd_prep_resolve(const float* dg, const float* dg2, const float* g, const
   prec &= ~PN_STORE_BF16;
   PN_CHECK_ARG(prec == PN_PREC_BF16 || (prec == PN_PREC_BF16X3 && wf_lo), "maxbwd_prep_resolve: bad prec / missing lo weights");
   PN_CHECK_ARG(x->h16 == 0 || (x->h16 == 1 && x->ld % 8 == 0), "maxbwd_prep_resolve: 16-bit rows need ld %% 8 == 0");
-  const PrepArgs a = make_prep(dg, dg2, g, zstar, B, C, mean, invstd, scale, batch_stats, count, hs, e, nege, f, dgamma, dbeta, W, K, Wt, We);
+  const PrepArgs a = make_prep(dg, dg2, g, zstar, B, C, mean, invstd, scale, batch_stats, count, hs, e, nege, f, dgamma, dbeta, W, K, Wt, We, pm_slabs);
   const int n_prep = cdiv(C, 32), qpc = cdiv(N, 32);
   const __bf16* wh = reinterpret_cast<const __bf16*>(wf_hi);
   const __bf16* wl = reinterpret_cast<const __bf16*>(wf_lo);

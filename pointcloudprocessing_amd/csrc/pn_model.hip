@@ -157,6 +157,7 @@ struct WS {
   float *Weff1, *dWeff1, *X64, *dX64, *tmpA12, *gb, *dgb, *dGseg, *dGcls;
   float *cls_logits, *cls_dlogits, *seg_dlogits, *seg_part, *dense_part, *slabs, *slabs_main, *bpart, *s5slab, *R3eye, *regpart;
   float* sync_part = nullptr;
+  float* pm_slabs = nullptr;
   size_t slab_floats, slab_main_floats;
   float* slab_pool;          // slabs of the parameter-gradient jobs whose reduction is deferred to the end of the (phase of the) pass
   size_t slab_pool_floats;
@@ -311,6 +312,7 @@ static void plan_ws(Arena& A, WS& w, const pn_model_desc& d, int B, int N, bool 
   w.X64 = d.vanilla ? nullptr : plan_act(A, "X64", (size_t)M * 64, s16);
   w.gb = A.get<float>("gb", (size_t)Bd * 512);
   w.cls_logits = A.get<float>("cls_logits", (size_t)Bd * d.ccls);
+  w.pm_slabs = A.get<float>("pm_slabs", (size_t)32 * 128 * 128);      // the 32 prep workgroups' shares of a max-pooled layer's Pm (one layer at a time)
   w.sync_part = W > 1 ? A.get<float>("sync_part", (size_t)T * 2 * 512) : nullptr;      // all-reduced copy of a layer's per-tile partial sums
   // per 128-row block of seg_out_fwd, or per 64-row tile of the fused frozen head (never straddling clouds)
   w.seg_part = A.get<float>("seg_part", (size_t)std::max<long long>(cdivll(M, seg_out_part_rows()), (long long)B * cdiv(N, seg_head_fused_rows())) *
@@ -836,17 +838,20 @@ struct Run {
     const int K = r.cin, C = r.cout;
     const int bs = bn_batch(r.block) ? 1 : 0;
     const bool wg = tr(r.block) && G;
+    // Pm in the preparation launch itself (PN_PM_IN_PREP=0: the weight-gradient launch of rounds 1-2)
+    static const bool pm_in_prep = !(getenv("PN_PM_IN_PREP") && atoi(getenv("PN_PM_IN_PREP")) == 0);
+    float* pms = (pm_in_prep && K == 128 && C % 32 == 0 && C / 32 <= 32) ? w.pm_slabs : nullptr;
     // + the channel-major copies Wt, We = -e (.) Wt used below, and -- in the same launch, on workgroups of their own -- the rows of
     // the maxima (m.argq, left by the forward pass, -> m.arg: pn_maxbwd.hip)
     if (W > 1) {
       // synchronised BN: dG / dG2 hold every rank's clouds (Bd rows), and so do the pooled maxima: hs for all of them, the batch terms
       // e, f (and dgamma, dbeta) from the sums over ALL clouds; the rows of the maxima are resolved for this rank's clouds only
       PN_TRY(maxbwd_prep(dG, dG2, m.g_all, m.zstar_all, Bd, C, l.mean, l.invstd, l.scale, bs, M * W, m.hs, m.e, m.nege, m.f, wg ? gr(r.gamma) : nullptr,
-                         wg ? gr(r.beta) : nullptr, p(r.kernel), K, m.Wt, m.We, st));
+                         wg ? gr(r.beta) : nullptr, p(r.kernel), K, m.Wt, m.We, st, pms));
       PN_TRY(max_resolve(&xop, m.wb_hi, m.wb_lo, prec, m.argq, B, N, K, C, m.arg, st));
     } else {
     PN_TRY(maxbwd_prep_resolve(dG, dG2, m.g, m.zstar, B, C, l.mean, l.invstd, l.scale, bs, M, m.hs, m.e, m.nege, m.f, wg ? gr(r.gamma) : nullptr,
-                               wg ? gr(r.beta) : nullptr, p(r.kernel), K, m.Wt, m.We, &xop, m.wb_hi, m.wb_lo, prec, m.argq, N, m.arg, st));
+                               wg ? gr(r.beta) : nullptr, p(r.kernel), K, m.Wt, m.We, &xop, m.wb_hi, m.wb_lo, prec, m.argq, N, m.arg, st, pms));
     }
     const float* hs_loc = W > 1 ? loc(m.hs, C) : m.hs;       // this rank's clouds
     // the parameter-gradient branch forks here: it needs m.arg, hs, e, f of the launch above and nothing of what follows
@@ -882,8 +887,11 @@ struct Run {
     }
     // Pm[k'][k] = sum_c (-e_c) W[k'][c] W[k][c]: the contraction runs over the 1024 channels, so it is laid out as a
     // weight-gradient problem over "rows" c (16 slabs of 64 channels -> 16 workgroups) instead of one 128x128 tile
-    // ... and q = W f (needs only maxbwd_prep's f) rides in the launch that reduces those slabs
-    {
+    // ... and q = W f (needs only maxbwd_prep's f) rides in the launch that reduces those slabs.
+    // Round 3: the preparation workgroups form their 32 channels' share of Pm themselves (pms: C / 32 slabs) and the launch is gone.
+    if (pms) {
+      PN_TRY(slab_reduce_q(pms, C / 32, (long long)K * K, m.Pm, p(r.kernel), m.f, K, C, m.q, st));
+    } else {
       int spc;
       const int rows = (int)wgrad_slab_rows(1, C, K, K, &spc);
       float* sl = cur_slabs();

@@ -51,7 +51,7 @@ for s in "$@"; do
     rprof:*) a="${s#rprof:}"; n="${a%%:*}"; sc="${a#*:}"
       cd /tmp
       step "rprof $n" 300 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/rprof -o $n -- python3 $R/$sc
-      cd $R; rm -f $out/rprof/*kernel_trace* ;;
+      cd $R; case "$n" in trace*) ;; *) rm -f $out/rprof/*kernel_trace* ;; esac ;;
     env:*) export "${s#env:}"; echo "env ${s#env:}" | tee -a $R/$out/summary.txt ;;
     unset:*) unset "${s#unset:}" ;;
     py:*) n=$(echo "${s#py:}" | tr -c 'A-Za-z0-9_.\n' '_' | cut -c1-40)
