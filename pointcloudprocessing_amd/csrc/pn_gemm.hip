@@ -47,6 +47,7 @@ struct GemmArgs {
   // epilogue
   float* out;               // STORE: (B*N, C);  SLAB: slabs
   const float* cloud_bias;  // STORE (optional) (B, C)
+  long long cloud_bias_stride;   // elements between two clouds' rows of cloud_bias (C; 0: one row for every cloud)
   const float* addend;      // STORE (optional) (B*N, C)
   const float* zmask;       // STORE (optional) relu mask source (B*N, C)
   const float* msc;         // mask scale/shift per channel
@@ -634,7 +635,7 @@ __device__ __forceinline__ void rows_tile_t(const GemmArgs& g, const int bx, con
       const int jl = wcol0 + n * 32 + r, j = col0 + jl;
       const bool jv = j < g.C;
       float bias = 0.f, msc = 0.f, msh = 0.f;
-      if (jv && g.cloud_bias) bias = g.cloud_bias[(long long)cloud * g.C + j];
+      if (jv && g.cloud_bias) bias = g.cloud_bias[(long long)cloud * g.cloud_bias_stride + j];
       if (jv && g.zmask) { msc = g.msc[j]; msh = g.msh[j]; }
       float a1 = 0.f, a2 = 0.f;
 #pragma unroll
@@ -843,7 +844,7 @@ int conv_fwd(const pn_operand* x, const float* w, long long wcs, int B, int N, i
   g.store16 = store16;
   g.a = *x; g.w = w; g.w_cloud_stride = wcs; g.B = B; g.N = N; g.K = K; g.C = C;
   g.tiles_per_cloud = cdiv(N, 128);
-  g.out = z; g.cloud_bias = cloud_bias; g.stat_partials = stat_partials;
+  g.out = z; g.cloud_bias = cloud_bias; g.cloud_bias_stride = C; g.stat_partials = stat_partials;
   if (w16 && wcs == 0 && prec == PN_PREC_BF16 && x->h16 && (reinterpret_cast<uintptr_t>(w16) & 15) == 0 && K % 8 == 0)
     g.w16 = reinterpret_cast<const unsigned short*>(w16);
   static const int dbg = getenv("PN_GEMM_DBG") ? atoi(getenv("PN_GEMM_DBG")) : 0;
@@ -871,7 +872,7 @@ int conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C
 
 int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, int N, int K, int C, const float* addend,
                   const float* zmask, const float* msc, const float* msh, float* out, float* stat_partials, int prec,
-                  hipStream_t st, const void* w16) {
+                  hipStream_t st, const void* w16, const float* col_bias) {
   PN_TRY(check_operand(dz, "pn_conv_bwd_data.dz"));
   PN_CHECK_ARG(B > 0 && N > 0, "pn_conv_bwd_data: B and N must be positive");
   PN_CHECK_ARG(K >= 64 && K % 64 == 0, "pn_conv_bwd_data: K must be a multiple of 64 (K=%d)", K);
@@ -888,6 +889,7 @@ int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, in
   g.a = *dz; g.w = w; g.w_cloud_stride = wcs; g.B = B; g.N = N; g.K = K; g.C = C;
   g.tiles_per_cloud = cdiv(N, 128);
   g.out = out; g.addend = addend; g.zmask = zmask; g.msc = msc; g.msh = msh; g.stat_partials = stat_partials;
+  g.cloud_bias = col_bias; g.cloud_bias_stride = 0;
   if (w16 && wcs == 0 && prec == PN_PREC_BF16 && dz->h16 && (reinterpret_cast<uintptr_t>(w16) & 15) == 0 && K % 8 == 0)
     g.w16 = reinterpret_cast<const unsigned short*>(w16);
   if (dz->s2) return dispatch_bwd<true>(g, prec, st);

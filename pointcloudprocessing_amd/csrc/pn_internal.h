@@ -13,7 +13,7 @@ int conv_fwd_max(const pn_operand* x, const float* w, int B, int N, int K, int C
                  float* stat_partials, int prec, hipStream_t st);
 int conv_bwd_data(const pn_operand* dz, const float* w, long long wcs, int B, int N, int K, int C, const float* addend,
                   const float* zmask, const float* msc, const float* msh, float* out, float* stat_partials, int prec,
-                  hipStream_t st, const void* w16 = nullptr);
+                  hipStream_t st, const void* w16 = nullptr, const float* col_bias = nullptr);      // col_bias (C): added to every row
 // weight-gradient jobs whose launches are grouped by tile shape (pn_gemm.hip: conv_wgrad_batch)
 struct WgradDesc {
   pn_operand a, b;
@@ -181,6 +181,8 @@ int maxbwd_dw(const pn_operand* x, const int* arg, const float* hs, int B, int N
 int maxbwd_q(const float* w, const float* f, int K, int C, float* q, hipStream_t st);
 int maxbwd_scatter(const int* arg, const float* hs, const float* wt, const float* q, int B, int N, int K, int C, float* D,
                    int store16, hipStream_t st);
+int maxbwd_scatter_reduce(const int* arg, const float* hs, const float* wt, int B, int N, int K, int C, float* D, int store16,
+                          const float* slabs, int n_slabs, long long elems, float* pm, const float* w, const float* f, float* q, hipStream_t st);
 int maxbwd_prep_resolve(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean,
                         const float* invstd, const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege,
                         float* f, float* dgamma, float* dbeta, const float* W, int K, float* Wt, float* We, const pn_operand* x,

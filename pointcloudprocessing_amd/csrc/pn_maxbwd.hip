@@ -14,6 +14,7 @@
 // (pn_conv_wgrad / pn_conv_fwd / pn_conv_bwd_data); this file holds the small glue kernels.
 #include <cstring>
 #include "pn_common.h"
+#include "pn_slab_reduce.h"
 #include "pn_internal.h"
 
 namespace pn {
@@ -453,9 +454,9 @@ __global__ __launch_bounds__(256) void maxbwd_prep_kernel(const PrepArgs pa) { m
 // list (166 registers: one workgroup per CU) 21.8.  Ablations of this form (PN_SCATTER_DBG): launch + workgroup scheduling 4.6, the
 // list 0.2, the stores 3-4.6, the hits 6.5-9 -- the heaviest tile's chain of dependent groups, with the other tiles long finished.
 // K <= 128, K % 32 == 0.
-__global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restrict__ arg, const float* __restrict__ hs,
-                                                             const float* __restrict__ wt, const float* __restrict__ q, int N,
-                                                             int K, int C, int quarters_per_cloud, float* __restrict__ D, int store16, int dbg) {
+__device__ __forceinline__ void maxbwd_scatter_body(const int bx, const int* __restrict__ arg, const float* __restrict__ hs,
+                                                    const float* __restrict__ wt, const float* __restrict__ q, int N,
+                                                    int K, int C, int quarters_per_cloud, float* __restrict__ D, int store16, int dbg) {
   constexpr int CHUNK = 1024;                  // channels examined per round (4 per thread)
   constexpr int PAD = 64;                      // the list is padded with hits of row -1 (match nothing) to whole groups
   constexpr int GS = 4;                        // 16-hit steps per group: 32 loads per lane in flight
@@ -465,7 +466,7 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restri
   float* s_h = reinterpret_cast<float*>(s_out + 2 * (CHUNK + PAD));
   static_assert(3 * (CHUNK + PAD) <= 32 * 128, "the hit list fits the output tile's LDS");
   __shared__ int cnt[16];                      // hits of (pass, wave)
-  const int bx = blockIdx.x, cloud = bx / quarters_per_cloud, qin = bx - cloud * quarters_per_cloud;
+  const int cloud = bx / quarters_per_cloud, qin = bx - cloud * quarters_per_cloud;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m = lane & 31, kh = lane >> 5;
   const int rbase = qin * 32, nr = min(32, N - rbase);
@@ -473,7 +474,7 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restri
   const float* hb = hs + (long long)cloud * C;
   const bool wave_on = 32 * wave < K;          // this wave's 32 columns exist
   const int kcol = wave_on ? 32 * wave + m : m;
-  const float qk = q[kcol];                    // requested with the first rows of the maxima
+  const float qk = q ? q[kcol] : 0.f;          // requested with the first rows of the maxima (null: the consumer adds q itself)
   mb_f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -575,6 +576,30 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restri
   }
 }
 
+__global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restrict__ arg, const float* __restrict__ hs,
+                                                             const float* __restrict__ wt, const float* __restrict__ q, int N,
+                                                             int K, int C, int quarters_per_cloud, float* __restrict__ D, int store16, int dbg) {
+  maxbwd_scatter_body(blockIdx.x, arg, hs, wt, q, N, K, C, quarters_per_cloud, D, store16, dbg);
+}
+// Round 3: the scatter (without q: the data-gradient GEMM that consumes D adds it as a per-column constant) no longer depends on the
+// launch that reduces the Pm slabs and forms q = W f -- so that launch's workgroups ride BEHIND the scatter's (their block ids follow:
+// the heaviest tiles start at once, the reductions fill the CUs the light tiles leave): one dependent launch less per max-pooled layer
+__global__ __launch_bounds__(256) void maxbwd_scatter_reduce_kernel(const int* __restrict__ arg, const float* __restrict__ hs,
+                                                                    const float* __restrict__ wt, int N, int K, int C, int quarters_per_cloud,
+                                                                    int n_scatter, float* __restrict__ D, int store16, int dbg,
+                                                                    const float* __restrict__ slabs, int n_slabs, long long elems,
+                                                                    float* __restrict__ pm, int nb_reduce, const float* __restrict__ w,
+                                                                    const float* __restrict__ f, float* __restrict__ q) {
+  if ((int)blockIdx.x < n_scatter) {
+    maxbwd_scatter_body(blockIdx.x, arg, hs, wt, nullptr, N, K, C, quarters_per_cloud, D, store16, dbg);
+    return;
+  }
+  __shared__ float red[8][32];
+  const int bx = (int)blockIdx.x - n_scatter;
+  if (bx < nb_reduce) slab_reduce_block(slabs, n_slabs, elems, pm, bx, 0, red);
+  else slab_q_body(bx - nb_reduce, w, f, K, C, q);
+}
+
 static PrepArgs make_prep(const float* dg, const float* dg2, const float* g, const float* zstar, int B, int C, const float* mean,
                           const float* invstd, const float* scale, int batch_stats, long long count, float* hs, float* e, float* nege,
                           float* f, float* dgamma, float* dbeta, const float* W, int K, float* Wt, float* We, float* pm_slabs = nullptr) {
@@ -668,6 +693,20 @@ int maxbwd_scatter(const int* arg, const float* hs, const float* wt, const float
   // PN_SCATTER_DBG (timing ablations, WRONG results): 1 = no hit processing, 2 = no stores, 4 = no rows of the maxima read
   static const int dbg = getenv("PN_SCATTER_DBG") ? atoi(getenv("PN_SCATTER_DBG")) : 0;
   hipLaunchKernelGGL(maxbwd_scatter_kernel, dim3(B * qpc), dim3(256), 0, st, arg, hs, wt, q, N, K, C, qpc, D, store16, dbg);
+  PN_CHECK_LAUNCH();
+  return PN_OK;
+}
+
+// the scatter WITHOUT q + the reduction of n_slabs slabs of `elems` floats into pm + q = W f, one launch (the caller hands q to the
+// data-gradient GEMM as its per-column constant)
+int maxbwd_scatter_reduce(const int* arg, const float* hs, const float* wt, int B, int N, int K, int C, float* D, int store16,
+                          const float* slabs, int n_slabs, long long elems, float* pm, const float* w, const float* f, float* q, hipStream_t st) {
+  PN_CHECK_ARG(arg && hs && wt && D && slabs && pm && w && f && q, "maxbwd_scatter_reduce: null pointer");
+  PN_CHECK_ARG(K <= 128 && K % 32 == 0 && n_slabs > 0 && elems > 0, "maxbwd_scatter_reduce: bad sizes (K=%d)", K);
+  const int qpc = cdiv(N, 32), n_scatter = B * qpc, nb = (int)cdivll(elems, 32);
+  static const int dbg = getenv("PN_SCATTER_DBG") ? atoi(getenv("PN_SCATTER_DBG")) : 0;
+  hipLaunchKernelGGL(maxbwd_scatter_reduce_kernel, dim3(n_scatter + nb + cdiv(K, 4)), dim3(256), 0, st, arg, hs, wt, N, K, C, qpc, n_scatter, D, store16,
+                     dbg, slabs, n_slabs, elems, pm, nb, w, f, q);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }

@@ -890,7 +890,9 @@ struct Run {
     // ... and q = W f (needs only maxbwd_prep's f) rides in the launch that reduces those slabs.
     // Round 3: the preparation workgroups form their 32 channels' share of Pm themselves (pms: C / 32 slabs) and the launch is gone.
     if (pms) {
-      PN_TRY(slab_reduce_q(pms, C / 32, (long long)K * K, m.Pm, p(r.kernel), m.f, K, C, m.q, st));
+      // ... and the reduction + q ride behind the scatter's workgroups; q enters the data gradient as the GEMM's per-column constant
+      PN_TRY(maxbwd_scatter_reduce(m.arg, hs_loc, m.Wt, B, N, K, C, m.D, s16, pms, C / 32, (long long)K * K, m.Pm, p(r.kernel), m.f, m.q, st));
+      return conv_bwd_data(&xop, m.Pm, 0, B, N, K, K, m.D, prev.Z, prev.scale, prev.shift, prev.dy, w.bpart, prec, st, nullptr, m.q);
     } else {
       int spc;
       const int rows = (int)wgrad_slab_rows(1, C, K, K, &spc);

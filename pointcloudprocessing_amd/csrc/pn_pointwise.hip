@@ -1,6 +1,7 @@
 // Bandwidth-bound per-point kernels and the small finalisers between contractions (gfx950).
 #include <cstring>
 #include "pn_common.h"
+#include "pn_slab_reduce.h"
 #include "pn_internal.h"
 
 namespace pn {
@@ -167,45 +168,6 @@ int conv3_wgrad(const float* x3, const pn_operand* dz, int B, int N, int C, floa
   return PN_OK;
 }
 
-// ------------------------------------------------------------------------------------------------------
-// fixed-order slab reduction: out[g][e] = sum_s slabs[g*per_group+s][e]
-// ------------------------------------------------------------------------------------------------------
-// block = 32 consecutive elements x 8 partitions of the slab range; each partition is summed with 4 independent
-// accumulators, partitions are combined in a fixed order -> bitwise reproducible
-__device__ __forceinline__ void slab_reduce_block(const float* __restrict__ slabs, int per_group, long long elems, float* __restrict__ out,
-                                                  long long bx, int grp, float (*red)[32]) {
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const long long e = bx * 32 + tx;
-  float acc = 0.f;
-  if (e < elems) {
-    const float* s = slabs + (long long)grp * per_group * elems + e;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    int i = ty;
-    // four rounds (16 loads) in flight while that many remain: the reduction is a chain of memory round trips and nothing else; the
-    // four partial sums take their slabs in the same order as the one-round loop below
-    for (; i + 24 + 96 < per_group; i += 128) {
-      float x[4][4];
-#pragma unroll
-      for (int it = 0; it < 4; ++it)
-#pragma unroll
-        for (int u = 0; u < 4; ++u) x[it][u] = s[(long long)(i + 32 * it + 8 * u) * elems];
-#pragma unroll
-      for (int it = 0; it < 4; ++it) { a0 += x[it][0]; a1 += x[it][1]; a2 += x[it][2]; a3 += x[it][3]; }
-    }
-    for (; i + 24 < per_group; i += 32) {
-      const float x0 = s[(long long)i * elems], x1 = s[(long long)(i + 8) * elems];
-      const float x2 = s[(long long)(i + 16) * elems], x3 = s[(long long)(i + 24) * elems];
-      a0 += x0; a1 += x1; a2 += x2; a3 += x3;
-    }
-    for (; i < per_group; i += 8) a0 += s[(long long)i * elems];
-    acc = (a0 + a1) + (a2 + a3);
-  }
-  red[ty][tx] = acc;
-  __syncthreads();
-  if (ty == 0 && e < elems)
-    out[(long long)grp * elems + e] = ((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx])) + ((red[4][tx] + red[5][tx]) + (red[6][tx] + red[7][tx]));
-}
-
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, int per_group, long long elems,
                                                           float* __restrict__ out) {
   __shared__ float red[8][32];
@@ -242,25 +204,7 @@ __global__ __launch_bounds__(256) void slab_reduce_q_kernel(const float* __restr
     slab_reduce_block(slabs, n_slabs, elems, out, blockIdx.x, 0, red);
     return;
   }
-  const int k = ((int)blockIdx.x - nb_reduce) * 4 + (threadIdx.x >> 6);
-  if (k >= K) return;
-  const int lane = threadIdx.x & 63;
-  float s = 0.f;
-  // sixteen channel groups (32 loads) in flight per lane: at C = 1024 ONE memory round trip instead of sixteen; same order of the sum
-  for (int c0 = lane; c0 < C; c0 += 64 * 16) {
-    float fv[16], wv[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int c = min(c0 + 64 * u, C - 1);
-      fv[u] = f[c];
-      wv[u] = w[(long long)k * C + c];
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u)
-      if (c0 + 64 * u < C) s = fmaf(fv[u], wv[u], s);
-  }
-  s = wave_sum(s);
-  if (lane == 0) q[k] = s;
+  slab_q_body((int)blockIdx.x - nb_reduce, w, f, K, C, q);
 }
 
 int slab_reduce_q(const float* slabs, int n_slabs, long long elems, float* out, const float* w, const float* f, int K, int C, float* q,
