@@ -22,6 +22,7 @@
 //   C/D register g (0..15)      = D[row (g&3) + 8*(g>>2) + 4h][col r]
 #include <vector>
 #include "pn_common.h"
+#include "pn_dense_wgrad.h"
 #include "pn_internal.h"
 
 namespace pn {
@@ -525,12 +526,11 @@ struct WgradBatch {
   int n;
 };
 template <int BM, int BN, int NS, bool B2>
-__global__ __launch_bounds__(256) void wgrad_batch_kernel(const WgradBatch wb) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[GemmLds<BM, BN, NS>::BYTES];
+__device__ __forceinline__ void wgrad_batch_tile(const WgradBatch& wb, const int bxi, unsigned char* lds_raw) {
   int j = 0;
-  while (j + 1 < wb.n && (int)blockIdx.x >= wb.blk_end[j]) ++j;      // block-uniform
+  while (j + 1 < wb.n && bxi >= wb.blk_end[j]) ++j;      // block-uniform
   const int first = j ? wb.blk_end[j - 1] : 0;
-  const int local = (int)blockIdx.x - first;
+  const int local = bxi - first;
   const int nslab = wb.nslab[j], ny = wb.ny[j];
   const int n_out = (wb.blk_end[j] - first) / nslab;          // output tiles per slab
   // Block -> (slab, output tile).  The n_out tiles of a slab read the same rows of both operands; workgroups are dealt round-robin
@@ -549,6 +549,25 @@ __global__ __launch_bounds__(256) void wgrad_batch_kernel(const WgradBatch wb) {
     tile = l2 / rem;
   }
   wgrad_tile<BM, BN, NS, false, B2>(wb.g[j], bx, tile % ny, tile / ny, lds_raw);
+}
+template <int BM, int BN, int NS, bool B2>
+__global__ __launch_bounds__(256) void wgrad_batch_kernel(const WgradBatch wb) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[GemmLds<BM, BN, NS>::BYTES];
+  wgrad_batch_tile<BM, BN, NS, B2>(wb, (int)blockIdx.x, lds_raw);
+}
+
+// Round 3: the G W products of the max-pooled layers are a 96-workgroup launch (three 128 x 1024 outputs in 64 x 64 tiles) that leaves
+// most of the chip idle for its 10 us, and the dense layers' batched weight-gradient launch (13 us, ~600 workgroups) depends on nothing
+// in the backward pass's tail: its workgroups ride on the block ids behind the G W launch's own.
+template <int BM, int BN, int NS, bool B2>
+__global__ __launch_bounds__(256) void wgrad_batch_dense_kernel(const WgradBatch wb, int n_w, const DenseWgradBatch db) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[GemmLds<BM, BN, NS>::BYTES];
+  static_assert(GemmLds<BM, BN, NS>::BYTES >= 16 * 32 * 4, "the dense riders' LDS tile fits");
+  if ((int)blockIdx.x >= n_w) {                    // block-uniform
+    dense_wgrad_batch_body(db, (int)blockIdx.x - n_w, reinterpret_cast<float(*)[32]>(lds_raw));
+    return;
+  }
+  wgrad_batch_tile<BM, BN, NS, B2>(wb, (int)blockIdx.x, lds_raw);
 }
 
 // ---- the kernel ----------------------------------------------------------------------------------------
@@ -940,7 +959,8 @@ static int launch_wgrad_batch(const WgradBatch& wb, bool b2, int prec, int block
 }
 
 // jobs of the same tile shape / operand form / precision share a launch (up to WGRAD_BATCH_MAX each)
-int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st) {
+int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st, const DenseWgradJob* dense_riders, int n_dense, bool* rode) {
+  if (rode) *rode = false;
   std::vector<char> done(n > 0 ? n : 0, 0);
   // shape 3 (round 3, an experiment behind PN_WGRAD_WIDE=1): 128 x 256 output tiles for the wide jobs of the bf16 mode (seg_l2: 512 x
   // 256) -- a tile re-stages its rows of both operands, so with 128 x 128 tiles that job reads its operands three times over (402 MB
@@ -975,6 +995,15 @@ int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st) {
     }
     const bool b2 = (k & 4) != 0;
     const int prec = (k & 1) ? PN_PREC_BF16X3 : PN_PREC_BF16;
+    if (dense_riders && n_dense > 0 && rode && !*rode && k / 8 == 2 && !b2 && prec == PN_PREC_BF16X3) {
+      DenseWgradBatch db;
+      int dblocks = 0;
+      PN_TRY(make_dense_wgrad_batch(dense_riders, n_dense, db, dblocks));
+      hipLaunchKernelGGL((wgrad_batch_dense_kernel<64, 64, 3, false>), dim3((int)blocks + dblocks), dim3(256), 0, st, wb, (int)blocks, db);
+      PN_CHECK_LAUNCH();
+      *rode = true;
+      continue;
+    }
     switch (k / 8) {
       case 0: PN_TRY((launch_wgrad_batch<128, 128>(wb, b2, prec, (int)blocks, st))); break;
       case 1: PN_TRY((launch_wgrad_batch<64, 128>(wb, b2, prec, (int)blocks, st))); break;

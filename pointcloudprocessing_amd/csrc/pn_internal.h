@@ -22,7 +22,9 @@ struct WgradDesc {
   int prec, colsum;
   int small_tiles;      // 64x64 output tiles whatever the channel counts: for jobs with so few slabs that 128-wide tiles leave the chip idle
 };
-int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st);
+struct DenseWgradJob;
+// dense_riders: the dense layers' batched weight-gradient jobs, carried behind the first 64 x 64 split-operand batch (*rode tells whether)
+int conv_wgrad_batch(const WgradDesc* jobs, int n, hipStream_t st, const DenseWgradJob* dense_riders = nullptr, int n_dense = 0, bool* rode = nullptr);
 int conv_wgrad(const pn_operand* a, const pn_operand* b, int B, int N, int Ci, int Cj, int slab_rows, float* slabs, int prec,
                hipStream_t st, int colsum = 0);   // colsum: every slab is followed by Ci floats = sum over its rows of operand a
 

@@ -438,7 +438,16 @@ struct Run {
     wg_jobs.clear();
     if (rc == PN_OK && !jobs.empty()) rc = slab_reduce_batch(jobs.data(), (int)jobs.size(), st);
     jobs.clear();
-    if (rc == PN_OK && !gw_jobs.empty()) rc = conv_wgrad_batch(gw_jobs.data(), (int)gw_jobs.size(), st);
+    // the dense layers' weight gradients (independent of everything here) ride behind the G W products' 96 workgroups (PN_DENSE_RIDE=0: a
+    // launch of their own at the end, as before)
+    static const bool dense_ride = !(getenv("PN_DENSE_RIDE") && atoi(getenv("PN_DENSE_RIDE")) == 0);
+    bool rode = false;
+    if (rc == PN_OK && !gw_jobs.empty()) {
+      if (dense_ride && !dense_jobs.empty() && dense_jobs.size() <= (size_t)DENSE_WGRAD_MAX_JOBS)
+        rc = conv_wgrad_batch(gw_jobs.data(), (int)gw_jobs.size(), st, dense_jobs.data(), (int)dense_jobs.size(), &rode);
+      else rc = conv_wgrad_batch(gw_jobs.data(), (int)gw_jobs.size(), st);
+    }
+    if (rode) dense_jobs.clear();
     gw_jobs.clear();
     for (auto& f : after_jobs) {
       if (rc != PN_OK) break;
