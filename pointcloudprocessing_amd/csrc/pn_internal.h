@@ -36,7 +36,8 @@ int conv_fwd_max_panel(const pn_operand* x, const void* wf_hi, const void* wf_lo
 int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const long long* colacc, const void* wf_hi, const void* wf_lo, int prec,
                    int B, int N, int K, int C, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps,
                    int use_batch, int update, float* mean, float* invstd, float* scale, float* shift, float* g, float* zstar, int* argq,
-                   hipStream_t st, int count_mult = 1);   // count_mult: the statistics were summed over that many ranks (synchronised BN)
+                   hipStream_t st, int count_mult = 1,    // count_mult: the statistics were summed over that many ranks (synchronised BN)
+                   const struct WgradDesc* gram = nullptr);   // a 128-multiple, bf16, single-source weight-gradient job carried behind the finaliser
 
 // inference: ConvLayer(3 | 64 -> 64) -> ConvLayer(64 -> 128) -> ConvLayer(128 -> 1024) -> reduce_max in one launch (pn_panel.hip: chain_max_kernel);
 // exactly one of x (64-channel bf16 lazy operand, with w1t = the first kernel's transposed bf16 copy) and xyz (with w1 = the (3, 64) kernel)

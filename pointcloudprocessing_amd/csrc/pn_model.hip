@@ -133,6 +133,8 @@ struct ML {   // extra state of a max-pooled layer
   long long* pa1;
   float *g_all = nullptr, *zstar_all = nullptr;   // synchronised BatchNormalization: the pooled features / pre-BN maxima of ALL ranks' clouds
   float *pmax, *sumsq, *g, *zstar, *hs, *e, *nege, *f, *a1part, *a1, *gram, *GW, *Pm, *q, *D, *Wt, *We, *dG;
+  float* gram_slabs = nullptr;     // the Gram job's slabs when the forward pass's finaliser carries it (gram_rides)
+  int gram_rows = 0, gram_spc = 0;
   int *pq, *argq, *arg;            // per tile: 32-row block of the maximum; per cloud: the same after the reduction; the row (backward)
   unsigned short *wb_hi, *wb_lo;   // fragment-ordered bf16 copies of the kernel for the panel kernel (pn_panel.hip)
   int T64, tpc64, rows;   // panel tiles (all clouds / per cloud) and rows per panel
@@ -242,6 +244,10 @@ static void plan_ml(Arena& A, ML& m, const char* nm, int B, int N, long long M, 
     m.nege = A.get<float>((n + ".nege").c_str(), C);
     m.f = A.get<float>((n + ".f").c_str(), C);
     m.gram = A.get<float>((n + ".gram").c_str(), (size_t)K * K + K);   // A^T A followed by a1 = A^T 1 (one slab reduction for both)
+    if (K == 128) {                  // slabs of the Gram job when it rides behind the forward pass's finaliser: 128 slabs in all
+      m.gram_rows = (int)wgrad_slab_rows(B, N, K, K, &m.gram_spc, 128);
+      m.gram_slabs = A.get<float>((n + ".gram_slabs").c_str(), (size_t)B * m.gram_spc * ((size_t)K * K + K));
+    }
     m.a1 = m.gram + (size_t)K * K;
     m.a1part = nullptr;
     m.GW = A.get<float>((n + ".GW").c_str(), (size_t)K * C);
@@ -565,6 +571,15 @@ struct Run {
                     st, (wcs == 0 && W == p(r.kernel)) ? l.wt16 : nullptr));
     return bn_fin(l, r);
   }
+  // Experiment (PN_GRAM_RIDE=1; off by default: measured SLOWER): the Gram matrix of a max-pooled layer's input (what its Gram-form
+  // backward needs: forward activations only) rides behind the forward pass's finaliser instead of waiting for the backward pass's
+  // tail.  A lone 256-workgroup weight-gradient job is a 12-15 us chain of dependent chunk loads, the finaliser it rides behind 7.5 us:
+  // the launch grew to 15.1 us, +22.8 us per step against the 17.8 us tail launch it removes (C2 0.738 -> 0.749 ms).  Work hides behind
+  // a launch only if its own chain is shorter than that launch's.  The same predicate in both passes.
+  bool gram_rides(const ML& m, const LRef& r) const {
+    static const bool on = getenv("PN_GRAM_RIDE") && atoi(getenv("PN_GRAM_RIDE")) == 1;
+    return on && training && tr(r.block) && G && W == 1 && !aux && m.gram_slabs && r.cin == 128 && s16 && (prec & ~PN_STORE_BF16) == PN_PREC_BF16;
+  }
   int fwd_max(CL& l, ML& m, const LRef& r, const pn_operand& x, int prof_slot) {
     const int ub = bn_batch(r.block) ? 1 : 0;
     void** ev = io.prof_events;
@@ -576,8 +591,10 @@ struct Run {
       PN_TRY(sync_sum(m.pa1, m.pa1, (long long)B * r.cin * ((prec & ~PN_STORE_BF16) == PN_PREC_BF16X3 ? 2 : 1), 1));
     }
     // one finaliser: the layer's BatchNormalization coefficients (+ moving statistics) and the reduce_max over each cloud's panels
+    WgradDesc gram{x, x, B, N, r.cin, r.cin, m.gram_rows, m.gram_slabs, prec, 1, 0};
     PN_TRY(panel_finalize(m.pmax, m.pq, m.sumsq, m.pa1, m.wb_hi, m.wb_lo, prec, B, N, r.cin, r.cout, p(r.gamma), p(r.beta), p(r.mm), p(r.mv), d.bn_momentum, d.bn_eps, ub,
-                          ub, l.mean, l.invstd, l.scale, l.shift, W > 1 ? loc(m.g_all, r.cout) : m.g, W > 1 ? loc(m.zstar_all, r.cout) : m.zstar, m.argq, st, W));
+                          ub, l.mean, l.invstd, l.scale, l.shift, W > 1 ? loc(m.g_all, r.cout) : m.g, W > 1 ? loc(m.zstar_all, r.cout) : m.zstar, m.argq, st, W,
+                          gram_rides(m, r) ? &gram : nullptr));
     if (W > 1) {                 // the dense layers behind the pool see every rank's clouds; the backward needs every rank's maxima
       PN_TRY(sync_gather_rows(m.g_all, (long long)B * r.cout));
       PN_TRY(sync_gather_rows(m.zstar_all, (long long)B * r.cout));
@@ -871,6 +888,10 @@ struct Run {
       const float* Wk = p(r.kernel);
       // this whole branch feeds only dW: the Gram slabs are reduced with the other deferred jobs and the two consumers follow them
       PN_TRY(side([=] {
+        if (gram_rides(mm, r)) {       // the slabs were written in the forward pass (fwd_max): only their reduction is left, with the others
+          jobs.push_back(SlabJob{mm.gram_slabs, mm.gram, (long long)K * K + K, B * mm.gram_spc});
+          last_deferred = true;
+        } else
         PN_TRY(wgrad_general(xop, xop, B, N, K, K, mm.gram, false, prec, true, true));   // Gram matrix and a1 = column sums together
         // G W in weight-gradient form: out[k][c] = sum_k' G[k'][k] W[k'][c] over ONE slab of K rows written straight into GW (G is
         // symmetric up to the rounding of its cross terms); in that form the three layers can share a launch (conv_wgrad_batch)

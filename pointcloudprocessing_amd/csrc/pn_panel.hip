@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include "pn_common.h"
 #include "pn_internal.h"
+#include "pn_gemm_core.h"
 
 namespace pn {
 
@@ -886,17 +887,17 @@ struct PanelFinArgs {
   int* argq;
 };
 constexpr int PANEL_FIN_MAXK = 128;
-__global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs a) {
+__device__ __forceinline__ void panel_finalize_body(const PanelFinArgs& a, const int bxi, const int byi) {
   __shared__ double red[8][2][32];
   __shared__ double A1[2 * PANEL_FIN_MAXK];
   __shared__ long long A1part[2 * PANEL_FIN_MAXK];   // [group][column]: 256 entries whatever the split
   __shared__ float sc_s[32], sh_s[32], sg_s[32];
   const int tid = threadIdx.x, cl = tid & 31, part = tid >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  const int c = bxi * 32 + cl;
   const float gam = a.gamma[c];
   const float sg = gam < 0.f ? -1.f : 1.f;
   // the first cloud's slot maxima of this thread: requested now, used after the statistics
-  const int b0 = blockIdx.y * 8 + part;
+  const int b0 = byi * 8 + part;
   float pre_v[8];
   int pre_q[8];
   {
@@ -995,7 +996,7 @@ __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs 
       const float scl = gam * is;
       const float sft = a.beta[c] - (float)mean * scl;
       sc_s[cl] = scl; sh_s[cl] = sft; sg_s[cl] = sg;
-      if (blockIdx.y == 0) {
+      if (byi == 0) {
         a.mean[c] = (float)mean; a.invstd[c] = is; a.scale[c] = scl; a.shift[c] = sft;
         if (a.update) {
           a.mm[c] = a.momentum * a.mm[c] + (1.f - a.momentum) * (float)mean;
@@ -1009,12 +1010,12 @@ __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs 
     const float scl = gam * is;
     const float sft = a.beta[c] - mean * scl;
     sc_s[cl] = scl; sh_s[cl] = sft; sg_s[cl] = sg;
-    if (blockIdx.y == 0) { a.mean[c] = mean; a.invstd[c] = is; a.scale[c] = scl; a.shift[c] = sft; }
+    if (byi == 0) { a.mean[c] = mean; a.invstd[c] = is; a.scale[c] = scl; a.shift[c] = sft; }
   }
   __syncthreads();
   // per cloud: thread <-> (channel, cloud); this block's slice of the clouds
   const float scl = sc_s[cl], sft = sh_s[cl], sgc = sg_s[cl];
-  for (int b = blockIdx.y * 8 + part; b < a.B; b += 8 * gridDim.y) {
+  for (int b = byi * 8 + part; b < a.B; b += 8 * gridDim.y) {
     float best = -INFINITY;
     int bq = 0;
     const long long base = (long long)b * a.tpc * a.C + c;
@@ -1043,11 +1044,23 @@ __global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs 
     if (a.argq) a.argq[o] = (bq >= 0 && bq < a.n_blocks32) ? bq : 0;     // NaN inputs leave no winner: keep the index in range
   }
 }
+__global__ __launch_bounds__(256) void panel_finalize_kernel(const PanelFinArgs a) { panel_finalize_body(a, blockIdx.x, blockIdx.y); }
+// Round 3: the finaliser is 128 workgroups on a 256-CU chip, and the Gram matrix A^T A (+ column sums) of the layer's INPUT -- what
+// the Gram-form backward of this layer needs, formed from forward activations only -- was a weight-gradient launch of the backward
+// pass's tail (three layers: 17.8 us).  Its workgroups ride on the block ids behind the finaliser's (training, layer trainable).
+__global__ __launch_bounds__(256) void panel_finalize_gram_kernel(const PanelFinArgs a, int nx, int n_fin, const WgradBatch wb) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds_raw[GemmLds<128, 128, 1>::BYTES];
+  if ((int)blockIdx.x < n_fin) {                  // block-uniform
+    panel_finalize_body(a, (int)blockIdx.x % nx, (int)blockIdx.x / nx);
+    return;
+  }
+  wgrad_batch_tile<128, 128, 1, false>(wb, (int)blockIdx.x - n_fin, lds_raw);
+}
 
 int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const long long* colacc, const void* wf_hi, const void* wf_lo, int prec,
                    int B, int N, int K, int C, const float* gamma, const float* beta, float* mm, float* mv, float momentum, float eps,
                    int use_batch, int update, float* mean, float* invstd, float* scale, float* shift, float* g, float* zstar, int* argq,
-                   hipStream_t st, int count_mult) {
+                   hipStream_t st, int count_mult, const WgradDesc* gram) {
   PN_CHECK_ARG(pmax && pq && gamma && beta && mm && mv && mean && invstd && scale && shift && g, "pn_panel_finalize: null pointer");
   prec &= ~PN_STORE_BF16;
   PN_CHECK_ARG(!use_batch || (sumsq && colacc && wf_hi && (prec != PN_PREC_BF16X3 || wf_lo)),
@@ -1065,6 +1078,16 @@ int panel_finalize(const float* pmax, const int* pq, const float* sumsq, const l
   a.gamma = gamma; a.beta = beta; a.mm = mm; a.mv = mv; a.momentum = momentum; a.eps = eps; a.use_batch = use_batch; a.update = update;
   a.mean = mean; a.invstd = invstd; a.scale = scale; a.shift = shift; a.g = g; a.zstar = zstar; a.argq = argq;
   const int slices = B >= 32 ? 4 : (B >= 16 ? 2 : 1);      // the statistics are recomputed per slice: a few, for parallelism over the clouds
+  if (gram) {          // the Gram matrix of the layer's input rides behind the finaliser's workgroups (128 x 128 tiles, bf16 operands)
+    WgradBatch wb;
+    int wblocks = 0;
+    PN_CHECK_ARG((gram->prec & ~PN_STORE_BF16) == PN_PREC_BF16 && !gram->b.s2, "pn_panel_finalize: the riding Gram job is a bf16, single-source job");
+    PN_TRY(wgrad_batch_one(*gram, 128, 128, wb, wblocks));
+    const int n_fin = (C / 32) * slices;
+    hipLaunchKernelGGL(panel_finalize_gram_kernel, dim3(n_fin + wblocks), dim3(256), 0, st, a, C / 32, n_fin, wb);
+    PN_CHECK_LAUNCH();
+    return PN_OK;
+  }
   hipLaunchKernelGGL(panel_finalize_kernel, dim3(C / 32, slices), dim3(256), 0, st, a);
   PN_CHECK_LAUNCH();
   return PN_OK;
