@@ -261,11 +261,14 @@ def main():
         for _ in range(13):
             ts3.run()
         torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(60):
-            ts3.run()
-        torch.cuda.synchronize()
-        dt3 = (time.perf_counter() - t1) / 60
+        batches = []                       # the median of three batches of 20 steps: a batch now and then runs 15-20 % slow on this pool
+        for _ in range(3):
+            t1 = time.perf_counter()
+            for _ in range(20):
+                ts3.run()
+            torch.cuda.synchronize()
+            batches.append((time.perf_counter() - t1) / 20)
+        dt3 = sorted(batches)[1]
         out["fp32_grade"] = {"precision": "bf16x3", "ms_per_step": dt3 * 1e3, "value": B * N / dt3, "unit": "points/s", "launch": ts3.mode,
                              "note": "split bf16 MFMA operands (3 products, 16 significant bits), fp32 layer-boundary tensors; inference parity vs the fp64 oracle 7e-6"}
         # how far the headline mode's TRAINING-mode forward is from the fp32-grade mode's on the same weights, clouds and dropout masks
