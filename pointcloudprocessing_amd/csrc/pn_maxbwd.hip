@@ -454,30 +454,35 @@ __global__ __launch_bounds__(256) void maxbwd_prep_kernel(const PrepArgs pa) { m
 // list (166 registers: one workgroup per CU) 21.8.  Ablations of this form (PN_SCATTER_DBG): launch + workgroup scheduling 4.6, the
 // list 0.2, the stores 3-4.6, the hits 6.5-9 -- the heaviest tile's chain of dependent groups, with the other tiles long finished.
 // K <= 128, K % 32 == 0.
+// RB: 32-row blocks per tile (1: 32-row tiles; 2: 64-row tiles for clouds of 2048 points and more -- a cloud has C hits whatever its size, and a
+// workgroup costs a fixed chain of round trips: half the workgroups, the same hits)
+template <int RB>
 __device__ __forceinline__ void maxbwd_scatter_body(const int bx, const int* __restrict__ arg, const float* __restrict__ hs,
                                                     const float* __restrict__ wt, const float* __restrict__ q, int N,
                                                     int K, int C, int quarters_per_cloud, float* __restrict__ D, int store16, int dbg) {
   constexpr int CHUNK = 1024;                  // channels examined per round (4 per thread)
   constexpr int PAD = 64;                      // the list is padded with hits of row -1 (match nothing) to whole groups
   constexpr int GS = 4;                        // 16-hit steps per group: 32 loads per lane in flight
-  __shared__ __attribute__((aligned(16))) int s_out[32 * 128];      // the finished tile (fp32 or bf16), then:
+  __shared__ __attribute__((aligned(16))) int s_out[32 * RB * 128]; // the finished tile (fp32 or bf16), then:
   int* s_row = s_out;                                               // the hit list lives in the same 16 KB while it is needed
   int* s_c = s_out + (CHUNK + PAD);
   float* s_h = reinterpret_cast<float*>(s_out + 2 * (CHUNK + PAD));
-  static_assert(3 * (CHUNK + PAD) <= 32 * 128, "the hit list fits the output tile's LDS");
+  static_assert(3 * (CHUNK + PAD) <= 32 * RB * 128, "the hit list fits the output tile's LDS");
   __shared__ int cnt[16];                      // hits of (pass, wave)
   const int cloud = bx / quarters_per_cloud, qin = bx - cloud * quarters_per_cloud;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int m = lane & 31, kh = lane >> 5;
-  const int rbase = qin * 32, nr = min(32, N - rbase);
+  const int rbase = qin * 32 * RB, nr = min(32 * RB, N - rbase);
   const int* ab = arg + (long long)cloud * C;
   const float* hb = hs + (long long)cloud * C;
   const bool wave_on = 32 * wave < K;          // this wave's 32 columns exist
   const int kcol = wave_on ? 32 * wave + m : m;
   const float qk = q ? q[kcol] : 0.f;          // requested with the first rows of the maxima (null: the consumer adds q itself)
-  mb_f32x16 acc;
+  mb_f32x16 acc[RB];
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[rb][e] = 0.f;
   for (int c0 = 0; c0 < C; c0 += CHUNK) {
     int mrow[4];
     float hv[4];
@@ -529,18 +534,25 @@ __device__ __forceinline__ void maxbwd_scatter_body(const int bx, const int* __r
             const float4 h0v = *reinterpret_cast<const float4*>(s_h + jb), h1v = *reinterpret_cast<const float4*>(s_h + jb + 4);
             const int rj[8] = {r0v.x, r0v.y, r0v.z, r0v.w, r1v.x, r1v.y, r1v.z, r1v.w};
             const float hj[8] = {h0v.x, h0v.y, h0v.z, h0v.w, h1v.x, h1v.y, h1v.z, h1v.w};
-            mb_bf16x8 ah, al, bh, bl;
+            mb_bf16x8 bh, bl;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-              const float av = rj[e] == m ? hj[e] : 0.f;
-              ah[e] = (__bf16)av;
-              al[e] = (__bf16)(av - (float)ah[e]);
               bh[e] = (__bf16)bv[s2][e];
               bl[e] = (__bf16)(bv[s2][e] - (float)bh[e]);
             }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+              mb_bf16x8 ah, al;
+#pragma unroll
+              for (int e = 0; e < 8; ++e) {
+                const float av = rj[e] == 32 * rb + m ? hj[e] : 0.f;
+                ah[e] = (__bf16)av;
+                al[e] = (__bf16)(av - (float)ah[e]);
+              }
+              acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[rb], 0, 0, 0);
+              acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[rb], 0, 0, 0);
+            }
           }
         }
       };
@@ -561,10 +573,12 @@ __device__ __forceinline__ void maxbwd_scatter_body(const int bx, const int* __r
     act_switch(store16, [&](auto h) {
       constexpr bool H = decltype(h)::value;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int r = (e & 3) + 8 * (e >> 2) + 4 * kh;
-        act_st<H>(ot, (long long)r * K + kcol, acc[e] + qk);
-      }
+      for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int r = 32 * rb + (e & 3) + 8 * (e >> 2) + 4 * kh;
+          act_st<H>(ot, (long long)r * K + kcol, acc[rb][e] + qk);
+        }
     });
   }
   __syncthreads();
@@ -576,14 +590,16 @@ __device__ __forceinline__ void maxbwd_scatter_body(const int bx, const int* __r
   }
 }
 
+template <int RB>
 __global__ __launch_bounds__(256) void maxbwd_scatter_kernel(const int* __restrict__ arg, const float* __restrict__ hs,
                                                              const float* __restrict__ wt, const float* __restrict__ q, int N,
                                                              int K, int C, int quarters_per_cloud, float* __restrict__ D, int store16, int dbg) {
-  maxbwd_scatter_body(blockIdx.x, arg, hs, wt, q, N, K, C, quarters_per_cloud, D, store16, dbg);
+  maxbwd_scatter_body<RB>(blockIdx.x, arg, hs, wt, q, N, K, C, quarters_per_cloud, D, store16, dbg);
 }
 // Round 3: the scatter (without q: the data-gradient GEMM that consumes D adds it as a per-column constant) no longer depends on the
 // launch that reduces the Pm slabs and forms q = W f -- so that launch's workgroups ride BEHIND the scatter's (their block ids follow:
 // the heaviest tiles start at once, the reductions fill the CUs the light tiles leave): one dependent launch less per max-pooled layer
+template <int RB>
 __global__ __launch_bounds__(256) void maxbwd_scatter_reduce_kernel(const int* __restrict__ arg, const float* __restrict__ hs,
                                                                     const float* __restrict__ wt, int N, int K, int C, int quarters_per_cloud,
                                                                     int n_scatter, float* __restrict__ D, int store16, int dbg,
@@ -591,7 +607,7 @@ __global__ __launch_bounds__(256) void maxbwd_scatter_reduce_kernel(const int* _
                                                                     float* __restrict__ pm, int nb_reduce, const float* __restrict__ w,
                                                                     const float* __restrict__ f, float* __restrict__ q) {
   if ((int)blockIdx.x < n_scatter) {
-    maxbwd_scatter_body(blockIdx.x, arg, hs, wt, nullptr, N, K, C, quarters_per_cloud, D, store16, dbg);
+    maxbwd_scatter_body<RB>(blockIdx.x, arg, hs, wt, nullptr, N, K, C, quarters_per_cloud, D, store16, dbg);
     return;
   }
   __shared__ float red[8][32];
@@ -689,10 +705,15 @@ int maxbwd_scatter(const int* arg, const float* hs, const float* wt, const float
                    int store16, hipStream_t st) {
   PN_CHECK_ARG(arg && hs && wt && q && D, "maxbwd_scatter: null pointer");
   PN_CHECK_ARG(K <= 128 && K % 32 == 0, "maxbwd_scatter: K must be a multiple of 32, at most 128 (K=%d)", K);
-  const int qpc = cdiv(N, 32);
   // PN_SCATTER_DBG (timing ablations, WRONG results): 1 = no hit processing, 2 = no stores, 4 = no rows of the maxima read
   static const int dbg = getenv("PN_SCATTER_DBG") ? atoi(getenv("PN_SCATTER_DBG")) : 0;
-  hipLaunchKernelGGL(maxbwd_scatter_kernel, dim3(B * qpc), dim3(256), 0, st, arg, hs, wt, q, N, K, C, qpc, D, store16, dbg);
+  if (N >= 2048) {
+    const int qpc = cdiv(N, 64);
+    hipLaunchKernelGGL(maxbwd_scatter_kernel<2>, dim3(B * qpc), dim3(256), 0, st, arg, hs, wt, q, N, K, C, qpc, D, store16, dbg);
+  } else {
+    const int qpc = cdiv(N, 32);
+    hipLaunchKernelGGL(maxbwd_scatter_kernel<1>, dim3(B * qpc), dim3(256), 0, st, arg, hs, wt, q, N, K, C, qpc, D, store16, dbg);
+  }
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
@@ -703,10 +724,15 @@ int maxbwd_scatter_reduce(const int* arg, const float* hs, const float* wt, int 
                           const float* slabs, int n_slabs, long long elems, float* pm, const float* w, const float* f, float* q, hipStream_t st) {
   PN_CHECK_ARG(arg && hs && wt && D && slabs && pm && w && f && q, "maxbwd_scatter_reduce: null pointer");
   PN_CHECK_ARG(K <= 128 && K % 32 == 0 && n_slabs > 0 && elems > 0, "maxbwd_scatter_reduce: bad sizes (K=%d)", K);
-  const int qpc = cdiv(N, 32), n_scatter = B * qpc, nb = (int)cdivll(elems, 32);
+  const int rb = N >= 2048 ? 2 : 1;
+  const int qpc = cdiv(N, 32 * rb), n_scatter = B * qpc, nb = (int)cdivll(elems, 32);
   static const int dbg = getenv("PN_SCATTER_DBG") ? atoi(getenv("PN_SCATTER_DBG")) : 0;
-  hipLaunchKernelGGL(maxbwd_scatter_reduce_kernel, dim3(n_scatter + nb + cdiv(K, 4)), dim3(256), 0, st, arg, hs, wt, N, K, C, qpc, n_scatter, D, store16,
-                     dbg, slabs, n_slabs, elems, pm, nb, w, f, q);
+  if (rb == 2)
+    hipLaunchKernelGGL(maxbwd_scatter_reduce_kernel<2>, dim3(n_scatter + nb + cdiv(K, 4)), dim3(256), 0, st, arg, hs, wt, N, K, C, qpc, n_scatter, D,
+                       store16, dbg, slabs, n_slabs, elems, pm, nb, w, f, q);
+  else
+    hipLaunchKernelGGL(maxbwd_scatter_reduce_kernel<1>, dim3(n_scatter + nb + cdiv(K, 4)), dim3(256), 0, st, arg, hs, wt, N, K, C, qpc, n_scatter, D,
+                       store16, dbg, slabs, n_slabs, elems, pm, nb, w, f, q);
   PN_CHECK_LAUNCH();
   return PN_OK;
 }
